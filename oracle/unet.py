@@ -1,0 +1,273 @@
+"""ORACLE (test infrastructure, NOT product code): CPU fp32 restatement of the reference's two
+in-scope networks as *pure functions over a state dict*.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product path (brats21_amd/) never does and has no CPU fallback.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).  The
+state-dict key names are the reference's own, so the same ``sd`` can be loaded
+into the reference modules (tests/golden/make_golden.py does exactly that to pin this oracle) and
+into the product modules.  Layout here is the reference's NCDHW; arithmetic is stock torch CPU ops
+(F.conv3d, F.group_norm, F.max_pool3d, F.interpolate), i.e. the same ATen kernels the reference's
+CPU path executes.
+
+Pinning status: ``equiunet_forward`` is pinned by tests/golden/equiunet_*.npz (generated from the
+reference source itself).  ``assp_evo_forward`` is pinned against the reference source *under the
+MONAI stub* (oracle/refshim.py) -- parity unpinned at the MONAI boundary (MaxAvgPool,
+ResidualSELayer), see DESIGN.md.
+"""
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- EquiUnet (GN + act)
+def _act(x, act):
+    # networks/factory.py:195-200 -> MONAI Act lookup; only relu / leakyrelu are in scope
+    if act == "relu":
+        return F.relu(x)
+    if act == "leakyrelu":
+        return F.leaky_relu(x, 0.01)
+    raise ValueError(act)
+
+
+def conv_gn_act(sd, pre, x, dilation=1, act="relu"):
+    """ConvBnRelu, networks/equiunet2020.py:51-75: conv3x3x3 (no bias, pad=dil) -> GroupNorm(8) -> act
+    -> Dropout(p=0) (identity).  GroupNorm(8, C, affine) from networks/factory.py:179-182."""
+    y = F.conv3d(x, sd[pre + ".conv.weight"], None, 1, dilation, dilation)
+    y = F.group_norm(y, 8, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], 1e-5)
+    return _act(y, act)
+
+
+def ublock(sd, pre, x, dilation=(1, 1), act="relu"):
+    """UBlock, networks/equiunet2020.py:105-123."""
+    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act)
+    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act)
+
+
+def _up(x, s):
+    # nn.Upsample(scale_factor=s, mode="trilinear", align_corners=True), equiunet2020.py:439
+    return F.interpolate(x, scale_factor=s, mode="trilinear", align_corners=True)
+
+
+def _c1(sd, pre, x):
+    # conv1x1 with bias, networks/equiunet2020.py:37-41
+    return F.conv3d(x, sd[pre + ".weight"], sd[pre + ".bias"])
+
+
+def equiunet_forward(sd, x, act="relu", deep_supervision=True):
+    """EquiUnet.forward, networks/equiunet2020.py:467-500. Returns (logits, [4 deep heads])."""
+    down1 = ublock(sd, "encoder1", x, act=act)
+    down2 = ublock(sd, "encoder2", F.max_pool3d(down1, 2, 2), act=act)
+    down3 = ublock(sd, "encoder3", F.max_pool3d(down2, 2, 2), act=act)
+    down4 = ublock(sd, "encoder4", F.max_pool3d(down3, 2, 2), act=act)
+    bottom = ublock(sd, "bottom", down4, (2, 2), act)
+    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act)
+    up3 = ublock(sd, "decoder3", torch.cat([down3, _up(bottom_2, 2)], 1), act=act)
+    up2 = ublock(sd, "decoder2", torch.cat([down2, _up(up3, 2)], 1), act=act)
+    up1 = ublock(sd, "decoder1", torch.cat([down1, _up(up2, 2)], 1), act=act)
+    out = _c1(sd, "outconv", up1)
+    if not deep_supervision:
+        return out
+    deeps = [
+        _up(_c1(sd, "deep_bottom.0", bottom), 8),     # equiunet2020.py:444-446
+        _up(_c1(sd, "deep_bottom2.0", bottom_2), 8),  # :448-450
+        _up(_c1(sd, "deep3.0", up3), 4),              # :452-454
+        _up(_c1(sd, "deep2.0", up2), 2),              # :456-458
+    ]
+    return out, deeps
+
+
+def equiunet_state_shapes(width, inplanes=4, num_classes=3):
+    """Ordered {key: shape} of EquiUnet(features=[width*2**i]) with GroupNorm, deep supervision
+    (networks/equiunet2020.py:424-458). Checked against the reference in tests/golden."""
+    f = [width * 2 ** i for i in range(4)]
+    shapes = {}
+
+    def cbr(pre, cin, cout):
+        shapes[pre + ".conv.weight"] = (cout, cin, 3, 3, 3)
+        shapes[pre + ".bn.weight"] = (cout,)
+        shapes[pre + ".bn.bias"] = (cout,)
+
+    def ub(pre, cin, mid, cout):
+        cbr(pre + ".ConvBnRelu1", cin, mid)
+        cbr(pre + ".ConvBnRelu2", mid, cout)
+
+    def c1(pre, cin, cout):
+        shapes[pre + ".weight"] = (cout, cin, 1, 1, 1)
+        shapes[pre + ".bias"] = (cout,)
+
+    ub("encoder1", inplanes, f[0], f[0])
+    ub("encoder2", f[0], f[1], f[1])
+    ub("encoder3", f[1], f[2], f[2])
+    ub("encoder4", f[2], f[3], f[3])
+    ub("bottom", f[3], f[3], f[3])
+    cbr("bottom_2", f[3] * 2, f[2])
+    ub("decoder3", f[2] * 2, f[2], f[1])
+    ub("decoder2", f[1] * 2, f[1], f[0])
+    ub("decoder1", f[0] * 2, f[0], f[0])
+    c1("outconv", f[0], num_classes)
+    c1("deep_bottom.0", f[3], num_classes)
+    c1("deep_bottom2.0", f[2], num_classes)
+    c1("deep3.0", f[1], num_classes)
+    c1("deep2.0", f[0], num_classes)
+    return shapes
+
+
+# --------------------------------------------------------------------------- EquiUnetASSPEvo
+def evonorm_s0(x, gamma, beta, groups=8, eps=1e-5):
+    """EvoNorm3D S0, efficient=True path: networks/equiunet2021.py:95-103 with group_std :48-52.
+    x*sigmoid(x) / sqrt(var_unbiased over (C/groups, D, H, W) + eps) * gamma + beta.
+    Parameter ``v`` and buffer ``running_var`` are unused on this path."""
+    n, c = x.shape[:2]
+    xg = x.reshape(n, groups, c // groups, *x.shape[2:])
+    var = torch.var(xg, dim=(2, 3, 4, 5), keepdim=True)  # unbiased (torch.var default)
+    std = torch.sqrt(var + eps).expand_as(xg).reshape(x.shape)
+    return x * torch.sigmoid(x) / std * gamma + beta
+
+
+def residual_se(sd, pre, x):
+    """MONAI ResidualSELayer(3, C, r=2, relu, sigmoid) as used at equiunet2021.py:204-205
+    (MONAI 0.6.0 semantics restated)."""
+    y = x.mean(dim=(2, 3, 4))
+    y = F.relu(F.linear(y, sd[pre + ".fc.0.weight"], sd[pre + ".fc.0.bias"]))
+    y = torch.sigmoid(F.linear(y, sd[pre + ".fc.2.weight"], sd[pre + ".fc.2.bias"]))
+    return x + x * y[:, :, None, None, None]
+
+
+def conv_evo_block(sd, pre, x):
+    """ConvEvoBlockCorrected, networks/equiunet2021.py:192-209 (Sequential indices 0,1,3,4,6)."""
+    p = pre + ".conv_conv_se"
+    x = F.conv3d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], 1, 1)
+    x = evonorm_s0(x, sd[p + ".1.gamma"], sd[p + ".1.beta"])
+    x = F.conv3d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], 1, 1)
+    x = evonorm_s0(x, sd[p + ".4.gamma"], sd[p + ".4.beta"])
+    return residual_se(sd, p + ".6", x)
+
+
+def conv_evo(sd, pre, x):
+    """ConvEvo (1x1x1 conv + bias -> EvoNorm), networks/equiunet2021.py:212-222."""
+    x = F.conv3d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"])
+    return evonorm_s0(x, sd[pre + ".evo.gamma"], sd[pre + ".evo.beta"])
+
+
+def max_avg_pool(x):
+    """MONAI MaxAvgPool(spatial_dims=3, kernel_size=2), equiunet2021.py:261: cat([max, avg], 1)."""
+    return torch.cat([F.max_pool3d(x, 2), F.avg_pool3d(x, 2)], 1)
+
+
+def aspp(sd, pre, x, dilations=(1, 2, 4, 6), kernels=(1, 3, 3, 3)):
+    """SimpleASPPEVO, networks/equiunet2021.py:121-189; pad = same_padding(k, d) = (k-1)/2*d."""
+    outs = []
+    for i, (k, d) in enumerate(zip(kernels, dilations)):
+        pad = (k - 1) // 2 * d
+        outs.append(F.conv3d(x, sd[f"{pre}.convs.{i}.weight"], sd[f"{pre}.convs.{i}.bias"], 1, pad, d))
+    return conv_evo(sd, pre + ".conv_k1", torch.cat(outs, 1))
+
+
+def assp_evo_forward(sd, x, deep_supervision=True):
+    """EquiUnetASSPEvo.forward, networks/equiunet2021.py:289-333. Returns (logits, [2 deeps])."""
+    down1 = conv_evo_block(sd, "encoder1", x)
+    down2 = conv_evo_block(sd, "encoder2", max_avg_pool(down1))
+    down3 = conv_evo_block(sd, "encoder3", max_avg_pool(down2))
+    down4 = conv_evo_block(sd, "encoder4", max_avg_pool(down3))
+    a = aspp(sd, "aspp", down4)
+    down1b = conv_evo(sd, "bridge1", down1)
+    down2b = conv_evo(sd, "bridge2", down2)
+    down3b = conv_evo(sd, "bridge3", down3)
+    up3 = conv_evo_block(sd, "decoder3", torch.cat([down3b, _up(conv_evo(sd, "upconv3", a), 2)], 1))
+    up2 = conv_evo_block(sd, "decoder2", torch.cat([down2b, _up(conv_evo(sd, "upconv2", up3), 2)], 1))
+    up1 = conv_evo_block(sd, "decoder1", torch.cat([down1b, _up(conv_evo(sd, "upconv1", up2), 2)], 1))
+    out = _c1(sd, "out_conv", up1)
+    if not deep_supervision:
+        return out
+    deeps = [_up(_c1(sd, "deep3.0", up3), 4), _up(_c1(sd, "deep2.0", up2), 2)]  # :326-332
+    return out, deeps
+
+
+def assp_evo_state_shapes(width, inplanes=4, num_classes=3):
+    """Ordered {key: shape} of EquiUnetASSPEvo (networks/equiunet2021.py:246-281), incl. the unused
+    EvoNorm ``v`` parameter and ``running_var`` buffer (:76-83)."""
+    f = [width * 2 ** i for i in range(4)]
+    shapes = {}
+
+    def evo(pre, c):
+        for k in ("gamma", "beta", "v", "running_var"):
+            shapes[f"{pre}.{k}"] = (1, c, 1, 1, 1)
+
+    def block(pre, cin, cout):
+        p = pre + ".conv_conv_se"
+        shapes[p + ".0.weight"] = (cout, cin, 3, 3, 3)
+        shapes[p + ".0.bias"] = (cout,)
+        evo(p + ".1", cout)
+        shapes[p + ".3.weight"] = (cout, cout, 3, 3, 3)
+        shapes[p + ".3.bias"] = (cout,)
+        evo(p + ".4", cout)
+        shapes[p + ".6.fc.0.weight"] = (cout // 2, cout)
+        shapes[p + ".6.fc.0.bias"] = (cout // 2,)
+        shapes[p + ".6.fc.2.weight"] = (cout, cout // 2)
+        shapes[p + ".6.fc.2.bias"] = (cout,)
+
+    def cevo(pre, cin, cout):
+        shapes[pre + ".conv.weight"] = (cout, cin, 1, 1, 1)
+        shapes[pre + ".conv.bias"] = (cout,)
+        evo(pre + ".evo", cout)
+
+    def c1(pre, cin, cout):
+        shapes[pre + ".weight"] = (cout, cin, 1, 1, 1)
+        shapes[pre + ".bias"] = (cout,)
+
+    block("encoder1", inplanes, f[0])
+    block("encoder2", 2 * f[0], f[1])
+    block("encoder3", 2 * f[1], f[2])
+    block("encoder4", 2 * f[2], f[3])
+    cevo("bridge1", f[0], f[0] // 2)
+    cevo("bridge2", f[1], f[1] // 2)
+    cevo("bridge3", f[2], f[2] // 2)
+    for i, k in enumerate((1, 3, 3, 3)):
+        shapes[f"aspp.convs.{i}.weight"] = (f[3] // 4, f[3], k, k, k)
+        shapes[f"aspp.convs.{i}.bias"] = (f[3] // 4,)
+    cevo("aspp.conv_k1", f[3], f[3])
+    cevo("upconv3", f[3], f[3] // 4)
+    block("decoder3", f[2], f[2])
+    cevo("upconv2", f[2], f[2] // 4)
+    block("decoder2", f[1], f[1])
+    cevo("upconv1", f[1], f[1] // 4)
+    block("decoder1", f[0], f[0])
+    c1("out_conv", f[0], num_classes)
+    c1("deep3.0", f[2], num_classes)
+    c1("deep2.0", f[1], num_classes)
+    return shapes
+
+
+# --------------------------------------------------------------------------- loss / train step
+def dice_loss(logits, target, jaccard=False, smooth=1e-5):
+    """monai.losses.DiceLoss(include_background, sigmoid, squared_pred, batch=True, mean) as
+    configured at src/definer.py:184-203 (formula restated in SURVEY.md a16)."""
+    p = torch.sigmoid(logits.float())
+    t = target.float()
+    axes = (0, 2, 3, 4)
+    inter = (t * p).sum(axes)
+    denom = (t * t).sum(axes) + (p * p).sum(axes)
+    if jaccard:
+        denom = 2.0 * (denom - inter)
+    return (1.0 - (2.0 * inter + smooth) / (denom + smooth)).mean()
+
+
+def deep_supervision_loss(outputs, target, jaccard=False):
+    """Engine._compute_loss, learning/engine.py:312-333: mean over [main] + deep heads of the
+    criterion against the same full-resolution label."""
+    if isinstance(outputs, (tuple, list)):
+        heads = [outputs[0]] + list(outputs[1])
+    else:
+        heads = [outputs]
+    return torch.stack([dice_loss(h, target, jaccard) for h in heads]).mean()
+
+
+def hard_dice(logits, target):
+    """Hard Dice of thresholded sigmoid(logits) per class (post_trans threshold 0.5,
+    src/definer.py:696-697) -- the 'Dice within 1e-3' check of BASELINE.md."""
+    p = (torch.sigmoid(logits.float()) > 0.5).float()
+    t = target.float()
+    axes = (0, 2, 3, 4)
+    inter = (p * t).sum(axes)
+    return (2 * inter + 1e-5) / (p.sum(axes) + t.sum(axes) + 1e-5)

@@ -1,0 +1,200 @@
+"""Generates the committed golden vectors in tests/golden/*.npz by running the REFERENCE source
+(/root/reference, imported under oracle/refshim.py) on closed-form inputs/weights (oracle/synth.py).
+
+Run here only (the GPU box has no /root/reference):  python tests/golden/make_golden.py
+The fixtures hold inputs' *recipes* (names/sizes) and the reference's outputs -- data only, no
+reference source in any encoding.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import refshim, synth, unet  # noqa: E402
+
+refshim.install()
+from networks.equiunet2020 import EquiUnet, ConvBnRelu  # noqa: E402
+from networks.equiunet2021 import (EquiUnetASSPEvo, EvoNorm3D, SimpleASPPEVO,  # noqa: E402
+                                   ConvEvoBlockCorrected, ConvEvo)
+from networks.factory import get_norm_layer  # noqa: E402
+from utils.inferers import sliding_window_inference, _get_scan_interval  # noqa: E402
+from monai.data.utils import dense_patch_slices  # noqa: E402  (the stub)
+from monai.losses import DiceLoss  # noqa: E402  (the stub)
+import tta  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def _criterion():
+    # src/definer.py:184-193
+    return DiceLoss(include_background=True, sigmoid=True, softmax=False, squared_pred=True,
+                    jaccard=False, batch=True)
+
+
+def _ds_loss(outputs, target, crit):
+    # learning/engine.py:322-330 (flatten -> mean over heads)
+    heads = [outputs[0]] + list(outputs[1])
+    return torch.mean(torch.stack([crit(h, target) for h in heads]))
+
+
+def _model_fixture(model, shapes_fn, width, size, fname, sub):
+    sd = synth.fill_state_dict(shapes_fn(width))
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), "state-dict key order/name mismatch vs reference"
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    x = synth.closed_form_image(1, 4, size)
+    t = synth.nested_spheres(1, size)
+    out = model(x)
+    loss = _ds_loss(out, t, _criterion())
+    loss.backward()
+    res = {
+        "meta": json.dumps({"width": width, "size": list(size), "sub": sub,
+                            "keys": list(sd.keys()), "shapes": [list(v.shape) for v in sd.values()]}),
+        "logits": out[0].detach().numpy()[:, :, ::sub, ::sub, ::sub],
+        "loss": np.float64(loss.item()),
+    }
+    for i, d in enumerate(out[1]):
+        res[f"deep{i}"] = d.detach().numpy()[:, :, ::2 * sub, ::2 * sub, ::2 * sub]
+    names, gn = [], []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        gn.append(float(p.grad.double().norm()))
+        if p.grad.numel() <= 4096:
+            res["grad:" + k] = p.grad.numpy().copy()
+    res["grad_names"] = json.dumps(names)
+    res["grad_norms"] = np.array(gn)
+    np.savez_compressed(os.path.join(OUT, fname), **res)
+    print(fname, "loss", loss.item(), "logits absmax", float(out[0].abs().max()))
+
+
+def equiunet_fixtures():
+    for size, fname, sub in (((32, 32, 32), "equiunet_w8_32.npz", 1), ((64, 64, 64), "equiunet_w8_64.npz", 4)):
+        m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="group", act="relu", deep_supervision=True, dropout=0)
+        _model_fixture(m, unet.equiunet_state_shapes, 8, size, fname, sub)
+
+
+def assp_fixture():
+    m = EquiUnetASSPEvo(4, 3, [16, 32, 64, 128], norm_layer="group", act="relu", deep_supervision=True, dropout=0)
+    _model_fixture(m, unet.assp_evo_state_shapes, 16, (32, 32, 32), "assp_w16_32.npz", 1)
+
+
+def op_fixtures():
+    res = {}
+    x = synth.closed_form_image(1, 16, (12, 12, 12), "opx")
+    # ConvBnRelu with dilation 2 (the `bottom` block, equiunet2020.py:429)
+    m = ConvBnRelu(16, 16, "relu", get_norm_layer("group"), dilation=2)
+    sd = synth.fill_state_dict({"conv.weight": (16, 16, 3, 3, 3), "bn.weight": (16,), "bn.bias": (16,)})
+    m.load_state_dict(sd)
+    res["cbr_d2"] = m(x).detach().numpy()
+    # EvoNorm3D S0 (equiunet2021.py:55-118), forward + input gradient
+    e = EvoNorm3D(16)
+    esd = synth.fill_state_dict({k: (1, 16, 1, 1, 1) for k in ("gamma", "beta", "v", "running_var")})
+    e.load_state_dict(esd)
+    xe = x.clone().requires_grad_(True)
+    ye = e(xe)
+    (ye * synth.closed_form("evo_go", ye.shape)).sum().backward()
+    res["evo_y"] = ye.detach().numpy()
+    res["evo_dx"] = xe.grad.numpy()
+    res["evo_dgamma"] = e.gamma.grad.numpy()
+    res["evo_dbeta"] = e.beta.grad.numpy()
+    # SimpleASPPEVO (equiunet2021.py:121-189)
+    xa = synth.closed_form_image(1, 32, (8, 8, 8), "asppx")
+    a = SimpleASPPEVO(32, 8)
+    shapes = {}
+    for i, k in enumerate((1, 3, 3, 3)):
+        shapes[f"convs.{i}.weight"] = (8, 32, k, k, k)
+        shapes[f"convs.{i}.bias"] = (8,)
+    shapes["conv_k1.conv.weight"] = (32, 32, 1, 1, 1)
+    shapes["conv_k1.conv.bias"] = (32,)
+    for k in ("gamma", "beta", "v", "running_var"):
+        shapes[f"conv_k1.evo.{k}"] = (1, 32, 1, 1, 1)
+    a.load_state_dict(synth.fill_state_dict(shapes))
+    res["aspp_y"] = a(xa).detach().numpy()
+    # ConvEvoBlockCorrected (equiunet2021.py:192-209) incl. the MONAI ResidualSELayer stub
+    b = ConvEvoBlockCorrected(16, 16, 0)
+    bsh = {}
+    for idx in ("0", "3"):
+        bsh[f"conv_conv_se.{idx}.weight"] = (16, 16, 3, 3, 3)
+        bsh[f"conv_conv_se.{idx}.bias"] = (16,)
+    for idx in ("1", "4"):
+        for k in ("gamma", "beta", "v", "running_var"):
+            bsh[f"conv_conv_se.{idx}.{k}"] = (1, 16, 1, 1, 1)
+    bsh["conv_conv_se.6.fc.0.weight"] = (8, 16)
+    bsh["conv_conv_se.6.fc.0.bias"] = (8,)
+    bsh["conv_conv_se.6.fc.2.weight"] = (16, 8)
+    bsh["conv_conv_se.6.fc.2.bias"] = (16,)
+    order = list(b.state_dict().keys())
+    bsd = synth.fill_state_dict({k: bsh[k] for k in order})
+    b.load_state_dict(bsd)
+    res["block_y"] = b(x).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **res)
+    print("ops.npz", {k: v.shape for k, v in res.items()})
+
+
+def inference_fixtures():
+    res = {}
+    # window lists for config 4 and the reference default
+    for size in ((240, 240, 155), (240, 240, 160)):
+        for ov in (0.25, 0.5):
+            iv = _get_scan_interval(size, (128, 128, 128), 3, ov)
+            sl = dense_patch_slices(size, (128, 128, 128), iv)
+            res[f"starts_{size[2]}_{int(ov * 100)}"] = np.array([[s.start for s in w] for w in sl])
+    # stitched output of a cheap analytic predictor that returns (out, [deep]) like the nets do
+    x = synth.closed_form_image(1, 4, (20, 27, 17), "swx")
+    w = synth.closed_form("swpred", (3, 4), 0.5)
+
+    def predictor(p):
+        zz = torch.arange(p.shape[2], dtype=torch.float32).view(1, 1, -1, 1, 1) * 0.01
+        out = torch.einsum("oc,ncdhw->nodhw", w, p) + zz  # position-in-window dependent
+        return out, [out * 2]
+
+    for mode in ("constant", "gaussian"):
+        for ov in (0.25, 0.5):
+            y = sliding_window_inference(x, (16, 16, 16), 1, predictor, overlap=ov, mode=mode)
+            res[f"sw_{mode}_{int(ov * 100)}"] = y.numpy()
+    y = sliding_window_inference(x[..., :12], (16, 16, 16), 2, predictor, overlap=0.5)  # roi > image: padded
+    res["sw_pad"] = y.numpy()
+    # TTA: parameter order + augmented/deaugmented tensors of a tiny non-cubic volume
+    from src_definer_tta import get_tta  # noqa
+    comp = get_tta(tta)
+    res["tta_params"] = json.dumps([[str(a), bool(f), int(r)] for a, f, r in comp.aug_transform_parameters])
+    v = synth.closed_form("ttav", (1, 2, 4, 6, 6))
+    augs, deaugs = [], []
+    for tr in comp:
+        a = tr.augment_image(v)
+        augs.append(a.contiguous().numpy().ravel())
+        deaugs.append(tr.deaugment_mask(a).contiguous().numpy())
+    res["tta_aug"] = np.stack(augs)
+    res["tta_roundtrip"] = np.stack(deaugs)
+    np.savez_compressed(os.path.join(OUT, "inference.npz"), **res)
+    print("inference.npz", {k: getattr(v, "shape", None) for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    # src/definer.py imports half of MONAI at module import; restate only its 6-line TTA list
+    # constructor call (src/definer.py:653-657) against the reference's own tta package.
+    import types
+
+    m = types.ModuleType("src_definer_tta")
+    m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
+                                     t.Rotate90(angles=[0, 90, 180, 270])])
+    sys.modules["src_definer_tta"] = m
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference"]
+    if "equiunet" in which:
+        equiunet_fixtures()
+    if "assp" in which:
+        assp_fixture()
+    if "ops" in which:
+        op_fixtures()
+    if "inference" in which:
+        inference_fixtures()

@@ -1,0 +1,131 @@
+"""-m "not gpu": the CPU oracle (oracle/) against the golden vectors produced by the reference
+source (tests/golden/make_golden.py).  This is what pins the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import inference as oinf
+from oracle import synth, unet
+
+TOL = 2e-5  # fp32 CPU vs fp32 CPU, same ATen kernels, different op grouping
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _run(forward, shapes_fn, g):
+    meta = json.loads(str(g["meta"]))
+    shapes = shapes_fn(meta["width"])
+    assert list(shapes.keys()) == meta["keys"]
+    assert [list(s) for s in shapes.values()] == meta["shapes"]
+    sd = {k: v.requires_grad_(True) for k, v in synth.fill_state_dict(shapes).items()}
+    size = tuple(meta["size"])
+    x = synth.closed_form_image(1, 4, size)
+    t = synth.nested_spheres(1, size)
+    out = forward(sd, x)
+    loss = unet.deep_supervision_loss(out, t)
+    loss.backward()
+    return meta, sd, out, loss
+
+
+@pytest.mark.parametrize("fname", ["equiunet_w8_32.npz", "equiunet_w8_64.npz"])
+def test_equiunet_oracle_matches_reference(golden_dir, fname):
+    g = _load(golden_dir, fname)
+    meta, sd, out, loss = _run(unet.equiunet_forward, unet.equiunet_state_shapes, g)
+    s = meta["sub"]
+    np.testing.assert_allclose(out[0].detach().numpy()[:, :, ::s, ::s, ::s], g["logits"], atol=TOL, rtol=0)
+    for i, d in enumerate(out[1]):
+        np.testing.assert_allclose(d.detach().numpy()[:, :, ::2 * s, ::2 * s, ::2 * s], g[f"deep{i}"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+    for k in g.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=1e-6, rtol=1e-4)
+
+
+def test_assp_oracle_matches_reference(golden_dir):
+    g = _load(golden_dir, "assp_w16_32.npz")
+    meta, sd, out, loss = _run(unet.assp_evo_forward, unet.assp_evo_state_shapes, g)
+    np.testing.assert_allclose(out[0].detach().numpy(), g["logits"], atol=TOL, rtol=0)
+    for i, d in enumerate(out[1]):
+        np.testing.assert_allclose(d.detach().numpy()[:, :, ::2, ::2, ::2], g[f"deep{i}"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    assert not any(n.endswith(".v") for n in names)  # EvoNorm `v` is statically unused
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+
+
+def test_op_vectors(golden_dir):
+    g = _load(golden_dir, "ops.npz")
+    x = synth.closed_form_image(1, 16, (12, 12, 12), "opx")
+    sd = synth.fill_state_dict({"conv.weight": (16, 16, 3, 3, 3), "bn.weight": (16,), "bn.bias": (16,)})
+    y = unet.conv_gn_act({"p." + k: v for k, v in sd.items()}, "p", x, 2)
+    np.testing.assert_allclose(y.numpy(), g["cbr_d2"], atol=TOL)
+    esd = synth.fill_state_dict({k: (1, 16, 1, 1, 1) for k in ("gamma", "beta", "v", "running_var")})
+    xe = x.clone().requires_grad_(True)
+    gam, bet = esd["gamma"].requires_grad_(True), esd["beta"].requires_grad_(True)
+    ye = unet.evonorm_s0(xe, gam, bet)
+    (ye * synth.closed_form("evo_go", ye.shape)).sum().backward()
+    np.testing.assert_allclose(ye.detach().numpy(), g["evo_y"], atol=TOL)
+    np.testing.assert_allclose(xe.grad.numpy(), g["evo_dx"], atol=TOL)
+    np.testing.assert_allclose(gam.grad.numpy(), g["evo_dgamma"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bet.grad.numpy(), g["evo_dbeta"], rtol=1e-4, atol=1e-4)
+    shapes = {}
+    for i, k in enumerate((1, 3, 3, 3)):
+        shapes[f"convs.{i}.weight"] = (8, 32, k, k, k)
+        shapes[f"convs.{i}.bias"] = (8,)
+    shapes["conv_k1.conv.weight"] = (32, 32, 1, 1, 1)
+    shapes["conv_k1.conv.bias"] = (32,)
+    for k in ("gamma", "beta", "v", "running_var"):
+        shapes[f"conv_k1.evo.{k}"] = (1, 32, 1, 1, 1)
+    asd = {"a." + k: v for k, v in synth.fill_state_dict(shapes).items()}
+    xa = synth.closed_form_image(1, 32, (8, 8, 8), "asppx")
+    np.testing.assert_allclose(unet.aspp(asd, "a", xa).numpy(), g["aspp_y"], atol=TOL)
+    order = []
+    for idx in ("0", "1", "3", "4"):
+        if idx in ("0", "3"):
+            order += [(f"conv_conv_se.{idx}.weight", (16, 16, 3, 3, 3)), (f"conv_conv_se.{idx}.bias", (16,))]
+        else:
+            order += [(f"conv_conv_se.{idx}.{k}", (1, 16, 1, 1, 1)) for k in ("gamma", "beta", "v", "running_var")]
+    order += [("conv_conv_se.6.fc.0.weight", (8, 16)), ("conv_conv_se.6.fc.0.bias", (8,)),
+              ("conv_conv_se.6.fc.2.weight", (16, 8)), ("conv_conv_se.6.fc.2.bias", (16,))]
+    bsd = {"b." + k: v for k, v in synth.fill_state_dict(dict(order)).items()}
+    np.testing.assert_allclose(unet.conv_evo_block(bsd, "b", x).numpy(), g["block_y"], atol=TOL)
+
+
+def test_sliding_window_and_tta_vectors(golden_dir):
+    g = _load(golden_dir, "inference.npz")
+    for size in ((240, 240, 155), (240, 240, 160)):
+        for ov in (0.25, 0.5):
+            st = oinf.window_starts(size, (128,) * 3, oinf.scan_interval(size, (128,) * 3, ov))
+            assert len(st) == 18
+            np.testing.assert_array_equal(np.array(st), g[f"starts_{size[2]}_{int(ov * 100)}"])
+    x = synth.closed_form_image(1, 4, (20, 27, 17), "swx")
+    w = synth.closed_form("swpred", (3, 4), 0.5)
+
+    def predictor(p):
+        zz = torch.arange(p.shape[2], dtype=torch.float32).view(1, 1, -1, 1, 1) * 0.01
+        out = torch.einsum("oc,ncdhw->nodhw", w, p) + zz
+        return out, [out * 2]
+
+    for mode in ("constant", "gaussian"):
+        for ov in (0.25, 0.5):
+            y = oinf.sliding_window_inference(x, (16, 16, 16), 1, predictor, overlap=ov, mode=mode)
+            np.testing.assert_allclose(y.numpy(), g[f"sw_{mode}_{int(ov * 100)}"], atol=1e-6)
+    y = oinf.sliding_window_inference(x[..., :12], (16, 16, 16), 2, predictor, overlap=0.5)
+    np.testing.assert_allclose(y.numpy(), g["sw_pad"], atol=1e-6)
+    params = oinf.tta_param_list()
+    assert [[a, f, r] for a, f, r in params] == json.loads(str(g["tta_params"]))
+    v = synth.closed_form("ttav", (1, 2, 4, 6, 6))
+    for i, p in enumerate(params):
+        a = oinf.tta_augment(v, *p)
+        np.testing.assert_array_equal(a.contiguous().numpy().ravel(), g["tta_aug"][i])
+        np.testing.assert_array_equal(oinf.tta_deaugment(a, *p).contiguous().numpy(), g["tta_roundtrip"][i])
+        np.testing.assert_array_equal(g["tta_roundtrip"][i], v.numpy())  # all 16 exactly invertible (F7)
