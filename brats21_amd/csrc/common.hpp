@@ -1,0 +1,79 @@
+// Shared device/host helpers for libbrats_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
+#include "../../include/brats_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define DEVI __device__ __forceinline__
+
+DEVI float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+DEVI bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> DEVI float to_f(T v);
+template <> DEVI float to_f<float>(float v) { return v; }
+template <> DEVI float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> DEVI T from_f(float v);
+template <> DEVI float from_f<float>(float v) { return v; }
+template <> DEVI bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// N contiguous elements <-> float registers (N*sizeof(T) must be 8 or 16 bytes, pointer aligned)
+template <typename T, int N> struct Vec;
+template <> struct Vec<float, 4> {
+  static DEVI void load(const float* p, float* o) { f32x4 v = *(const f32x4*)p; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+  static DEVI void store(float* p, const float* o) { f32x4 v = {o[0], o[1], o[2], o[3]}; *(f32x4*)p = v; }
+};
+template <> struct Vec<bf16_t, 4> {
+  static DEVI void load(const bf16_t* p, float* o) {
+    u32x2 v = *(const u32x2*)p;
+    o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xffff0000u);
+    o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xffff0000u);
+  }
+  static DEVI void store(bf16_t* p, const float* o) {
+    u32x2 v;
+    v[0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+    v[1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    *(u32x2*)p = v;
+  }
+};
+template <> struct Vec<bf16_t, 8> {
+  static DEVI void load(const bf16_t* p, float* o) {
+    u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+  }
+  static DEVI void store(bf16_t* p, const float* o) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
+    *(u32x4*)p = v;
+  }
+};
+
+// compile-time loop with a constexpr index
+template <int I, int N, typename F> DEVI void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+void brats_set_error(const char* fmt, ...);
+#define BRATS_FAIL(code, ...) do { brats_set_error(__VA_ARGS__); return (code); } while (0)
+#define BRATS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
+  BRATS_FAIL(BRATS_E_HIP, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

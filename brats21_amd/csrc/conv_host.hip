@@ -1,0 +1,135 @@
+// C-ABI entry points for the implicit-GEMM convolution: weight packing + forward/dgrad launch.
+#include <stdarg.h>
+#include "conv_igemm.hpp"
+
+static thread_local char g_err[512] = "";
+void brats_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* brats_last_error(void) { return g_err; }
+extern "C" int brats_abi_version(void) { return 1; }
+
+// ---- chunk selection ---------------------------------------------------------------------------
+extern "C" int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2) {
+  (void)ksize; (void)dil;
+  static const int bf[] = {48, 32, 16, 8};
+  static const int f32[] = {16, 8, 4};
+  const int* cand = dtype == BRATS_BF16 ? bf : f32;
+  const int n = dtype == BRATS_BF16 ? 4 : 3;
+  for (int i = 0; i < n; ++i)
+    if (c1 % cand[i] == 0 && (c2 <= 0 || c2 % cand[i] == 0)) return cand[i];
+  return 0;
+}
+
+static int macro_steps(int dtype, int ksize, int ck) {
+  const int taps = ksize * ksize * ksize;
+  if (dtype == BRATS_BF16) return (taps * (ck / 8) + 3) / 4;
+  return (taps * ck / 4 + 3) / 4;
+}
+
+extern "C" size_t brats_conv3d_packed_bytes(int dtype, int ksize, int cin, int cout, int ck) {
+  if (ck <= 0 || cin % ck) return 0;
+  const int rows16 = ceil_div(cout, 16);
+  return (size_t)(cin / ck) * macro_steps(dtype, ksize, ck) * rows16 * 64 * 16;
+}
+
+// ---- weight packing ----------------------------------------------------------------------------
+// out[chunk][ms][row16][lane][16 B]; see conv_igemm.hpp for the unit -> (tap, channel) map.
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int taps,
+                                    int cin_w, int cin_off, int rows, int rows16, int kdim, int ck, int ms_n,
+                                    size_t total) {
+  constexpr bool BF = std::is_same<T, bf16_t>::value;
+  constexpr int EPL = BF ? 8 : 4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = idx % EPL;
+  size_t t = idx / EPL;
+  const int lane = t % 64; t /= 64;
+  const int ft = t % rows16; t /= rows16;
+  const int ms = t % ms_n;
+  const int chunk = t / ms_n;
+  const int q = lane >> 4, row = ft * 16 + (lane & 15);
+  int tap, kc;
+  bool valid;
+  if (BF) {
+    const int upt = ck / 8, g = 4 * ms + q;
+    valid = g < taps * upt;
+    tap = g / upt;
+    kc = chunk * ck + (g % upt) * 8 + e;
+  } else {
+    const int g = 4 * (4 * ms + e) + q;
+    valid = g < taps * ck;
+    tap = g / ck;
+    kc = chunk * ck + g % ck;
+  }
+  float val = 0.f;
+  if (valid && row < rows && kc < kdim) {
+    if (mode == BRATS_PACK_FWD) val = w[((size_t)row * cin_w + cin_off + kc) * taps + tap];
+    else val = w[((size_t)kc * cin_w + cin_off + row) * taps + (taps - 1 - tap)];
+  }
+  out[idx] = from_f<T>(val);
+}
+
+extern "C" int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize,
+                                         int cout_w, int cin_w, int cin_off, int cin_cnt, int ck,
+                                         brats_stream_t s) {
+  if (!w || !packed || (ksize != 1 && ksize != 3) || ck <= 0) BRATS_FAIL(BRATS_E_ARG, "pack_weights: bad argument");
+  const int taps = ksize * ksize * ksize;
+  const int rows = mode == BRATS_PACK_FWD ? cout_w : cin_cnt;
+  const int kdim = mode == BRATS_PACK_FWD ? cin_cnt : cout_w;
+  if (kdim % ck) BRATS_FAIL(BRATS_E_ARG, "pack_weights: K channels %d not a multiple of chunk %d", kdim, ck);
+  const int rows16 = ceil_div(rows, 16);
+  const int ms = macro_steps(dtype, ksize, ck);
+  const int epl = dtype == BRATS_BF16 ? 8 : 4;
+  const size_t total = (size_t)(kdim / ck) * ms * rows16 * 64 * epl;
+  const int blocks = (int)((total + 255) / 256);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, mode,
+                       taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)packed, mode,
+                       taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- forward / dgrad ---------------------------------------------------------------------------
+extern "C" int brats_conv3d_tiles_per_sample(int D, int H, int W) {
+  return ceil_div(D, CONV_TZ) * ceil_div(H, CONV_TY) * ceil_div(W, CONV_TX);
+}
+
+extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
+                                const void* packed_w, const float* bias, void* y, int ypitch, float* stats,
+                                int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
+                                brats_stream_t s) {
+  if (!x1 || !packed_w || !y || c1 <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0)
+    BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: null pointer or non-positive size");
+  if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: c2 > 0 but x2 is NULL");
+  if (c2 < 0) c2 = 0;
+  if (cout % 4) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: cout %d must be a multiple of 4", cout);
+  const int align = dtype == BRATS_BF16 ? 8 : 4;
+  if (pitch1 % align || (c2 && pitch2 % align) || ypitch % 4)
+    BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: channel pitches must keep 16-byte loads / 4-channel stores aligned");
+  const int ck = brats_conv3d_chunk(dtype, ksize, dil, c1, c2);
+  if (!ck) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: no channel chunk divides c1=%d c2=%d", c1, c2);
+  ConvParams p;
+  p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
+  p.wpk = packed_w; p.bias = bias; p.y = y; p.ypitch = ypitch; p.stats = stats;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.cout = cout; p.rows16 = ceil_div(cout, 16);
+  p.nchunks = (c1 + c2) / ck;
+  p.tz = ceil_div(D, CONV_TZ); p.ty = ceil_div(H, CONV_TY); p.tx = ceil_div(W, CONV_TX);
+  hipStream_t st = (hipStream_t)s;
+  if (ksize == 1) dil = 1;
+#define GO(T) \
+  if (ksize == 3 && dil == 1) return conv_launch<T, 3, 1>(p, ck, st); \
+  if (ksize == 3 && dil == 2) return conv_launch<T, 3, 2>(p, ck, st); \
+  if (ksize == 1) return conv_launch<T, 1, 1>(p, ck, st);
+  if (dtype == BRATS_BF16) { GO(bf16_t) }
+  else if (dtype == BRATS_F32) { GO(float) }
+#undef GO
+  BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: unsupported dtype=%d ksize=%d dilation=%d", dtype, ksize, dil);
+}

@@ -1,0 +1,335 @@
+// Implicit-GEMM 3x3x3 / 1x1x1 convolution for gfx950 (MFMA), NDHWC activations.
+//
+// Replaces nn.Conv3d of the reference (networks/equiunet2020.py:19-25, networks/equiunet2021.py:197-206)
+// and, with weights packed in DGRAD mode, its autograd input-gradient.
+//
+// GEMM view: D[cout][voxel] = sum_{tap, cin} Wp[cout][(tap,cin)] * X[voxel + off(tap)][cin]
+//   A operand (MFMA rows)  = packed weights, streamed from L2 in fragment order (16 B / lane / step)
+//   B operand (MFMA cols)  = activations, read from an LDS halo tile (one ds_read_b128 per fragment)
+//   C/D: lane (q = lane>>4, v = lane&15) holds cout rows 4q..4q+3 of voxel v -> 4 contiguous
+//        NDHWC channels per lane = one 8/16-byte store.
+// Workgroup = 256 threads = 4 waves on a 4x8x8 voxel tile: wave (wm, wn); wm picks 2 z-slices
+// (128 voxels = 8 voxel-fragments), wn picks either the cout half (tile = 2*NF*16 couts) or, when
+// the layer has too few couts (KSPLIT), the parity of the K macro-steps (reduced through LDS).
+// Per Cin chunk (CK channels) the halo tile is staged once and all taps read it (27x reuse from
+// LDS; HBM/L2 sees only the ~2x halo amplification).  2 workgroups/CU overlap staging with MFMA.
+#pragma once
+#include "common.hpp"
+
+struct ConvParams {
+  const void* x1; const void* x2; int c1, c2, p1, p2;
+  const void* wpk; const float* bias; void* y; int ypitch; float* stats;
+  int N, D, H, W, cout, rows16, nchunks;
+  int tz, ty, tx;
+};
+
+constexpr int CONV_TZ = 4, CONV_TY = 8, CONV_TX = 8;
+
+template <typename T, int KS, int CK, int DIL>
+struct ConvGeom {
+  static constexpr bool BF = std::is_same<T, bf16_t>::value;
+  static constexpr int ESZ = sizeof(T);
+  static constexpr int EPL = 16 / ESZ;  // elements per 16-byte lane fragment
+  static constexpr int R = (KS == 3) ? DIL : 0;
+  static constexpr int HZ = CONV_TZ + 2 * R, HY = CONV_TY + 2 * R, HX = CONV_TX + 2 * R;
+  static constexpr int HVOX = HZ * HY * HX;
+  static constexpr int ROWB = CK * ESZ;
+  static constexpr int PPV = ROWB / 16;
+  static constexpr int S = (PPV % 2 == 0) ? ROWB + 16 : ROWB;  // odd number of 16-B slots per voxel
+  static constexpr int NPIECE = HVOX * PPV;
+  static constexpr int NITER = (NPIECE + 255) / 256;
+  static constexpr int TAPS = KS * KS * KS;
+  // bf16: one macro-step = one K=32 MFMA = 4 "units" of 8 channels (one per lane quarter)
+  // f32 : one macro-step = four K=4 MFMAs; a K=4 step = 4 units of 1 channel
+  static constexpr int UPT = BF ? CK / 8 : CK;           // units per tap
+  static constexpr int UNITS = TAPS * UPT;
+  static constexpr int MS = BF ? (UNITS + 3) / 4 : (UNITS / 4 + 3) / 4;
+  static constexpr int UB = BF ? 16 : 4;                 // bytes per unit
+  static constexpr int LDS_TILE = HVOX * S;
+  static_assert(ROWB % 16 == 0, "CK*sizeof(T) must be a multiple of 16");
+  static_assert(BF || CK % 4 == 0, "f32 CK must be a multiple of 4");
+
+  static constexpr int tapoff(int tap) {
+    return KS == 1 ? 0 : ((((tap / 9) * DIL) * HY + ((tap / 3) % 3) * DIL) * HX + (tap % 3) * DIL) * S;
+  }
+  // byte offset (relative to the lane's voxel) of unit g; invalid units read offset 0 (weights are 0)
+  static constexpr int unitoff(int g) { return g < UNITS ? tapoff(g / UPT) + (g % UPT) * UB : 0; }
+};
+
+template <int NF, bool KSPLIT> struct ConvTile {
+  static constexpr int NFW = KSPLIT ? NF : 2 * NF;  // cout16-fragments per workgroup
+  static constexpr int RED_BYTES = KSPLIT ? 2 * NF * 8 * 64 * 16 : 0;
+  static constexpr int SRED_BYTES = 2 * NFW * 16 * 2 * 4;
+};
+
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
+constexpr int conv_lds_bytes() {
+  using G = ConvGeom<T, KS, CK, DIL>;
+  using TL = ConvTile<NF, KSPLIT>;
+  int a = G::LDS_TILE > TL::RED_BYTES ? G::LDS_TILE : TL::RED_BYTES;
+  a = (a + 15) / 16 * 16;
+  return a + TL::SRED_BYTES;
+}
+
+template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */>
+DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
+                         int lane, f32x4 (&acc)[NF][8]) {
+  using G = ConvGeom<T, KS, CK, DIL>;
+  constexpr int FOZ = G::HY * G::HX * G::S;  // one z-slice
+  static_for<0, G::MS>([&](auto ms_) {
+    constexpr int ms = ms_;
+    if constexpr (PARITY < 0 || (ms & 1) == PARITY) {
+      if constexpr (G::BF) {
+        const bf16x8* wp = (const bf16x8*)wpk_chunk + ((size_t)ms * rows16 + f0) * 64 + lane;
+        bf16x8 a[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) a[f] = wp[f * 64];
+        constexpr int o0 = G::unitoff(4 * ms), o1 = G::unitoff(4 * ms + 1), o2 = G::unitoff(4 * ms + 2),
+                      o3 = G::unitoff(4 * ms + 3);
+        int lb;
+        if constexpr (o1 - o0 == G::UB && o2 - o0 == 2 * G::UB && o3 - o0 == 3 * G::UB) {
+          lb = lane_b + o0;  // lane_b already carries q*UB
+        } else {
+          lb = lane_b + (q == 0 ? o0 : q == 1 ? o1 - G::UB : q == 2 ? o2 - 2 * G::UB : o3 - 3 * G::UB);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bf16x8 b = *(const bf16x8*)(ldsb + lb + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
+#pragma unroll
+          for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f], b, acc[f][i], 0, 0, 0);
+        }
+      } else {
+        const f32x4* wp = (const f32x4*)wpk_chunk + ((size_t)ms * rows16 + f0) * 64 + lane;
+        f32x4 a[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) a[f] = wp[f * 64];
+        static_for<0, 4>([&](auto j_) {
+          constexpr int j = j_;
+          constexpr int o = G::unitoff(4 * (4 * ms + j));  // CK%4==0: the 4 quarters share the tap
+          if constexpr (4 * (4 * ms + j) < G::UNITS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float b = *(const float*)(ldsb + lane_b + o + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
+#pragma unroll
+              for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][j], b, acc[f][i], 0, 0, 0);
+            }
+          }
+        });
+      }
+    }
+  });
+}
+
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+  using G = ConvGeom<T, KS, CK, DIL>;
+  using TL = ConvTile<NF, KSPLIT>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int q = lane >> 4, v = lane & 15;
+
+  int bt = blockIdx.x;
+  const int tile_in_sample = bt % (p.tz * p.ty * p.tx);
+  const int txi = bt % p.tx; bt /= p.tx;
+  const int tyi = bt % p.ty; bt /= p.ty;
+  const int tzi = bt % p.tz;
+  const int n = bt / p.tz;
+  const int z0 = tzi * CONV_TZ, y0 = tyi * CONV_TY, x0 = txi * CONV_TX;
+  const int ct = blockIdx.y;
+  const int f0 = ct * TL::NFW + (KSPLIT ? 0 : wn * NF);
+  const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+
+  // --- staging descriptors (identical for every Cin chunk) ---
+  int voff[G::NITER];
+#pragma unroll
+  for (int i = 0; i < G::NITER; ++i) {
+    const int pc = tid + 256 * i;
+    const int hv = pc / G::PPV;
+    const int hz = hv / (G::HY * G::HX), rr = hv % (G::HY * G::HX);
+    const int hy = rr / G::HX, hx = rr % G::HX;
+    const int gz = z0 - G::R + hz, gy = y0 - G::R + hy, gx = x0 - G::R + hx;
+    const bool inb = pc < G::NPIECE && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    voff[i] = inb ? (gz * p.H + gy) * p.W + gx : -1;
+  }
+
+  f32x4 acc[NF][8];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane's voxel inside the halo tile (tap (0,0,0) corner) + quarter offset
+  const int lane_b = ((wm * 2) * G::HY * G::HX + (v >> 3) * G::HX + (v & 7)) * G::S + q * G::UB;
+  const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;  // bytes of packed weights per chunk
+
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int c0 = chunk * CK;
+    const T* src;
+    int pitch;
+    if (c0 < p.c1) { src = (const T*)p.x1 + c0; pitch = p.p1; }
+    else { src = (const T*)p.x2 + (c0 - p.c1); pitch = p.p2; }
+    src += sample_vox * pitch;
+    u32x4 r[G::NITER];
+#pragma unroll
+    for (int i = 0; i < G::NITER; ++i) {
+      const int part = (tid + 256 * i) % G::PPV;
+      r[i] = u32x4{0u, 0u, 0u, 0u};
+      if (voff[i] >= 0) r[i] = *(const u32x4*)(src + (size_t)voff[i] * pitch + part * G::EPL);
+    }
+    if (chunk > 0) __syncthreads();  // all waves finished reading the previous chunk's tile
+#pragma unroll
+    for (int i = 0; i < G::NITER; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < G::NPIECE) *(u32x4*)(lds + (pc / G::PPV) * G::S + (pc % G::PPV) * 16) = r[i];
+    }
+    __syncthreads();
+    const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
+    if constexpr (KSPLIT) {
+      if (wn == 0) conv_mma_chunk<T, KS, CK, DIL, NF, 0>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+      else conv_mma_chunk<T, KS, CK, DIL, NF, 1>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    } else {
+      conv_mma_chunk<T, KS, CK, DIL, NF, -1>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    }
+  }
+
+  // --- K-split reduction through LDS ---
+  if constexpr (KSPLIT) {
+    __syncthreads();
+    f32x4* red = (f32x4*)lds;
+    if (wn == 1) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[((wm * NF + f) * 8 + i) * 64 + lane] = acc[f][i];
+    }
+    __syncthreads();
+    if (wn == 0) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[f][i] += red[((wm * NF + f) * 8 + i) * 64 + lane];
+    }
+  }
+
+  // --- epilogue: bias, per-channel tile statistics, NDHWC store ---
+  constexpr int LDS_MAIN = ((G::LDS_TILE > TL::RED_BYTES ? G::LDS_TILE : TL::RED_BYTES) + 15) / 16 * 16;
+  float* sred = (float*)(lds + LDS_MAIN);  // [2 (wm)][NFW*16][2]
+  const bool active = KSPLIT ? (wn == 0) : true;
+  if (active) {
+    T* yb = (T*)p.y + sample_vox * p.ypitch;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int cbase = (f0 + f) * 16 + 4 * q;
+      const bool cok = cbase < p.cout;
+      float bias[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && cok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = p.bias[cbase + r];
+      }
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int z = z0 + 2 * wm + (i >> 2), y = y0 + 2 * (i & 3) + (v >> 3), x = x0 + (v & 7);
+        const bool ok = cok && z < p.D && y < p.H && x < p.W;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = acc[f][i][r] + bias[r];
+        if (ok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s1[r] += o[r]; s2[r] += o[r] * o[r]; }
+          Vec<T, 4>::store(yb + ((size_t)(z * p.H + y) * p.W + x) * p.ypitch + cbase, o);
+        }
+      }
+      if (p.stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            s1[r] += __shfl_xor(s1[r], m);
+            s2[r] += __shfl_xor(s2[r], m);
+          }
+        }
+        if (v == 0) {
+          const int cl = (f0 + f - ct * TL::NFW) * 16 + 4 * q;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 0] = s1[r];
+            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 1] = s2[r];
+          }
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (tid < TL::NFW * 16) {
+      const int c = ct * TL::NFW * 16 + tid;
+      if (c < p.cout) {
+        const size_t tps = (size_t)p.tz * p.ty * p.tx;
+        float* dst = p.stats + (((size_t)n * tps + tile_in_sample) * p.cout + c) * 2;
+        dst[0] = sred[tid * 2] + sred[(TL::NFW * 16 + tid) * 2];
+        dst[1] = sred[tid * 2 + 1] + sred[(TL::NFW * 16 + tid) * 2 + 1];
+      }
+    }
+  }
+}
+
+// ---- host-side dispatch -----------------------------------------------------------------------
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
+int conv_launch_one(const ConvParams& p, hipStream_t st) {
+  constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT>();
+  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT>::NFW));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+struct ConvTileChoice { int nf; bool ksplit; int nfw; };
+static inline ConvTileChoice conv_choose_tile(int rows16) {
+  if (rows16 % 6 == 0) return {3, false, 6};
+  if (rows16 % 3 == 0) return {3, true, 3};
+  if (rows16 % 4 == 0) return {2, false, 4};
+  if (rows16 % 2 == 0) return {2, true, 2};
+  return {1, true, 1};
+}
+
+template <typename T, int KS, int CK, int DIL>
+int conv_launch_ck(const ConvParams& p, hipStream_t st) {
+  const ConvTileChoice t = conv_choose_tile(p.rows16);
+  if (t.nf == 3 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 3, false>(p, st);
+  if (t.nf == 3 && t.ksplit) return conv_launch_one<T, KS, CK, DIL, 3, true>(p, st);
+  if (t.nf == 2 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, false>(p, st);
+  if (t.nf == 2 && t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, true>(p, st);
+  return conv_launch_one<T, KS, CK, DIL, 1, true>(p, st);
+}
+
+// implemented in conv_<dtype>_k<KS>_d<DIL>.hip (one translation unit each, for parallel builds)
+template <typename T, int KS, int DIL> int conv_launch(const ConvParams& p, int ck, hipStream_t st);
+
+#define CONV_DEFINE_LAUNCH_BF16(KS, DIL)                                                        \
+  template <> int conv_launch<bf16_t, KS, DIL>(const ConvParams& p, int ck, hipStream_t st) {   \
+    switch (ck) {                                                                               \
+      case 48: return conv_launch_ck<bf16_t, KS, 48, DIL>(p, st);                               \
+      case 32: return conv_launch_ck<bf16_t, KS, 32, DIL>(p, st);                               \
+      case 16: return conv_launch_ck<bf16_t, KS, 16, DIL>(p, st);                               \
+      case 8: return conv_launch_ck<bf16_t, KS, 8, DIL>(p, st);                                 \
+    }                                                                                           \
+    BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv bf16: unsupported channel chunk %d", ck);             \
+  }
+#define CONV_DEFINE_LAUNCH_F32(KS, DIL)                                                         \
+  template <> int conv_launch<float, KS, DIL>(const ConvParams& p, int ck, hipStream_t st) {    \
+    switch (ck) {                                                                               \
+      case 16: return conv_launch_ck<float, KS, 16, DIL>(p, st);                                \
+      case 8: return conv_launch_ck<float, KS, 8, DIL>(p, st);                                  \
+      case 4: return conv_launch_ck<float, KS, 4, DIL>(p, st);                                  \
+    }                                                                                           \
+    BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv f32: unsupported channel chunk %d", ck);              \
+  }

@@ -1,0 +1,330 @@
+// Weight gradient of the 3x3x3 convolution (autograd of nn.Conv3d, networks/equiunet2020.py:19-25)
+// as an MFMA GEMM whose reduction dimension is the voxel index:
+//     dW[tap][co][ci] = sum_{n,v} dY[n,v][co] * X[n, v + off(tap)][ci]
+//   A operand = dY^T  (rows = co, k = voxel)      B operand = X (k = voxel, cols = ci)
+// Both operands are channel-minor in HBM/LDS but MFMA wants 8 consecutive k per lane, so bf16
+// fragments are fetched with the gfx950 transposing LDS read (ds_read_b64_tr_b16); f32 uses K=4
+// MFMAs whose one-value-per-lane operands are natural ds_read_b32.
+// Workgroup = 4 waves; every wave owns the accumulators of taps {w, w+4, ...} (<= 7 taps x COF x CIF
+// fragments, kept in registers across ALL the spatial tiles the workgroup walks), so an X halo tile
+// and a dY tile are staged once per tile and reused by 27 taps x COF x CIF MFMAs per k-step.
+// Split-K over workgroups writes f32 slabs ws[split][tap][co][ci]; a second kernel reduces them in a
+// fixed order (bitwise reproducible, no float atomics) into torch's [co][ci][tap] layout.
+#include "common.hpp"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradParams {
+  const void* x1; const void* x2; int c1, c2, p1, p2;
+  const void* dy; int dyp;
+  float* ws;
+  int N, D, H, W, cin, cout;
+  int tz, ty, tx, ntiles, nsplit;
+};
+
+constexpr int WG_TZ = 4, WG_TY = 8, WG_TX = 8, WG_VOX = 256;
+
+template <typename T, int DIL, int COF, int CIF>
+struct WgGeom {
+  static constexpr bool BF = std::is_same<T, bf16_t>::value;
+  static constexpr int ESZ = sizeof(T);
+  static constexpr int EPL = 16 / ESZ;
+  static constexpr int HZ = WG_TZ + 2 * DIL, HY = WG_TY + 2 * DIL, HX = WG_TX + 2 * DIL;
+  static constexpr int HVOX = HZ * HY * HX;
+  static constexpr int CI_T = 16 * CIF, CO_T = 16 * COF;
+  static constexpr int XROWB = CI_T * ESZ, YROWB = CO_T * ESZ;
+  static constexpr int SX = XROWB + 16, SY = YROWB + 16;
+  static constexpr int XPPV = XROWB / 16, YPPV = YROWB / 16;
+  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;
+  static constexpr int XITER = (XPIECES + 255) / 256, YITER = (YPIECES + 255) / 256;
+  static constexpr int LDS_X = HVOX * SX, LDS_Y = WG_VOX * SY;
+  static constexpr int LDS = LDS_X + LDS_Y;
+  static constexpr int TPW = 7;  // taps per wave (27 = 7+7+7+6)
+};
+
+DEVI bf16x8 tr_pair(const char* p0, const char* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, int DIL, int COF, int CIF>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p) {
+  using G = WgGeom<T, DIL, COF, CIF>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldx = lds;
+  char* ldy = lds + G::LDS_X;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, v = lane & 15;
+  const int split = blockIdx.x, cot = blockIdx.y, cit = blockIdx.z;
+  const int co0 = cot * G::CO_T, ci0 = cit * G::CI_T;
+  const T* xsrc;
+  int xpitch;
+  if (ci0 < p.c1) { xsrc = (const T*)p.x1 + ci0; xpitch = p.p1; }
+  else { xsrc = (const T*)p.x2 + (ci0 - p.c1); xpitch = p.p2; }
+  const int ci_lim = (ci0 < p.c1 ? p.c1 : p.c1 + p.c2) - ci0;  // valid channels from this source in the tile
+  const int co_lim = p.cout - co0;
+
+  f32x4 acc[G::TPW][COF][CIF];
+#pragma unroll
+  for (int j = 0; j < G::TPW; ++j)
+#pragma unroll
+    for (int m = 0; m < COF; ++m)
+#pragma unroll
+      for (int n = 0; n < CIF; ++n) acc[j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-wave tap offsets into the halo tile (bytes)
+  int tapo[G::TPW];
+#pragma unroll
+  for (int j = 0; j < G::TPW; ++j) {
+    const int t = wave + 4 * j;
+    tapo[j] = t < 27 ? ((((t / 9) * DIL) * G::HY + ((t / 3) % 3) * DIL) * G::HX + (t % 3) * DIL) * G::SX : 0;
+  }
+
+  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+    int bt = tile;
+    const int txi = bt % p.tx; bt /= p.tx;
+    const int tyi = bt % p.ty; bt /= p.ty;
+    const int tzi = bt % p.tz;
+    const int n = bt / p.tz;
+    const int z0 = tzi * WG_TZ, y0 = tyi * WG_TY, x0 = txi * WG_TX;
+    const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+    // ---- stage X halo tile and dY tile (zero-filled outside the volume / channel range) ----
+    u32x4 rx[G::XITER], ry[G::YITER];
+#pragma unroll
+    for (int i = 0; i < G::XITER; ++i) {
+      const int pc = tid + 256 * i;
+      const int hv = pc / G::XPPV, part = pc % G::XPPV;
+      const int hz = hv / (G::HY * G::HX), rr = hv % (G::HY * G::HX);
+      const int hy = rr / G::HX, hx = rr % G::HX;
+      const int gz = z0 - DIL + hz, gy = y0 - DIL + hy, gx = x0 - DIL + hx;
+      const bool ok = pc < G::XPIECES && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W &&
+                      part * G::EPL < ci_lim;
+      rx[i] = u32x4{0u, 0u, 0u, 0u};
+      if (ok) rx[i] = *(const u32x4*)(xsrc + (sample_vox + (size_t)(gz * p.H + gy) * p.W + gx) * xpitch + part * G::EPL);
+    }
+#pragma unroll
+    for (int i = 0; i < G::YITER; ++i) {
+      const int pc = tid + 256 * i;
+      const int vx = pc / G::YPPV, part = pc % G::YPPV;
+      const int gz = z0 + vx / 64, gy = y0 + (vx / 8) % 8, gx = x0 + vx % 8;
+      const bool ok = pc < G::YPIECES && gz < p.D && gy < p.H && gx < p.W && part * G::EPL < co_lim;
+      ry[i] = u32x4{0u, 0u, 0u, 0u};
+      if (ok) ry[i] = *(const u32x4*)((const T*)p.dy + (sample_vox + (size_t)(gz * p.H + gy) * p.W + gx) * p.dyp + co0 + part * G::EPL);
+    }
+    __syncthreads();  // previous tile's reads are done
+#pragma unroll
+    for (int i = 0; i < G::XITER; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < G::XPIECES) *(u32x4*)(ldx + (pc / G::XPPV) * G::SX + (pc % G::XPPV) * 16) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < G::YITER; ++i) {
+      const int pc = tid + 256 * i;
+      if (pc < G::YPIECES) *(u32x4*)(ldy + (pc / G::YPPV) * G::SY + (pc % G::YPPV) * 16) = ry[i];
+    }
+    __syncthreads();
+
+    // ---- MFMA over the 256 voxels of the tile ----
+    if constexpr (G::BF) {
+      // k-step s = voxels of flattened rows 4s..4s+3 (row = z*8+y), quarter q -> row 4s+q; the two
+      // transposing reads fetch x = 0..3 and x = 4..7 (lane 4q'+p of a quarter: voxel x=q', chans 4p..4p+3)
+      const int qq = v >> 2, pp = v & 3;
+      const int ybase = ((q * 8) + qq) * G::SY + pp * 8;
+      const int xbase = (q * G::HX + qq) * G::SX + pp * 8;  // tap (0,0,0) corner; tapo[] adds the tap shift
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int yoff = ybase + (32 * s) * G::SY;
+        const int xoff = xbase + (((s >> 1) * G::HY + 4 * (s & 1)) * G::HX) * G::SX;
+        bf16x8 a[COF];
+#pragma unroll
+        for (int m = 0; m < COF; ++m) a[m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 4 * G::SY + m * 32);
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+          if (wave + 4 * j < 27) {
+#pragma unroll
+            for (int n = 0; n < CIF; ++n) {
+              const bf16x8 b = tr_pair(ldx + xoff + tapo[j] + n * 32, ldx + xoff + tapo[j] + 4 * G::SX + n * 32);
+#pragma unroll
+              for (int m = 0; m < COF; ++m) acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[j][m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
+      // f32: k-step s' = voxels 4s'..4s'+3 of the flattened tile, quarter q -> voxel 4s'+q
+#pragma unroll 4
+      for (int s = 0; s < 64; ++s) {
+        const int vx = 4 * s + q;
+        const int z = vx >> 6, y = (vx >> 3) & 7, x = vx & 7;
+        const int yoff = vx * G::SY + v * 4;
+        const int xoff = ((z * G::HY + y) * G::HX + x) * G::SX + v * 4;
+        float a[COF];
+#pragma unroll
+        for (int m = 0; m < COF; ++m) a[m] = *(const float*)(ldy + yoff + m * 64);
+#pragma unroll
+        for (int j = 0; j < G::TPW; ++j) {
+          if (wave + 4 * j < 27) {
+#pragma unroll
+            for (int n = 0; n < CIF; ++n) {
+              const float b = *(const float*)(ldx + xoff + tapo[j] + n * 64);
+#pragma unroll
+              for (int m = 0; m < COF; ++m) acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[j][m][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write the split's slab: ws[split][tap][co][ci] ----
+#pragma unroll
+  for (int j = 0; j < G::TPW; ++j) {
+    const int t = wave + 4 * j;
+    if (t < 27) {
+      float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
+#pragma unroll
+      for (int m = 0; m < COF; ++m)
+#pragma unroll
+        for (int n = 0; n < CIF; ++n) {
+          const int ci = ci0 + n * 16 + v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = co0 + m * 16 + 4 * q + r;
+            if (co < p.cout && n * 16 + v < ci_lim) base[(size_t)co * p.cin + ci] = acc[j][m][n][r];
+          }
+        }
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int cout, int cin) {
+  const size_t per = (size_t)27 * cout * cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * per + i];
+    const int ci = i % cin;
+    const int co = (i / cin) % cout;
+    const int tap = (int)(i / ((size_t)cin * cout));
+    dw[((size_t)co * cin + ci) * 27 + tap] = s;
+  }
+}
+
+// dbias[c] = sum_v dy[v][c]
+template <typename T>
+__global__ void dbias_kernel(const T* __restrict__ dy, int pitch, float* __restrict__ db, size_t voxels, int C) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (size_t v = threadIdx.x; v < voxels; v += blockDim.x) s += to_f<T>(dy[v * pitch + c]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int m = 128; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[c] = red[0];
+}
+
+static int wgrad_nsplit(int ntiles, int cotiles, int citiles) {
+  int ns = ceil_div(512, cotiles * citiles);
+  if (ns > ntiles) ns = ntiles;
+  if (ns < 1) ns = 1;
+  return ns;
+}
+static void wgrad_tiles(int dtype, int c1, int c2, int cout, int* cof, int* cif) {
+  const int co16 = ceil_div(cout, 16);
+  *cof = co16 % 3 == 0 ? 3 : (co16 % 2 == 0 ? 2 : 1);
+  if (dtype == BRATS_F32) { *cif = 1; return; }
+  // the ci tile must not straddle the x1|x2 boundary
+  const int a = ceil_div(c1, 16), b = c2 > 0 ? ceil_div(c2, 16) : 0;
+  auto ok = [&](int f) { return a % f == 0 && (b == 0 || b % f == 0); };
+  *cif = ok(3) ? 3 : (ok(2) ? 2 : 1);
+}
+
+extern "C" size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout) {
+  if (ksize != 3) return 0;
+  int cof, cif;
+  wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
+  const int ntiles = N * ceil_div(D, WG_TZ) * ceil_div(H, WG_TY) * ceil_div(W, WG_TX);
+  const int cin_tiles = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
+  const int ns = wgrad_nsplit(ntiles, ceil_div(cout, 16 * cof), cin_tiles);
+  return (size_t)ns * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
+}
+
+template <typename T, int DIL, int COF, int CIF>
+static int wgrad_launch(const WgradParams& p, dim3 grid, hipStream_t st) {
+  using G = WgGeom<T, DIL, COF, CIF>;
+  auto kern = conv_wgrad_kernel<T, DIL, COF, CIF>;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", G::LDS, hipGetErrorString(e));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS, st, p);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int DIL>
+static int wgrad_dispatch(const WgradParams& p, int cof, int cif, dim3 grid, hipStream_t st) {
+#define WG_CASE(A, B) if (cof == A && cif == B) return wgrad_launch<T, DIL, A, B>(p, grid, st);
+  WG_CASE(3, 1) WG_CASE(2, 1) WG_CASE(1, 1)
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    WG_CASE(3, 3) WG_CASE(3, 2) WG_CASE(2, 3) WG_CASE(2, 2) WG_CASE(1, 3) WG_CASE(1, 2)
+  }
+#undef WG_CASE
+  BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: unsupported tile %dx%d", cof, cif);
+}
+
+extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy,
+                                  int dypitch, float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N,
+                                  int D, int H, int W, int cout, brats_stream_t s) {
+  if (!x1 || !dy || !ws || !dw || c1 <= 0 || cout <= 0) BRATS_FAIL(BRATS_E_ARG, "wgrad: null pointer / bad size");
+  if (ksize != 3 || (dil != 1 && dil != 2)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: ksize=%d dil=%d unsupported", ksize, dil);
+  if (c2 < 0) c2 = 0;
+  if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "wgrad: c2 > 0 but x2 NULL");
+  const int epl = dtype == BRATS_BF16 ? 8 : 4;
+  if (pitch1 % epl || (c2 && pitch2 % epl) || dypitch % epl || c1 % epl || c2 % epl || cout % epl)
+    BRATS_FAIL(BRATS_E_ARG, "wgrad: channel counts / pitches must be multiples of %d", epl);
+  int cof, cif;
+  wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
+  WgradParams p;
+  p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
+  p.dy = dy; p.dyp = dypitch; p.ws = ws;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.cin = c1 + c2; p.cout = cout;
+  p.tz = ceil_div(D, WG_TZ); p.ty = ceil_div(H, WG_TY); p.tx = ceil_div(W, WG_TX);
+  p.ntiles = N * p.tz * p.ty * p.tx;
+  const int cot = ceil_div(cout, 16 * cof);
+  const int cit = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
+  p.nsplit = wgrad_nsplit(p.ntiles, cot, cit);
+  // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
+  if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
+  hipStream_t st = (hipStream_t)s;
+  // slab entries of padded ci columns (c1 not a multiple of 16) are never written: clear the slab
+  if ((c1 + c2) % 16 || cout % 16) {
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * 27 * cout * p.cin * sizeof(float), st);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: memset: %s", hipGetErrorString(e));
+  }
+  dim3 grid(p.nsplit, cot, cit);
+  int rc;
+  if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
+  else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);
+  if (rc) return rc;
+  const size_t per = (size_t)27 * cout * p.cin;
+  size_t blocks = (per + 255) / 256;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, (const float*)ws, dw,
+                     p.nsplit, cout, p.cin);
+  if (dbias) {
+    const size_t vox = (size_t)N * D * H * W;
+    if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
+    else hipLaunchKernelGGL(dbias_kernel<float>, dim3(cout), dim3(256), 0, st, (const float*)dy, dypitch, dbias, vox, cout);
+  }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,208 @@
+// Segmentation heads: 1x1x1 conv C -> K (K <= 4) + bias, then trilinear (align_corners) up-sampling to
+// full resolution, emitted as NCDHW f32 logits for the PyTorch Dice loss (learning/engine.py:312-333).
+// Reference: conv1x1 networks/equiunet2020.py:37-41 (outconv :441, deep heads :443-458).
+// Pure HBM-bound kernels (AI <= 3 FLOP/B): no MFMA on purpose.
+#include "common.hpp"
+
+int brats_lerp_adjoint_f32_planes(const float* in, float* out, size_t outer, int Lout, int Lin, size_t inner, hipStream_t st);
+
+static inline int sgrid(size_t total, int block) {
+  size_t b = (total + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+constexpr int HEAD_KMAX = 4;
+
+template <typename T>
+__global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ b,
+                                 float* __restrict__ low, int C, int K, size_t voxels) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float ws[];  // [K][C]
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int n = blockIdx.y;
+  const T* xb = x + (size_t)n * voxels * xpitch;
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += (size_t)gridDim.x * blockDim.x) {
+    float acc[HEAD_KMAX] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < C; c0 += VW) {
+      float a[VW];
+      Vec<T, VW>::load(xb + v * xpitch + c0, a);
+#pragma unroll
+      for (int k = 0; k < HEAD_KMAX; ++k)
+        if (k < K) {
+#pragma unroll
+          for (int j = 0; j < VW; ++j) acc[k] += a[j] * ws[k * C + c0 + j];
+        }
+    }
+    for (int k = 0; k < K; ++k) low[((size_t)n * K + k) * voxels + v] = acc[k] + (b ? b[k] : 0.f);
+  }
+}
+
+struct Lerp { int i0, i1; float w0, w1; };
+DEVI Lerp lerp_coef(int o, int in_len, float scale) {
+  const float src = scale * (float)o;
+  Lerp l;
+  l.i0 = (int)src;
+  if (l.i0 > in_len - 1) l.i0 = in_len - 1;
+  l.i1 = l.i0 + (l.i0 < in_len - 1 ? 1 : 0);
+  l.w1 = fminf(fmaxf(src - (float)l.i0, 0.f), 1.f);
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+static inline float ac_scale(int in_len, int out_len) { return out_len > 1 ? (float)(in_len - 1) / (float)(out_len - 1) : 0.f; }
+
+__global__ void upsample_planes_kernel(const float* __restrict__ low, float* __restrict__ out, size_t planes, int D, int H,
+                                       int W, int sc, float sd, float sh, float sw) {
+  const int Do = D * sc, Ho = H * sc, Wo = W * sc;
+  const size_t total = planes * Do * Ho * Wo;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    size_t v = it;
+    const int xo = v % Wo; v /= Wo;
+    const int yo = v % Ho; v /= Ho;
+    const int zo = v % Do;
+    const size_t pl = v / Do;
+    const Lerp lz = lerp_coef(zo, D, sd), ly = lerp_coef(yo, H, sh), lx = lerp_coef(xo, W, sw);
+    const float* p = low + pl * D * H * W;
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = (k & 4) ? lz.i1 : lz.i0, yy = (k & 2) ? ly.i1 : ly.i0, xx = (k & 1) ? lx.i1 : lx.i0;
+      const float wgt = ((k & 4) ? lz.w1 : lz.w0) * ((k & 2) ? ly.w1 : ly.w0) * ((k & 1) ? lx.w1 : lx.w0);
+      o += wgt * p[((size_t)z * H + yy) * W + xx];
+    }
+    out[it] = o;
+  }
+}
+
+extern "C" int brats_head_fwd(const void* x, int xpitch, const float* w, const float* b, float* lowres, float* out,
+                              int dtype, int N, int C, int K, int D, int H, int W, int scale, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !w || !out || K < 1 || K > HEAD_KMAX || C % vw || xpitch % vw || scale < 1)
+    BRATS_FAIL(BRATS_E_ARG, "head_fwd: bad argument (K<=4, C multiple of %d)", vw);
+  if (scale > 1 && !lowres) BRATS_FAIL(BRATS_E_ARG, "head_fwd: lowres workspace required when scale > 1");
+  hipStream_t st = (hipStream_t)s;
+  const size_t vox = (size_t)D * H * W;
+  float* low = scale > 1 ? lowres : out;
+  dim3 grid(sgrid(vox, 256), N);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(head_conv_kernel<bf16_t>, grid, dim3(256), K * C * sizeof(float), st, (const bf16_t*)x, xpitch, w, b,
+                       low, C, K, vox);
+  else
+    hipLaunchKernelGGL(head_conv_kernel<float>, grid, dim3(256), K * C * sizeof(float), st, (const float*)x, xpitch, w, b, low,
+                       C, K, vox);
+  if (scale > 1) {
+    const size_t total = (size_t)N * K * vox * scale * scale * scale;
+    hipLaunchKernelGGL(upsample_planes_kernel, dim3(sgrid(total, 256)), dim3(256), 0, st, (const float*)low, out, (size_t)N * K,
+                       D, H, W, scale, ac_scale(D, D * scale), ac_scale(H, H * scale), ac_scale(W, W * scale));
+  }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx[v][c] = sum_k dlow[k][v]*w[k][c];  dw[k][c] += sum_v dlow[k][v]*x[v][c];  db[k] += sum_v dlow[k][v]
+template <typename T>
+__global__ void head_bwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ dlow,
+                                T* __restrict__ dx, int dxpitch, float* __restrict__ dw, float* __restrict__ db, int C, int K,
+                                size_t voxels) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];
+  float* ws = sm;  // [K][C]
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  float aw[HEAD_KMAX][VW];
+  float ab[HEAD_KMAX];
+#pragma unroll
+  for (int k = 0; k < HEAD_KMAX; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) aw[k][j] = 0.f;
+  }
+  if (myvl < vl_n) {
+    const T* xb = x + (size_t)n * voxels * xpitch;
+    T* dxb = dx ? dx + (size_t)n * voxels * dxpitch : nullptr;
+    for (size_t v = (size_t)blockIdx.x * vl_n + myvl; v < voxels; v += (size_t)gridDim.x * vl_n) {
+      float a[VW], o[VW], g[HEAD_KMAX];
+      Vec<T, VW>::load(xb + v * xpitch + c0, a);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < HEAD_KMAX; ++k) {
+        g[k] = k < K ? dlow[((size_t)n * K + k) * voxels + v] : 0.f;
+        ab[k] += g[k];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          aw[k][j] += g[k] * a[j];
+          if (k < K) o[j] += g[k] * ws[k * C + c0 + j];
+        }
+      }
+      if (dxb) Vec<T, VW>::store(dxb + v * dxpitch + c0, o);
+    }
+  }
+  float* scr = sm + K * C;  // [vl_n][K][C] + [vl_n][K]
+  __syncthreads();
+  if (myvl < vl_n) {
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) scr[(myvl * K + k) * C + c0 + j] = aw[k][j];
+      if (mycv == 0) scr[vl_n * K * C + myvl * K + k] = ab[k];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += scr[l * K * C + i];
+    atomicAdd(dw + i, t);
+  }
+  if ((int)threadIdx.x < K) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += scr[vl_n * K * C + l * K + threadIdx.x];
+    atomicAdd(db + threadIdx.x, t);
+  }
+}
+
+extern "C" size_t brats_head_bwd_ws_bytes(int N, int K, int D, int H, int W, int scale) {
+  if (scale <= 1) return 0;
+  const size_t p = (size_t)N * K;
+  const size_t dlow = p * D * H * W, t1 = p * D * (H * scale) * (W * scale), t2 = p * D * H * (W * scale);
+  return (dlow + t1 + t2) * sizeof(float);
+}
+
+extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout, float* ws, void* dx, int dxpitch,
+                              float* dw, float* db, int dtype, int N, int C, int K, int D, int H, int W, int scale,
+                              brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !w || !dout || !dw || !db || K < 1 || K > HEAD_KMAX || C % vw || xpitch % vw || (dx && dxpitch % vw) ||
+      C / vw > 128)
+    BRATS_FAIL(BRATS_E_ARG, "head_bwd: bad argument");
+  if (scale > 1 && !ws) BRATS_FAIL(BRATS_E_ARG, "head_bwd: workspace required when scale > 1");
+  hipStream_t st = (hipStream_t)s;
+  const size_t vox = (size_t)D * H * W, p = (size_t)N * K;
+  const float* dlow = dout;
+  if (scale > 1) {
+    float* dl = ws;
+    float* t1 = dl + p * vox;
+    float* t2 = t1 + p * D * (H * scale) * (W * scale);
+    int rc;
+    if ((rc = brats_lerp_adjoint_f32_planes(dout, t1, p, D * scale, D, (size_t)H * scale * W * scale, st))) return rc;
+    if ((rc = brats_lerp_adjoint_f32_planes(t1, t2, p * D, H * scale, H, (size_t)W * scale, st))) return rc;
+    if ((rc = brats_lerp_adjoint_f32_planes(t2, dl, p * D * H, W * scale, W, 1, st))) return rc;
+    dlow = dl;
+  }
+  hipError_t e = hipMemsetAsync(dw, 0, (size_t)K * C * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)K * sizeof(float), st);
+  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "head_bwd: memset: %s", hipGetErrorString(e));
+  const int cv = C / vw, vl = 256 / cv;
+  size_t gx = (vox + (size_t)vl * 16 - 1) / ((size_t)vl * 16);
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 1024 ? 1024 : gx)), N);
+  const size_t lds = (size_t)(K * C + vl * K * C + vl * K) * sizeof(float);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, w, dlow, (bf16_t*)dx,
+                       dxpitch, dw, db, C, K, vox);
+  else
+    hipLaunchKernelGGL(head_bwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, w, dlow, (float*)dx, dxpitch,
+                       dw, db, C, K, vox);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}

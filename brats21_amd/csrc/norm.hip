@@ -1,0 +1,271 @@
+// GroupNorm(8)+activation and EvoNorm-S0 (statistics finalize, fused apply, backward), NDHWC.
+// HBM-bound streaming kernels: 16-byte vector accesses, per-sample scale/shift staged in LDS.
+// Reference semantics: nn.GroupNorm(8, C) networks/factory.py:179-182 (biased var, eps 1e-5),
+// activations networks/factory.py:195-200; EvoNorm3D S0 networks/equiunet2021.py:95-103 (unbiased
+// group variance, x*sigmoid(x) numerator).
+#include "common.hpp"
+
+// ---- statistics finalize: one block per (n, group) ---------------------------------------------
+__global__ void gn_finalize_kernel(const float* __restrict__ stats, int tps, int C, int groups, double count_per_channel,
+                                   float eps, int unbiased, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean_rstd, float* __restrict__ scale_shift) {
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups;
+  double s1 = 0.0, s2 = 0.0;
+  const int items = tps * cpg;
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int t = it / cpg, j = it % cpg;
+    const f32x2 v = *(const f32x2*)(stats + (((size_t)n * tps + t) * C + g * cpg + j) * 2);
+    s1 += v[0];
+    s2 += v[1];
+  }
+  __shared__ double r1[256], r2[256];
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int m = blockDim.x / 2; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+    __syncthreads();
+  }
+  const double M = count_per_channel * cpg;
+  const double mean = r1[0] / M;
+  double var = r2[0] / M - mean * mean;
+  if (unbiased) var = var * M / (M - 1.0);
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    mean_rstd[(n * groups + g) * 2] = (float)mean;
+    mean_rstd[(n * groups + g) * 2 + 1] = rstd;
+  }
+  if (scale_shift && (int)threadIdx.x < cpg) {
+    const int c = g * cpg + threadIdx.x;
+    const float sc = rstd * gamma[c];
+    scale_shift[((size_t)n * C + c) * 2] = sc;
+    scale_shift[((size_t)n * C + c) * 2 + 1] = beta[c] - (float)mean * sc;
+  }
+}
+
+extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
+                                 double count_per_channel, float eps, const float* gamma, const float* beta,
+                                 float* mean_rstd, float* scale_shift, brats_stream_t s) {
+  if (!stats || !mean_rstd || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
+  if (scale_shift && (!gamma || !beta)) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: scale_shift needs gamma/beta");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, stats, tiles_per_sample, C, groups,
+                     count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- z = act(y*scale + shift) ------------------------------------------------------------------
+DEVI float act_fwd(float x, int act, float slope) {
+  if (act == BRATS_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == BRATS_ACT_LEAKY) return x > 0.f ? x : x * slope;
+  return x;
+}
+DEVI float act_grad(float x, int act, float slope) {  // derivative at pre-activation x
+  if (act == BRATS_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == BRATS_ACT_LEAKY) return x > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+template <typename T>
+__global__ void affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
+                                  T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float ss[];  // [C][2]
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) ss[i] = scale_shift[(size_t)n * C * 2 + i];
+  __syncthreads();
+  const int cv = C / VW;
+  const size_t total = (size_t)voxels * cv;
+  const T* yb = y + (size_t)n * voxels * ypitch;
+  T* zb = z + (size_t)n * voxels * zpitch;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const size_t vox = it / cv;
+    const int c0 = (int)(it % cv) * VW;
+    float a[VW];
+    Vec<T, VW>::load(yb + vox * ypitch + c0, a);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) a[j] = act_fwd(a[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1], act, slope);
+    Vec<T, VW>::store(zb + vox * zpitch + c0, a);
+  }
+}
+
+static inline int stream_grid(size_t total, int block) {
+  size_t b = (total + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
+                                    int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!y || !z || !scale_shift || C % vw || ypitch % vw || zpitch % vw)
+    BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d", vw);
+  dim3 grid(stream_grid((size_t)voxels * (C / vw), 256), N);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
+                       ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C);
+  else
+    hipLaunchKernelGGL(affine_act_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
+                       ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- backward of z = act(GN(y)) ----------------------------------------------------------------
+// pass 1: red[n][c] = { sum_v u, sum_v u*xhat },  u = dz * act'(y*scale+shift), xhat = (y-mean_g)*rstd_g
+template <typename T>
+__global__ void gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y, int ypitch,
+                                     const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
+                                     float* __restrict__ red, int act, float slope, int voxels, int C, int groups) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];  // ss[C*2], mr[C*2] (per channel mean,rstd), then reduction scratch
+  float* ss = sm;
+  float* mr = sm + 2 * C;
+  const int n = blockIdx.y;
+  const int cpg = C / groups;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    ss[i] = scale_shift[(size_t)n * C * 2 + i];
+    mr[i] = mean_rstd[(n * groups + (i >> 1) / cpg) * 2 + (i & 1)];
+  }
+  __syncthreads();
+  const int cv = C / VW;
+  const int vl_n = blockDim.x / cv;  // voxel lanes per block
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv;
+  const int c0 = mycv * VW;
+  float a1[VW], a2[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) a1[j] = a2[j] = 0.f;
+  if (myvl < vl_n) {
+    const T* dzb = dz + (size_t)n * voxels * dzpitch;
+    const T* yb = y + (size_t)n * voxels * ypitch;
+    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
+      float g[VW], yy[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
+      Vec<T, VW>::load(yb + vox * ypitch + c0, yy);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const float pre = yy[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1];
+        const float u = g[j] * act_grad(pre, act, slope);
+        const float xh = (yy[j] - mr[(c0 + j) * 2]) * mr[(c0 + j) * 2 + 1];
+        a1[j] += u;
+        a2[j] += u * xh;
+      }
+    }
+  }
+  // block reduction over voxel lanes through LDS, then one atomic per channel per block
+  float* scr = sm + 4 * C;  // [vl_n][C][2]
+  __syncthreads();
+  if (myvl < vl_n) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      scr[(myvl * C + c0 + j) * 2] = a1[j];
+      scr[(myvl * C + c0 + j) * 2 + 1] = a2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += scr[l * C * 2 + i];
+    atomicAdd(red + (size_t)n * C * 2 + i, t);
+  }
+}
+
+// pass 2: dy = rstd*(u*gamma - m1 - xhat*m2);  block (0,0) also finishes dgamma/dbeta
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y, int ypitch,
+                                    const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ red, T* __restrict__ dy,
+                                    int dypitch, float* __restrict__ dgamma, float* __restrict__ dbeta, int act, float slope,
+                                    int N, int voxels, int C, int groups) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];
+  float* ss = sm;            // [C][2]
+  float* mr = sm + 2 * C;    // [C][2] mean, rstd per channel
+  float* gm = sm + 4 * C;    // [C] gamma
+  float* m12 = sm + 5 * C;   // [C][2] m1, m2 per channel (group values replicated)
+  const int n = blockIdx.y;
+  const int cpg = C / groups;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    ss[i] = scale_shift[(size_t)n * C * 2 + i];
+    mr[i] = mean_rstd[(n * groups + (i >> 1) / cpg) * 2 + (i & 1)];
+  }
+  for (int i = threadIdx.x; i < C; i += blockDim.x) gm[i] = gamma[i];
+  __syncthreads();
+  const float invM = 1.f / ((float)cpg * (float)voxels);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g0 = (c / cpg) * cpg;
+    float t1 = 0.f, t2 = 0.f;
+    for (int j = 0; j < cpg; ++j) {
+      t1 += gm[g0 + j] * red[((size_t)n * C + g0 + j) * 2];
+      t2 += gm[g0 + j] * red[((size_t)n * C + g0 + j) * 2 + 1];
+    }
+    m12[c * 2] = t1 * invM;
+    m12[c * 2 + 1] = t2 * invM;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float b = 0.f, g = 0.f;
+      for (int m = 0; m < N; ++m) { b += red[((size_t)m * C + c) * 2]; g += red[((size_t)m * C + c) * 2 + 1]; }
+      dbeta[c] = b;
+      dgamma[c] = g;
+    }
+  }
+  __syncthreads();
+  const int cv = C / VW;
+  const size_t total = (size_t)voxels * cv;
+  const T* dzb = dz + (size_t)n * voxels * dzpitch;
+  const T* yb = y + (size_t)n * voxels * ypitch;
+  T* dyb = dy + (size_t)n * voxels * dypitch;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const size_t vox = it / cv;
+    const int c0 = (int)(it % cv) * VW;
+    float g[VW], yy[VW], o[VW];
+    Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
+    Vec<T, VW>::load(yb + vox * ypitch + c0, yy);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int c = c0 + j;
+      const float pre = yy[j] * ss[c * 2] + ss[c * 2 + 1];
+      const float u = g[j] * act_grad(pre, act, slope);
+      const float rstd = mr[c * 2 + 1];
+      const float xh = (yy[j] - mr[c * 2]) * rstd;
+      o[j] = rstd * (u * gm[c] - m12[c * 2] - xh * m12[c * 2 + 1]);
+    }
+    Vec<T, VW>::store(dyb + vox * dypitch + c0, o);
+  }
+}
+
+extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
+                                const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red,
+                                float* dgamma, float* dbeta, int dtype, int act, float slope, int N, int voxels,
+                                int C, int groups, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dz || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: null pointer");
+  if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: C=%d / pitches must be multiples of %d", C, vw);
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * C * 2 * sizeof(float), st);
+  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "gn_act_bwd: memset: %s", hipGetErrorString(e));
+  const int cv = C / vw, vl = 256 / cv;
+  const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
+  dim3 g1(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
+  const size_t lds1 = (size_t)(4 * C + vl * C * 2) * sizeof(float);
+  dim3 g2(stream_grid((size_t)voxels * cv, 256), N);
+  const size_t lds2 = (size_t)7 * C * sizeof(float);
+  if (dtype == BRATS_BF16) {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                       ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                       ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                       voxels, C, groups);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
+                       ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
+                       ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                       voxels, C, groups);
+  }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}

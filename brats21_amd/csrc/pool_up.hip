@@ -1,0 +1,298 @@
+// 2x2x2 max / max+avg pooling and align_corners=True trilinear up-sampling (forward + adjoint), NDHWC.
+// All HBM-bound: 16-byte channel vectors per thread, coalesced along the channel-minor layout.
+// Reference: nn.MaxPool3d(2,2) networks/equiunet2020.py:433; MONAI MaxAvgPool networks/equiunet2021.py:261
+// (cat([max, avg], dim=1)); nn.Upsample(trilinear, align_corners=True) networks/equiunet2020.py:439.
+#include "common.hpp"
+
+static inline int stream_grid(size_t total, int block) {
+  size_t b = (total + block - 1) / block;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ---- pooling -----------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch, int N, int C,
+                                    int D, int H, int W, int with_avg) {
+  constexpr int VW = 16 / sizeof(T);
+  const int cv = C / VW, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)N * Do * Ho * Wo * cv;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(it % cv) * VW;
+    size_t v = it / cv;
+    const int xo = v % Wo; v /= Wo;
+    const int yo = v % Ho; v /= Ho;
+    const int zo = v % Do;
+    const int n = (int)(v / Do);
+    float mx[VW], sm[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      float a[VW];
+      Vec<T, VW>::load(x + ((((size_t)n * D + z) * H + yy) * W + xx) * xpitch + c0, a);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) { mx[j] = (a[j] > mx[j] || a[j] != a[j]) ? a[j] : mx[j]; sm[j] += a[j]; }
+    }
+    T* yo_p = y + ((((size_t)n * Do + zo) * Ho + yo) * Wo + xo) * ypitch;
+    Vec<T, VW>::store(yo_p + c0, mx);
+    if (with_avg) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) sm[j] *= 0.125f;
+      Vec<T, VW>::store(yo_p + C + c0, sm);
+    }
+  }
+}
+
+// one thread per pooled voxel x channel vector: recompute the first arg-max (torch tie rule:
+// strict '>' in d,h,w scan order) and write all 8 input-gradient voxels of the window.
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xpitch, const T* __restrict__ dy, int dypitch,
+                                    const T* __restrict__ dxs, int dxspitch, T* __restrict__ dx, int dxpitch, int N, int C,
+                                    int D, int H, int W, int with_avg) {
+  constexpr int VW = 16 / sizeof(T);
+  const int cv = C / VW, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)N * Do * Ho * Wo * cv;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(it % cv) * VW;
+    size_t v = it / cv;
+    const int xo = v % Wo; v /= Wo;
+    const int yo = v % Ho; v /= Ho;
+    const int zo = v % Do;
+    const int n = (int)(v / Do);
+    float a[8][VW];
+    float mx[VW];
+    int am[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; am[j] = 0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      Vec<T, VW>::load(x + ((((size_t)n * D + z) * H + yy) * W + xx) * xpitch + c0, a[k]);
+#pragma unroll
+      for (int j = 0; j < VW; ++j)
+        if (a[k][j] > mx[j] || a[k][j] != a[k][j]) { mx[j] = a[k][j]; am[j] = k; }
+    }
+    const T* dyp = dy + ((((size_t)n * Do + zo) * Ho + yo) * Wo + xo) * dypitch;
+    float g[VW], ga[VW];
+    Vec<T, VW>::load(dyp + c0, g);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) ga[j] = 0.f;
+    if (with_avg) {
+      Vec<T, VW>::load(dyp + C + c0, ga);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) ga[j] *= 0.125f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
+      const size_t vox = (((size_t)n * D + z) * H + yy) * W + xx;
+      float o[VW];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) o[j] = ga[j] + (am[j] == k ? g[j] : 0.f);
+      if (dxs) {
+        float sk[VW];
+        Vec<T, VW>::load(dxs + vox * dxspitch + c0, sk);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) o[j] += sk[j];
+      }
+      Vec<T, VW>::store(dx + vox * dxpitch + c0, o);
+    }
+  }
+}
+
+extern "C" int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
+                                  int W, int with_avg, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !y || C % vw || xpitch % vw || ypitch % vw || (D | H | W) & 1)
+    BRATS_FAIL(BRATS_E_ARG, "maxpool2_fwd: C/pitch multiple of %d and even spatial dims required", vw);
+  const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vw);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch, N, C, D, H, W, with_avg);
+  else
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)x, xpitch, (float*)y, ypitch, N, C, D, H, W, with_avg);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int brats_maxpool2_bwd(const void* x, int xpitch, const void* y, int ypitch, const void* dy, int dypitch,
+                                  const void* dx_skip, int dxskip_pitch, void* dx, int dxpitch, int dtype, int N, int C,
+                                  int D, int H, int W, int with_avg, brats_stream_t s) {
+  (void)y; (void)ypitch;  // arg-max is recomputed from x
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !dy || !dx || C % vw || xpitch % vw || dypitch % vw || dxpitch % vw || (dx_skip && dxskip_pitch % vw) ||
+      (D | H | W) & 1)
+    BRATS_FAIL(BRATS_E_ARG, "maxpool2_bwd: bad argument");
+  const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vw);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16_t>, dim3(stream_grid(total, 128)), dim3(128), 0, (hipStream_t)s,
+                       (const bf16_t*)x, xpitch, (const bf16_t*)dy, dypitch, (const bf16_t*)dx_skip, dxskip_pitch,
+                       (bf16_t*)dx, dxpitch, N, C, D, H, W, with_avg);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(stream_grid(total, 128)), dim3(128), 0, (hipStream_t)s,
+                       (const float*)x, xpitch, (const float*)dy, dypitch, (const float*)dx_skip, dxskip_pitch, (float*)dx,
+                       dxpitch, N, C, D, H, W, with_avg);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- trilinear, align_corners=True -------------------------------------------------------------
+// torch semantics (UpSample.h area_pixel_compute_source_index, align_corners): scale = (in-1)/(out-1)
+// in f32, src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), lambda1 = src - i0.
+struct Lerp { int i0, i1; float w0, w1; };
+DEVI Lerp lerp_coef(int o, int in_len, float scale) {
+  const float src = scale * (float)o;
+  Lerp l;
+  l.i0 = (int)src;
+  if (l.i0 > in_len - 1) l.i0 = in_len - 1;
+  l.i1 = l.i0 + (l.i0 < in_len - 1 ? 1 : 0);
+  l.w1 = fminf(fmaxf(src - (float)l.i0, 0.f), 1.f);
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+static inline float ac_scale(int in_len, int out_len) { return out_len > 1 ? (float)(in_len - 1) / (float)(out_len - 1) : 0.f; }
+
+template <typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch, int N, int C, int D,
+                                    int H, int W, int sc, float sd, float sh, float sw) {
+  constexpr int VW = 16 / sizeof(T);
+  const int cv = C / VW, Do = D * sc, Ho = H * sc, Wo = W * sc;
+  const size_t total = (size_t)N * Do * Ho * Wo * cv;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(it % cv) * VW;
+    size_t v = it / cv;
+    const int xo = v % Wo; v /= Wo;
+    const int yo = v % Ho; v /= Ho;
+    const int zo = v % Do;
+    const int n = (int)(v / Do);
+    const Lerp lz = lerp_coef(zo, D, sd), ly = lerp_coef(yo, H, sh), lx = lerp_coef(xo, W, sw);
+    float o[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) o[j] = 0.f;
+    const T* xb = x + (size_t)n * D * H * W * xpitch + c0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = (k & 4) ? lz.i1 : lz.i0, yy = (k & 2) ? ly.i1 : ly.i0, xx = (k & 1) ? lx.i1 : lx.i0;
+      // same association as ATen's upsample_trilinear3d: w_z * (w_y * (w_x * v ...)) -> use product of weights
+      const float w = ((k & 4) ? lz.w1 : lz.w0) * ((k & 2) ? ly.w1 : ly.w0) * ((k & 1) ? lx.w1 : lx.w0);
+      float a[VW];
+      Vec<T, VW>::load(xb + ((size_t)(z * H + yy) * W + xx) * xpitch, a);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) o[j] += w * a[j];
+    }
+    Vec<T, VW>::store(y + ((((size_t)n * Do + zo) * Ho + yo) * Wo + xo) * ypitch + c0, o);
+  }
+}
+
+extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
+                                  int W, int scale, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !y || C % vw || xpitch % vw || ypitch % vw || scale < 1)
+    BRATS_FAIL(BRATS_E_ARG, "upsample_fwd: C/pitch must be multiples of %d", vw);
+  const size_t total = (size_t)N * D * H * W * scale * scale * scale * (C / vw);
+  const float sd = ac_scale(D, D * scale), sh = ac_scale(H, H * scale), sw = ac_scale(W, W * scale);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);
+  else
+    hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
+                       (const float*)x, xpitch, (float*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// 1-D adjoint of the lerp along one axis of a tensor viewed as [outer][L][inner_vox][C(+pitch)]:
+// out[o][i][v][c] = sum_{l : i0(l)==i} w0(l)*in[o][l][v][c] + sum_{l : i1(l)==i, i1!=i0} w1(l)*in[..l..].
+// Candidates l are re-derived with the *forward's own* f32 expression, so forward and adjoint are
+// exactly transposes of each other.
+template <typename TI, typename TO, int VW>
+__global__ void lerp_adjoint_kernel(const TI* __restrict__ in, int in_pitch, TO* __restrict__ out, int out_pitch,
+                                    size_t outer, int Lout /*len of in*/, int Lin /*len of out*/, size_t inner_vox, int C,
+                                    float scale) {
+  const int cv = C / VW;
+  const size_t total = outer * Lin * inner_vox * cv;
+  const float inv = scale > 0.f ? 1.f / scale : 0.f;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(it % cv) * VW;
+    size_t v = it / cv;
+    const size_t iv = v % inner_vox; v /= inner_vox;
+    const int i = (int)(v % Lin);
+    const size_t o = v / Lin;
+    int lo = (int)floorf((float)(i - 1) * inv) - 1, hi = (int)ceilf((float)(i + 1) * inv) + 1;
+    if (scale <= 0.f) { lo = 0; hi = Lout - 1; }
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > Lout - 1 ? Lout - 1 : hi;
+    float acc[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+    for (int l = lo; l <= hi; ++l) {
+      const Lerp c = lerp_coef(l, Lin, scale);
+      float w = 0.f;
+      if (c.i0 == i) w += c.w0;
+      if (c.i1 == i) w += c.w1;  // when i1 == i0 (clamped end) both weights land on the same index
+      if (w != 0.f) {
+        float a[VW];
+        if constexpr (VW == 1) a[0] = to_f<TI>(in[((o * Lout + l) * inner_vox + iv) * in_pitch + c0]);
+        else Vec<TI, VW>::load(in + ((o * Lout + l) * inner_vox + iv) * in_pitch + c0, a);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += w * a[j];
+      }
+    }
+    if constexpr (VW == 1) out[((o * Lin + i) * inner_vox + iv) * out_pitch + c0] = from_f<TO>(acc[0]);
+    else Vec<TO, VW>::store(out + ((o * Lin + i) * inner_vox + iv) * out_pitch + c0, acc);
+  }
+}
+
+// exported for head.hip: f32 planes [outer][L][inner] adjoint
+int brats_lerp_adjoint_f32_planes(const float* in, float* out, size_t outer, int Lout, int Lin, size_t inner,
+                                  hipStream_t st) {
+  const size_t total = outer * Lin * inner;
+  hipLaunchKernelGGL((lerp_adjoint_kernel<float, float, 1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, in, 1, out, 1,
+                     outer, Lout, Lin, inner, 1, ac_scale(Lin, Lout));
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t brats_upsample_bwd_ws_bytes(int dtype, int N, int C, int D, int H, int W, int scale) {
+  const size_t esz = dtype == BRATS_BF16 ? 2 : 4;
+  const size_t a = (size_t)N * D * (H * scale) * (W * scale) * C;  // after the D pass
+  const size_t b = (size_t)N * D * H * (W * scale) * C;            // after the H pass
+  return ((a * esz + 255) / 256 * 256) + ((b * esz + 255) / 256 * 256);
+}
+
+template <typename T>
+static int upsample_bwd_t(const T* dy, int dypitch, T* dx, int dxpitch, char* tmp, int N, int C, int D, int H, int W, int sc,
+                          hipStream_t st) {
+  constexpr int VW = 16 / sizeof(T);
+  const int Do = D * sc, Ho = H * sc, Wo = W * sc;
+  const size_t a_elems = (size_t)N * D * Ho * Wo * C;
+  T* t1 = (T*)tmp;
+  T* t2 = (T*)(tmp + ((a_elems * sizeof(T) + 255) / 256 * 256));
+  // D axis: [N][Do][Ho*Wo][C] -> [N][D][Ho*Wo][C]
+  size_t total = (size_t)N * D * Ho * Wo * (C / VW);
+  hipLaunchKernelGGL((lerp_adjoint_kernel<T, T, VW>), dim3(stream_grid(total, 256)), dim3(256), 0, st, dy, dypitch, t1, C,
+                     (size_t)N, Do, D, (size_t)Ho * Wo, C, ac_scale(D, Do));
+  // H axis: [N*D][Ho][Wo][C] -> [N*D][H][Wo][C]
+  total = (size_t)N * D * H * Wo * (C / VW);
+  hipLaunchKernelGGL((lerp_adjoint_kernel<T, T, VW>), dim3(stream_grid(total, 256)), dim3(256), 0, st, (const T*)t1, C, t2, C,
+                     (size_t)N * D, Ho, H, (size_t)Wo, C, ac_scale(H, Ho));
+  // W axis: [N*D*H][Wo][1][C] -> [N*D*H][W][1][C(pitch)]
+  total = (size_t)N * D * H * W * (C / VW);
+  hipLaunchKernelGGL((lerp_adjoint_kernel<T, T, VW>), dim3(stream_grid(total, 256)), dim3(256), 0, st, (const T*)t2, C, dx,
+                     dxpitch, (size_t)N * D * H, Wo, W, (size_t)1, C, ac_scale(W, Wo));
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int brats_upsample_bwd(const void* dy, int dypitch, void* dx, int dxpitch, void* tmp, int dtype, int N, int C,
+                                  int D, int H, int W, int scale, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dy || !dx || !tmp || C % vw || dypitch % vw || dxpitch % vw) BRATS_FAIL(BRATS_E_ARG, "upsample_bwd: bad argument");
+  if (dtype == BRATS_BF16)
+    return upsample_bwd_t<bf16_t>((const bf16_t*)dy, dypitch, (bf16_t*)dx, dxpitch, (char*)tmp, N, C, D, H, W, scale,
+                                  (hipStream_t)s);
+  return upsample_bwd_t<float>((const float*)dy, dypitch, (float*)dx, dxpitch, (char*)tmp, N, C, D, H, W, scale,
+                               (hipStream_t)s);
+}

@@ -1,0 +1,259 @@
+"""EquiUnet (GroupNorm + ReLU 3D U-Net) on the HIP kernels of libbrats_hip.so.
+
+Drop-in for ``networks.equiunet2020.EquiUnet`` of the reference (networks/equiunet2020.py:407-500):
+same constructor signature, same ``state_dict`` keys / shapes, same
+``forward(x) -> (logits, [deep heads])`` contract on NCDHW float32 input, trainable through
+``loss.backward()``.  Internally the whole network is ONE autograd node whose forward / backward are
+explicit programs over NDHWC activations: torch.cat is replaced by producers writing into channel
+slices of shared buffers, GroupNorm statistics come out of the convolution epilogue, and the skip /
+pool gradient sum is fused into the pooling backward.
+
+Precision follows the reference's switch (learning/engine.py:304 ``autocast(enabled=not no_amp)``):
+under autocast the bf16-storage / f32-accumulate kernels run, otherwise the exact-f32 MFMA kernels
+(the 1e-3 logit parity mode).  ``model.precision = "bf16" | "fp32"`` overrides it.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import PACK_DGRAD, PACK_FWD, BratsHipError
+
+
+# ------------------------------------------------------------------------------------------ parameter holders
+class _ConvParams(nn.Module):
+    """Parameter holder with nn.Conv3d's names, shapes and default init (weight [Co,Ci,k,k,k])."""
+
+    def __init__(self, cin, cout, k, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(cin * k * k * k)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _NormParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class ConvBnRelu(nn.Module):
+    """conv3x3x3 (no bias) -> GroupNorm(8) -> act -> Dropout(p)   (networks/equiunet2020.py:51-75)"""
+
+    def __init__(self, inplanes, planes, dilation=1):
+        super().__init__()
+        self.conv = _ConvParams(inplanes, planes, 3, bias=False)
+        self.bn = _NormParams(planes)
+        self.dilation = dilation
+
+
+class UBlock(nn.Module):
+    """networks/equiunet2020.py:105-123"""
+
+    def __init__(self, inplanes, midplanes, outplanes, dilation=(1, 1)):
+        super().__init__()
+        self.ConvBnRelu1 = ConvBnRelu(inplanes, midplanes, dilation[0])
+        self.ConvBnRelu2 = ConvBnRelu(midplanes, outplanes, dilation[1])
+
+
+def _head(cin, k):
+    return nn.ModuleList([_ConvParams(cin, k, 1, bias=True)])  # key "<name>.0.weight" like nn.Sequential
+
+
+# ------------------------------------------------------------------------------------------ programs
+def _cgr_fwd(unit, x, dtype, act, out=None):
+    """One ConvBnRelu: pack -> implicit-GEMM conv (+ tile statistics) -> finalize -> normalise+act."""
+    w = unit.conv.weight
+    cout, cin = w.shape[0], w.shape[1]
+    cin_pad = x.shape[-1]
+    wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation)
+    y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True)
+    n, d, h, wd, _ = y.shape
+    mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, 8, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
+    z = ops.affine_act(y, scale_shift, act, out=out)
+    return z, (unit, x, y, mean_rstd, scale_shift)
+
+
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True):
+    unit, x, y, mean_rstd, scale_shift = rec
+    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), 8, act)
+    dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation)
+    cin = unit.conv.weight.shape[1]
+    grads[names[unit.conv.weight]] = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
+    grads[names[unit.bn.weight]] = dgamma
+    grads[names[unit.bn.bias]] = dbeta
+    if not need_dx:
+        return None
+    wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
+    dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation)
+    return dx
+
+
+class _EquiUnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, dtype, *params):
+        m = model
+        act = m.act
+        f = m.features
+        n, _, d, h, w = x.shape
+        dev = x.device
+        tape = []
+
+        def cgr(unit, xin, out=None):
+            z, rec = _cgr_fwd(unit, xin, dtype, act, out)
+            tape.append(rec)
+            return z
+
+        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
+        cat1 = ops.new_act(n, d, h, w, 2 * f[0], dtype, dev)
+        cat2 = ops.new_act(n, d // 2, h // 2, w // 2, 2 * f[1], dtype, dev)
+        cat3 = ops.new_act(n, d // 4, h // 4, w // 4, 2 * f[2], dtype, dev)
+        cat4 = ops.new_act(n, d // 8, h // 8, w // 8, 2 * f[3], dtype, dev)
+        # encoder (networks/equiunet2020.py:469-475)
+        down1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0), cat1[..., :f[0]])
+        p1 = ops.maxpool2(down1)
+        down2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, p1), cat2[..., :f[1]])
+        p2 = ops.maxpool2(down2)
+        down3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, p2), cat3[..., :f[2]])
+        p3 = ops.maxpool2(down3)
+        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, p3), cat4[..., :f[3]])
+        # bottom (:477-478): dilated block, then conv over cat[down4, bottom]
+        bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4), cat4[..., f[3]:])
+        bottom_2 = cgr(m.bottom_2, cat4)
+        # decoder (:481-486): up-sample straight into the second half of the concat buffers
+        ops.upsample(bottom_2, 2, out=cat3[..., f[2]:])
+        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, cat3))
+        ops.upsample(up3, 2, out=cat2[..., f[1]:])
+        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, cat2))
+        ops.upsample(up2, 2, out=cat1[..., f[0]:])
+        up1 = cgr(m.decoder1.ConvBnRelu2, cgr(m.decoder1.ConvBnRelu1, cat1))
+        outs = [ops.head(up1, m.outconv.weight, m.outconv.bias, 1)]
+        heads = [(m.outconv, up1, 1)]
+        if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
+            for hd, src, sc in ((m.deep_bottom[0], bottom, 8), (m.deep_bottom2[0], bottom_2, 8), (m.deep3[0], up3, 4),
+                                (m.deep2[0], up2, 2)):
+                outs.append(ops.head(src, hd.weight, hd.bias, sc))
+                heads.append((hd, src, sc))
+        ctx.model, ctx.dtype, ctx.tape, ctx.heads = m, dtype, tape, heads
+        ctx.bufs = (down1, down2, down3, down4, bottom, bottom_2, up3, up2, up1)
+        ctx.nparams = len(params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        m, dtype, tape = ctx.model, ctx.dtype, ctx.tape
+        act, f = m.act, m.features
+        names = {p: i for i, p in enumerate(m.parameters())}
+        grads = {}
+        down1, down2, down3, down4, bottom, bottom_2, up3, up2, up1 = ctx.bufs
+        rec = {r[0]: r for r in tape}
+
+        def cbw(unit, dz, need_dx=True):
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx)
+
+        # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
+        dsrc = {}
+        for (hd, src, sc), dout in zip(ctx.heads, douts):
+            if dout is None:
+                continue
+            dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
+            grads[names[hd.weight]] = dw
+            grads[names[hd.bias]] = db
+            key = src.data_ptr()
+            dsrc[key] = dx if key not in dsrc else dsrc[key] + dx
+
+        def extra(t):
+            return dsrc.get(t.data_ptr())
+
+        def plus(a, b):
+            return a if b is None else a + b
+
+        d_up1 = extra(up1)
+        dcat1 = cbw(m.decoder1.ConvBnRelu1, cbw(m.decoder1.ConvBnRelu2, d_up1))
+        d_up2 = plus(ops.upsample_bwd(dcat1[..., f[0]:], 2), extra(up2))
+        dcat2 = cbw(m.decoder2.ConvBnRelu1, cbw(m.decoder2.ConvBnRelu2, d_up2))
+        d_up3 = plus(ops.upsample_bwd(dcat2[..., f[1]:], 2), extra(up3))
+        dcat3 = cbw(m.decoder3.ConvBnRelu1, cbw(m.decoder3.ConvBnRelu2, d_up3))
+        d_b2 = plus(ops.upsample_bwd(dcat3[..., f[2]:], 2), extra(bottom_2))
+        dcat4 = cbw(m.bottom_2, d_b2)
+        d_bottom = plus(dcat4[..., f[3]:], extra(bottom))
+        d_down4 = dcat4[..., :f[3]] + cbw(m.bottom.ConvBnRelu1, cbw(m.bottom.ConvBnRelu2, d_bottom))
+        d_p3 = cbw(m.encoder4.ConvBnRelu1, cbw(m.encoder4.ConvBnRelu2, d_down4))
+        d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=dcat3[..., :f[2]])
+        d_p2 = cbw(m.encoder3.ConvBnRelu1, cbw(m.encoder3.ConvBnRelu2, d_down3))
+        d_down2 = ops.maxpool2_bwd(down2, d_p2, dx_skip=dcat2[..., :f[1]])
+        d_p1 = cbw(m.encoder2.ConvBnRelu1, cbw(m.encoder2.ConvBnRelu2, d_down2))
+        d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=dcat1[..., :f[0]])
+        cbw(m.encoder1.ConvBnRelu1, cbw(m.encoder1.ConvBnRelu2, d_down1), need_dx=False)
+        ctx.tape = ctx.bufs = None
+        return (None, None, None) + tuple(grads.get(i) for i in range(ctx.nparams))
+
+
+# ------------------------------------------------------------------------------------------ module
+class EquiUnet(nn.Module):
+    """Constructor signature of networks/equiunet2020.py:413-414."""
+    name = "EquiUnet"
+
+    def __init__(self, inplanes, num_classes, features, norm_layer=None, act="relu", deep_supervision=False, dropout=0,
+                 refinement=False):
+        super().__init__()
+        if norm_layer != "group":
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group only (got {norm_layer!r})")
+        if act not in ("relu", "leakyrelu"):
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu only (got {act!r})")
+        if dropout:
+            raise NotImplementedError("dropout > 0 is not implemented (the published configs use 0)")
+        if refinement:
+            raise NotImplementedError("equiunet_ref (RefUnet) is outside the accelerated hot path")
+        if inplanes != 4 or num_classes > 4 or any(c % 8 for c in features):
+            raise NotImplementedError("EquiUnet kernels need inplanes=4, num_classes<=4, widths multiple of 8")
+        print(f"EquiUnet features: {features}")
+        self.deep_supervision = deep_supervision
+        self.act = act
+        self.features = list(features)
+        self.precision = "auto"
+        self.skip_deep_heads_in_eval = False
+        f = self.features
+        self.encoder1 = UBlock(inplanes, f[0], f[0])
+        self.encoder2 = UBlock(f[0], f[1], f[1])
+        self.encoder3 = UBlock(f[1], f[2], f[2])
+        self.encoder4 = UBlock(f[2], f[3], f[3])
+        self.bottom = UBlock(f[3], f[3], f[3], (2, 2))
+        self.bottom_2 = ConvBnRelu(f[3] * 2, f[2])
+        self.decoder3 = UBlock(f[2] * 2, f[2], f[1])
+        self.decoder2 = UBlock(f[1] * 2, f[1], f[0])
+        self.decoder1 = UBlock(f[0] * 2, f[0], f[0])
+        self.outconv = _ConvParams(f[0], num_classes, 1, bias=True)
+        if deep_supervision:
+            self.deep_bottom = _head(f[3], num_classes)
+            self.deep_bottom2 = _head(f[2], num_classes)
+            self.deep3 = _head(f[1], num_classes)
+            self.deep2 = _head(f[0], num_classes)
+        # init_weights(self, "kaiming"), networks/factory.py:203-224: kaiming-normal fan_out on conv weights
+        print("initialize network with kaiming")
+        for mod in self.modules():
+            if isinstance(mod, _ConvParams):
+                nn.init.kaiming_normal_(mod.weight.data, a=0.0, mode="fan_out")
+
+    def _dtype(self):
+        if self.precision == "bf16":
+            return torch.bfloat16
+        if self.precision == "fp32":
+            return torch.float32
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise BratsHipError("brats21_amd.EquiUnet runs on the GPU only (no CPU fallback); move input/model to cuda")
+        if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
+            raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
+        params = tuple(self.parameters())
+        outs = _EquiUnetFn.apply(self, x.float(), self._dtype(), *params)
+        if self.deep_supervision:
+            return outs[0], list(outs[1:])
+        return outs[0]

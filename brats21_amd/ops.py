@@ -1,0 +1,260 @@
+"""Raw (non-autograd) Python entry points over the C ABI of libbrats_hip.so.
+
+Activations are torch CUDA tensors of shape [N, D, H, W, C] (NDHWC) in torch.bfloat16 or
+torch.float32; a tensor may be a channel-slice *view* of a wider buffer (pitch = stride(3)), which
+is how torch.cat (networks/equiunet2020.py:478-486 of the reference) is removed.  PyTorch is only
+the allocator / stream provider here; every arithmetic op is a HIP kernel of the library.
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F32, PACK_DGRAD, PACK_FWD  # noqa: F401
+
+ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "leakyrelu": ACT_LEAKY}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _code(dtype):
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float32:
+        return F32
+    raise _lib.BratsHipError(f"unsupported activation dtype {dtype}")
+
+
+def _desc(t):
+    """(data_ptr, C, pitch) of an NDHWC tensor or channel-slice view."""
+    if t.dim() != 5 or not t.is_cuda:
+        raise _lib.BratsHipError("expected a CUDA tensor of shape [N, D, H, W, C]")
+    n, d, h, w, c = t.shape
+    p = t.stride(3)
+    if t.stride(4) != 1 or t.stride(2) != w * p or t.stride(1) != h * w * p or t.stride(0) != d * h * w * p:
+        raise _lib.BratsHipError(f"tensor is not NDHWC with a channel pitch: shape {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), c, p
+
+
+def _f32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise _lib.BratsHipError("expected a contiguous CUDA float32 tensor")
+    return t.data_ptr()
+
+
+def new_act(n, d, h, w, c, dtype, device):
+    return torch.empty((n, d, h, w, c), dtype=dtype, device=device)
+
+
+# ------------------------------------------------------------------------------------------ layout
+def ncdhw_to_ndhwc(x, dtype, cpad=None):
+    """[N,C,D,H,W] f32 -> [N,D,H,W,cpad] dtype (extra channels zero)."""
+    n, c, d, h, w = x.shape
+    cpad = cpad or c
+    x = x.contiguous().float()
+    out = new_act(n, d, h, w, cpad, dtype, x.device)
+    _lib.check(_lib.lib().brats_ncdhw_to_ndhwc(x.data_ptr(), out.data_ptr(), _code(dtype), n, c, cpad, cpad, d, h, w,
+                                               _stream()), "ncdhw_to_ndhwc")
+    return out
+
+
+def ndhwc_to_ncdhw(x):
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().brats_ndhwc_to_ncdhw(ptr, p, out.data_ptr(), _code(x.dtype), n, c, d, h, w, _stream()),
+               "ndhwc_to_ncdhw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ conv
+def conv_chunk(dtype, ksize, dil, c1, c2=0):
+    ck = _lib.lib().brats_conv3d_chunk(_code(dtype), ksize, dil, c1, c2)
+    if ck <= 0:
+        raise _lib.BratsHipError(f"conv3d: no channel chunk for c1={c1} c2={c2} dtype={dtype}")
+    return ck
+
+
+def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1):
+    """w: torch-layout [Cout, Cin, k, k, k] f32 parameter -> packed MFMA-fragment buffer.
+    mode PACK_FWD: GEMM rows = Cout, K = Cin (zero-padded to cin_pad); PACK_DGRAD: rows = Cin slice,
+    K = Cout, taps flipped."""
+    cout_w, cin_w, k = w.shape[0], w.shape[1], w.shape[2]
+    w = w.detach()
+    if cin_pad is not None and cin_pad != cin_w:
+        wp = torch.zeros((cout_w, cin_pad, k, k, k), dtype=torch.float32, device=w.device)
+        wp[:, :cin_w] = w
+        w, cin_w = wp, cin_pad
+    w = w.contiguous().float()
+    cin_cnt = cin_w - cin_off if cin_cnt is None else cin_cnt
+    code = _code(dtype)
+    if mode == PACK_FWD:
+        kdim, rows = cin_cnt, cout_w
+    else:
+        kdim, rows = cout_w, cin_cnt
+    ck = conv_chunk(dtype, k, dil, kdim)
+    nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(_lib.lib().brats_conv3d_pack_weights(w.data_ptr(), packed.data_ptr(), code, mode, k, cout_w, cin_w,
+                                                    cin_off, cin_cnt, ck, _stream()), "conv3d_pack_weights")
+    return packed
+
+
+def tiles_per_sample(d, h, w):
+    return _lib.lib().brats_conv3d_tiles_per_sample(d, h, w)
+
+
+def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False):
+    """y[N,D,H,W,cout] = conv(x) with weights from pack_weights().  Returns (y, stats|None) where
+    stats = [N, tiles, cout, 2] per-tile per-channel (sum, sum of squares) of the f32 result."""
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    if out is None:
+        out = new_act(n, d, h, w, cout, x.dtype, x.device)
+    optr, oc, op = _desc(out)
+    if oc != cout or out.dtype != x.dtype:
+        raise _lib.BratsHipError("conv3d: bad output tensor")
+    stats = None
+    if want_stats:
+        stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().brats_conv3d_fwd(ptr, c, p, None, 0, 0, packed_w.data_ptr(), _f32(bias), optr, op,
+                                           stats.data_ptr() if stats is not None else None, _code(x.dtype), ksize, dil,
+                                           n, d, h, w, cout, _stream()), "conv3d_fwd")
+    return out, stats
+
+
+def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False):
+    """dW [cout, cin, k,k,k] f32 (and dbias) from the layer input x and the output gradient dy."""
+    ptr, c, p = _desc(x)
+    dptr, cout, dp = _desc(dy)
+    n, d, h, w, _ = x.shape
+    code = _code(x.dtype)
+    nbytes = _lib.lib().brats_conv3d_wgrad_ws_bytes(code, ksize, n, d, h, w, c, 0, cout)
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, c, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
+    _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, None, 0, 0, dptr, dp, ws.data_ptr(), dw.data_ptr(),
+                                             db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
+                                             cout, _stream()), "conv3d_wgrad")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------ GroupNorm + act
+def gn_finalize(stats, n, c, groups, voxels, gamma, beta, eps=1e-5):
+    mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)
+    scale_shift = torch.empty((n, c, 2), dtype=torch.float32, device=stats.device)
+    _lib.check(_lib.lib().brats_gn_finalize(stats.data_ptr(), stats.shape[1], n, c, groups, float(voxels), eps,
+                                            _f32(gamma), _f32(beta), mean_rstd.data_ptr(), scale_shift.data_ptr(),
+                                            _stream()), "gn_finalize")
+    return mean_rstd, scale_shift
+
+
+def affine_act(y, scale_shift, act="relu", out=None, slope=0.01):
+    ptr, c, p = _desc(y)
+    n, d, h, w, _ = y.shape
+    if out is None:
+        out = new_act(n, d, h, w, c, y.dtype, y.device)
+    optr, oc, op = _desc(out)
+    _lib.check(_lib.lib().brats_affine_act_fwd(ptr, p, scale_shift.data_ptr(), optr, op, _code(y.dtype), ACTS[act], slope,
+                                               n, d * h * w, c, _stream()), "affine_act_fwd")
+    return out
+
+
+def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01):
+    """Returns (dy, dgamma, dbeta) for z = act(GroupNorm(y))."""
+    dzp, c, dzpitch = _desc(dz)
+    yp, _, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    dy = new_act(n, d, h, w, c, y.dtype, y.device)
+    red = torch.empty((n, c, 2), dtype=torch.float32, device=y.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().brats_gn_act_bwd(dzp, dzpitch, yp, ypitch, scale_shift.data_ptr(), mean_rstd.data_ptr(),
+                                           _f32(gamma), dy.data_ptr(), c, red.data_ptr(), dgamma.data_ptr(),
+                                           dbeta.data_ptr(), _code(y.dtype), ACTS[act], slope, n, d * h * w, c, groups,
+                                           _stream()), "gn_act_bwd")
+    return dy, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------ pool / upsample
+def maxpool2(x, with_avg=False, out=None):
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    co = 2 * c if with_avg else c
+    if out is None:
+        out = new_act(n, d // 2, h // 2, w // 2, co, x.dtype, x.device)
+    optr, oc, op = _desc(out)
+    _lib.check(_lib.lib().brats_maxpool2_fwd(ptr, p, optr, op, _code(x.dtype), n, c, d, h, w, int(with_avg), _stream()),
+               "maxpool2_fwd")
+    return out
+
+
+def maxpool2_bwd(x, dy, dx_skip=None, with_avg=False):
+    ptr, c, p = _desc(x)
+    dptr, _, dp = _desc(dy)
+    n, d, h, w, _ = x.shape
+    dx = new_act(n, d, h, w, c, x.dtype, x.device)
+    sptr, sp = (None, 0)
+    if dx_skip is not None:
+        sptr, _, sp = _desc(dx_skip)
+    _lib.check(_lib.lib().brats_maxpool2_bwd(ptr, p, None, 0, dptr, dp, sptr, sp, dx.data_ptr(), c, _code(x.dtype), n, c,
+                                             d, h, w, int(with_avg), _stream()), "maxpool2_bwd")
+    return dx
+
+
+def upsample(x, scale=2, out=None):
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    if out is None:
+        out = new_act(n, d * scale, h * scale, w * scale, c, x.dtype, x.device)
+    optr, oc, op = _desc(out)
+    _lib.check(_lib.lib().brats_upsample_fwd(ptr, p, optr, op, _code(x.dtype), n, c, d, h, w, scale, _stream()),
+               "upsample_fwd")
+    return out
+
+
+def upsample_bwd(dy, scale=2):
+    dptr, c, dp = _desc(dy)
+    n, do, ho, wo, _ = dy.shape
+    d, h, w = do // scale, ho // scale, wo // scale
+    code = _code(dy.dtype)
+    ws = torch.empty(_lib.lib().brats_upsample_bwd_ws_bytes(code, n, c, d, h, w, scale), dtype=torch.uint8, device=dy.device)
+    dx = new_act(n, d, h, w, c, dy.dtype, dy.device)
+    _lib.check(_lib.lib().brats_upsample_bwd(dptr, dp, dx.data_ptr(), c, ws.data_ptr(), code, n, c, d, h, w, scale,
+                                             _stream()), "upsample_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------ heads
+def head(x, weight, bias, scale=1):
+    """NCDHW f32 logits [N, K, D*s, H*s, W*s] = upsample_s(conv1x1(x)); weight [K, C, 1,1,1]."""
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    k = weight.shape[0]
+    wf = weight.detach().reshape(k, c).contiguous().float()
+    out = torch.empty((n, k, d * scale, h * scale, w * scale), dtype=torch.float32, device=x.device)
+    low = torch.empty((n, k, d, h, w), dtype=torch.float32, device=x.device) if scale > 1 else None
+    _lib.check(_lib.lib().brats_head_fwd(ptr, p, wf.data_ptr(), _f32(bias.detach()) if bias is not None else None,
+                                         low.data_ptr() if low is not None else None, out.data_ptr(), _code(x.dtype), n, c,
+                                         k, d, h, w, scale, _stream()), "head_fwd")
+    return out
+
+
+def head_bwd(x, weight, dout, scale=1, want_dx=True):
+    """Returns (dx | None, dweight [K,C,1,1,1], dbias [K])."""
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    k = weight.shape[0]
+    wf = weight.detach().reshape(k, c).contiguous().float()
+    dout = dout.contiguous().float()
+    nbytes = _lib.lib().brats_head_bwd_ws_bytes(n, k, d, h, w, scale)
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    dx = new_act(n, d, h, w, c, x.dtype, x.device) if want_dx else None
+    dw = torch.empty((k, c), dtype=torch.float32, device=x.device)
+    db = torch.empty(k, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().brats_head_bwd(ptr, p, wf.data_ptr(), dout.data_ptr(), ws.data_ptr(),
+                                         dx.data_ptr() if dx is not None else None, c, dw.data_ptr(), db.data_ptr(),
+                                         _code(x.dtype), n, c, k, d, h, w, scale, _stream()), "head_bwd")
+    return dx, dw.reshape(k, c, 1, 1, 1), db

@@ -1,0 +1,127 @@
+/* brats_hip.h -- C ABI of libbrats_hip.so: the MI355X (gfx950) drop-in for the device arithmetic of
+ * the BraTS21 3D U-Net hot path.
+ *
+ * The reference has NO native / FFI boundary: its hot path is stock torch.nn called
+ * from Python (`get_model(args) -> nn.Module`, src/definer.py:37-174).  Each entry point below
+ * therefore cites the torch.nn call site of the reference it replaces.  The Python side
+ * (brats21_amd/) binds these with ctypes and keeps the reference's module / factory API.
+ *
+ * Conventions
+ *   - activations are NDHWC ("voxel-major, channel-minor"): element (n,d,h,w,c) of a tensor with
+ *     channel pitch P lives at ((((n*D+d)*H+h)*W+w)*P + c).  A pitch larger than the channel count
+ *     lets producers write straight into a channel slice of a concat buffer (torch.cat removed).
+ *   - dtype: BRATS_F32 = 0 (exact-f32 MFMA, the parity mode), BRATS_BF16 = 1 (bf16 storage, f32
+ *     accumulate, the throughput mode).  Statistics / gradients of parameters are always f32.
+ *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library never
+ *     allocates, never synchronises, launches only on the stream passed in (graph-capturable).
+ *   - return 0 on success; <0 = BRATS_E_* (message via brats_last_error()).  Never throws.
+ *   - callable from any host thread; ordering is by stream.
+ */
+#ifndef BRATS_HIP_H
+#define BRATS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* brats_stream_t; /* hipStream_t */
+
+enum { BRATS_F32 = 0, BRATS_BF16 = 1 };
+enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
+enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2 };
+
+int brats_abi_version(void);
+const char* brats_last_error(void);
+
+/* ---- layout ---------------------------------------------------------------------------------
+ * NCDHW f32 (the reference's tensor layout, learning/engine.py:89) <-> NDHWC dtype.  `cpad` >= C
+ * channels are written, the extra ones as zeros (first layer: 4 -> 8 so K is MFMA-friendly). */
+int brats_ncdhw_to_ndhwc(const float* src, void* dst, int dtype, int N, int C, int cpad, int dst_pitch,
+                         int D, int H, int W, brats_stream_t s);
+int brats_ndhwc_to_ncdhw(const void* src, int src_pitch, float* dst, int dtype, int N, int C,
+                         int D, int H, int W, brats_stream_t s);
+
+/* ---- convolution 3x3x3 / 1x1x1, stride 1, "same" padding = dilation ---------------------------
+ * Replaces nn.Conv3d at networks/equiunet2020.py:19-25 (conv3x3, dilation 1|2) and
+ * networks/equiunet2021.py:197-206,169-171 (bias, dilation 1|2|4|6) by an implicit-GEMM MFMA
+ * kernel; dgrad is the same kernel on weights packed with mode=BRATS_PACK_DGRAD.
+ * The input is the virtual concat [x1 (c1 channels) | x2 (c2 channels, may be NULL/0)]
+ * (torch.cat at equiunet2020.py:478-486 removed).  `stats` (may be NULL) receives per-tile,
+ * per-channel sum / sum-of-squares of the (bias-added, f32) output:
+ * [N][tiles_per_sample][cout][2], reduced by brats_gn_finalize / brats_evonorm_finalize. */
+enum { BRATS_PACK_FWD = 0, BRATS_PACK_DGRAD = 1 };
+/* bytes of the packed-weight buffer for a conv with `cin` (GEMM-K) and `cout` (GEMM-M) channels */
+size_t brats_conv3d_packed_bytes(int dtype, int ksize, int cin, int cout, int ck);
+/* channel chunk the kernel will use for an input made of c1 (+c2) channels; 0 = unsupported */
+int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2);
+/* w: [Cout_w][Cin_w][k][k][k] f32 (torch layout).  FWD: GEMM rows = Cout_w, K = Cin_w slice
+ * [cin_off, cin_off+cin_cnt).  DGRAD: GEMM rows = Cin_w slice, K = Cout_w, taps flipped. */
+int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize,
+                              int cout_w, int cin_w, int cin_off, int cin_cnt, int ck, brats_stream_t s);
+int brats_conv3d_tiles_per_sample(int D, int H, int W);
+int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
+                     const void* packed_w, const float* bias, void* y, int ypitch, float* stats,
+                     int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
+                     brats_stream_t s);
+/* wgrad: dW[co][ci][tap] = sum_v dy[v][co] * x[v + off(tap)][ci]  (x = virtual concat as above).
+ * `ws` = f32 workspace of brats_conv3d_wgrad_ws_bytes(); dw = [cout][c1+c2][k^3] f32, overwritten.
+ * dbias (may be NULL): [cout] f32 = sum_v dy. */
+size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout);
+int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
+                       const void* dy, int dypitch, float* ws, float* dw, float* dbias,
+                       int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
+                       brats_stream_t s);
+
+/* ---- GroupNorm(8) + activation (nn.GroupNorm networks/factory.py:179-182, get_act :195-200) ---
+ * finalize: per-(n,channel) tile partials -> per-(n,group) mean / rstd (biased var, eps) and the
+ * fused per-(n,channel) affine  z = act(y*scale + shift). */
+int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
+                      double count_per_channel, float eps, const float* gamma, const float* beta,
+                      float* mean_rstd /*[N][groups][2]*/, float* scale_shift /*[N][C][2]*/,
+                      brats_stream_t s);
+int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
+                         int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s);
+/* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
+ * u = dz * act'(.) into `red` [N][C][2] (zeroed by the call); pass 2 writes dy and finishes
+ * dgamma/dbeta [C]. */
+int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
+                     const float* mean_rstd, const float* gamma, void* dy, int dypitch,
+                     float* red /*[N][C][2]*/, float* dgamma, float* dbeta,
+                     int dtype, int act, float slope, int N, int voxels, int C, int groups,
+                     brats_stream_t s);
+
+/* ---- pooling (nn.MaxPool3d(2,2) equiunet2020.py:433; MONAI MaxAvgPool equiunet2021.py:261) ---- */
+int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C,
+                       int D, int H, int W, int with_avg, brats_stream_t s);
+/* dx = [dx_skip (may be NULL) +] maxpool^T(dy[..C]) [+ avgpool^T(dy[C..2C]) if with_avg] */
+int brats_maxpool2_bwd(const void* x, int xpitch, const void* y, int ypitch, const void* dy, int dypitch,
+                       const void* dx_skip, int dxskip_pitch, void* dx, int dxpitch, int dtype,
+                       int N, int C, int D, int H, int W, int with_avg, brats_stream_t s);
+
+/* ---- trilinear up-sampling, align_corners=True (nn.Upsample equiunet2020.py:439,446-458) ------
+ * NDHWC -> NDHWC (scale 2, into a concat slice) ... */
+int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C,
+                       int D, int H, int W, int scale, brats_stream_t s);
+/* adjoint; dx overwritten.  tmp: workspace of brats_upsample_bwd_ws_bytes() */
+size_t brats_upsample_bwd_ws_bytes(int dtype, int N, int C, int D, int H, int W, int scale);
+int brats_upsample_bwd(const void* dy, int dypitch, void* dx, int dxpitch, void* tmp, int dtype,
+                       int N, int C, int D, int H, int W, int scale, brats_stream_t s);
+
+/* ---- segmentation heads: 1x1x1 conv C -> K (K <= 4) + bias (conv1x1 equiunet2020.py:37-41,441)
+ * followed by trilinear x`scale` up-sampling (deep heads :443-458); output NCDHW f32 logits. */
+int brats_head_fwd(const void* x, int xpitch, const float* w /*[K][C]*/, const float* b, float* lowres /*[N][K][D][H][W] ws*/,
+                   float* out /*[N][K][D*s][H*s][W*s]*/, int dtype, int N, int C, int K,
+                   int D, int H, int W, int scale, brats_stream_t s);
+/* dout [N][K][Ds][Hs][Ws] f32 -> dx (NDHWC dtype, may be NULL), dw [K][C], db [K] (overwritten).
+ * ws: f32 workspace of brats_head_bwd_ws_bytes() (unused when scale == 1). */
+size_t brats_head_bwd_ws_bytes(int N, int K, int D, int H, int W, int scale);
+int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout, float* ws,
+                   void* dx, int dxpitch, float* dw, float* db, int dtype, int N, int C, int K,
+                   int D, int H, int W, int scale, brats_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

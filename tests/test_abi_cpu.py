@@ -1,0 +1,61 @@
+"""-m "not gpu": the C-ABI library loads, exports every symbol include/brats_hip.h declares, and the
+host-side logic (argument validation, size queries, state-dict contract) works without a GPU."""
+import argparse
+import ctypes
+
+import pytest
+import torch
+
+from brats21_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    l = ctypes.CDLL(_lib.LIB_PATH)
+    names = _lib.declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(l, n), f"{n} declared in include/brats_hip.h but not exported"
+    assert _lib.lib().brats_abi_version() == 1
+
+
+def test_host_side_queries_and_argument_errors():
+    l = _lib.lib()
+    # chunk selection: width-48 layers use 48-channel chunks in bf16, 16 in f32; first layer 8 / 4
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 48, 0) == 48
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 96, 0) == 48
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 8, 0) == 8
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 64, 0) == 32
+    assert l.brats_conv3d_chunk(_lib.F32, 3, 1, 48, 0) == 16
+    assert l.brats_conv3d_chunk(_lib.F32, 3, 1, 4, 0) == 4
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 12, 0) == 0
+    assert l.brats_conv3d_tiles_per_sample(128, 128, 128) == 32 * 16 * 16
+    assert l.brats_conv3d_tiles_per_sample(4, 4, 4) == 1
+    # packed size: chunks * macro-steps * cout16 * 64 lanes * 16 B
+    assert l.brats_conv3d_packed_bytes(_lib.BF16, 3, 48, 48, 48) == 1 * 41 * 3 * 64 * 16
+    assert l.brats_conv3d_packed_bytes(_lib.F32, 3, 16, 16, 16) == 1 * 27 * 1 * 64 * 16
+    # NULL pointers are rejected with an error string, never dereferenced
+    rc = l.brats_conv3d_fwd(None, 8, 8, None, 0, 0, None, None, None, 8, None, _lib.BF16, 3, 1, 1, 8, 8, 8, 8, None)
+    assert rc == -1 and b"conv3d_fwd" in l.brats_last_error()
+    rc = l.brats_maxpool2_fwd(None, 8, None, 8, _lib.BF16, 1, 8, 8, 8, 8, 0, None)
+    assert rc == -1
+
+
+def test_state_dict_contract_and_factory_errors():
+    from brats21_amd import get_model
+    from oracle import unet
+    ns = dict(width=8, norm="group", act="relu", num_classes=3, dropout=0)
+    m = get_model(argparse.Namespace(model="equiunet", **ns))
+    shapes = unet.equiunet_state_shapes(8)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    with pytest.raises(NameError):
+        get_model(argparse.Namespace(model="nnunet", **ns))
+    with pytest.raises(NotImplementedError):
+        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "instance"}))
+    # no CPU fallback: a CPU forward must fail loudly
+    from brats21_amd import BratsHipError
+    with pytest.raises(BratsHipError):
+        m(torch.zeros(1, 4, 16, 16, 16))
+    import copy
+    copy.deepcopy(m)  # AveragedModel / SWA path of the reference (src/main_train.py:113)

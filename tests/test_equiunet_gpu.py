@@ -1,0 +1,120 @@
+"""-m gpu: end-to-end parity of brats21_amd.EquiUnet (HIP kernels through the C ABI) with
+(a) the committed golden vectors produced by the reference source and (b) the CPU oracle on the
+same closed-form inputs.  Bar (BASELINE.json north_star): logits within 1e-3 abs in the f32 mode;
+the bf16 mode's deviation is asserted at a stated looser bound."""
+import argparse
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth, unet
+
+pytestmark = pytest.mark.gpu
+LOGIT_ATOL = 1e-3  # north_star: "within 1e-3 abs on identical inputs"
+
+
+def _model(width, sd=None, precision="fp32"):
+    from brats21_amd import get_model
+    m = get_model(argparse.Namespace(model="equiunet", width=width, norm="group", act="relu", num_classes=3, dropout=0))
+    if sd is not None:
+        m.load_state_dict(sd, strict=True)
+    m.precision = precision
+    return m.cuda()
+
+
+def _golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("fname", ["equiunet_w8_32.npz", "equiunet_w8_64.npz"])
+def test_equiunet_f32_matches_reference_golden(golden_dir, fname):
+    g = _golden(golden_dir, fname)
+    meta = json.loads(str(g["meta"]))
+    size, s = tuple(meta["size"]), meta["sub"]
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(meta["width"]))
+    m = _model(meta["width"], sd, "fp32").train()
+    x = synth.closed_form_image(1, 4, size).cuda()
+    t = synth.nested_spheres(1, size).cuda()
+    out, deeps = m(x)
+    assert out.shape == (1, 3, *size) and len(deeps) == 4 and all(d.shape == out.shape for d in deeps)
+    err = np.abs(out.detach().cpu().numpy()[:, :, ::s, ::s, ::s] - g["logits"]).max()
+    assert err < LOGIT_ATOL, f"logit max abs err {err}"
+    for i, d in enumerate(deeps):
+        e = np.abs(d.detach().cpu().numpy()[:, :, ::2 * s, ::2 * s, ::2 * s] - g[f"deep{i}"]).max()
+        assert e < LOGIT_ATOL, f"deep head {i} max abs err {e}"
+    # loss + gradients through the PyTorch-side deep-supervision Dice loss (learning/engine.py:312-333)
+    loss = unet.deep_supervision_loss((out, deeps), t)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    names = json.loads(str(g["grad_names"]))
+    params = dict(m.named_parameters())
+    norms = np.array([float(params[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-3, atol=1e-7)
+    for k in g.files:
+        if k.startswith("grad:"):
+            ref = g[k]
+            got = params[k[5:]].grad.cpu().numpy()
+            np.testing.assert_allclose(got, ref, atol=2e-3 * max(np.abs(ref).max(), 1e-6), rtol=2e-3)
+
+
+def test_equiunet_bf16_deviation_bounded(golden_dir):
+    """bf16 storage cannot meet 1e-3 through 20 layers; assert the deviation
+    stays at bf16 level: logits within 0.15 abs / hard-Dice of the thresholded masks within 1e-2."""
+    g = _golden(golden_dir, "equiunet_w8_32.npz")
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(8))
+    m = _model(8, sd, "bf16").eval()
+    x = synth.closed_form_image(1, 4, (32, 32, 32)).cuda()
+    with torch.no_grad():
+        out, deeps = m(x)
+    ref = torch.from_numpy(g["logits"])
+    err = (out.cpu() - ref).abs()
+    assert float(err.max()) < 0.15 and float(err.mean()) < 0.02, (float(err.max()), float(err.mean()))
+    t = synth.nested_spheres(1, (32, 32, 32))
+    d_ref, d_got = unet.hard_dice(ref, t), unet.hard_dice(out.cpu(), t)
+    assert float((d_ref - d_got).abs().max()) < 1e-2
+
+
+def test_equiunet_autocast_selects_bf16_and_width48_runs():
+    """Width-48 channel counts (CK=48 chunks, 96-wide concat buffers) at a small volume vs the oracle."""
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(48))
+    m = _model(48, sd, "auto").train()
+    size = (16, 16, 16)
+    x = synth.closed_form_image(2, 4, size)
+    t = synth.nested_spheres(2, size)
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = unet.equiunet_forward(sd_ref, x)
+    loss_ref = unet.deep_supervision_loss(out_ref, t)
+    loss_ref.backward()
+    out, deeps = m(x.cuda())  # no autocast -> exact f32 kernels
+    err = float((out.detach().cpu() - out_ref[0].detach()).abs().max())
+    assert err < LOGIT_ATOL, err
+    loss = unet.deep_supervision_loss((out, deeps), t.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4
+    for k, p in m.named_parameters():
+        ref = sd_ref[k].grad
+        rel = float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12))
+        assert rel < 2e-3, (k, rel)
+    m.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out_b, deeps_b = m(x.cuda())
+        loss_b = unet.deep_supervision_loss((out_b, deeps_b), t.cuda())
+    loss_b.backward()
+    assert out_b.dtype == torch.float32
+    assert float((out_b.detach().cpu() - out_ref[0].detach()).abs().max()) < 0.25
+    assert abs(loss_b.item() - loss_ref.item()) < 5e-3
+    worst = 0.0
+    for k, p in m.named_parameters():
+        ref = sd_ref[k].grad
+        worst = max(worst, float((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)))
+    assert worst < 0.12, worst  # bf16 activations + bf16 gradients end to end
+
+
+def test_cpu_input_fails_loudly():
+    from brats21_amd import BratsHipError
+    m = _model(8)
+    with pytest.raises(BratsHipError):
+        m(torch.zeros(1, 4, 16, 16, 16))

@@ -1,0 +1,221 @@
+"""-m gpu: every HIP op through the C ABI against a plain torch fp32 CPU reference of the same op
+(the ATen calls the reference's CPU path makes).  f32 kernels: tight tolerances (exact-f32 MFMA);
+bf16 kernels: tolerance stated per test (bf16 storage has 8 mantissa bits)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _to_ndhwc(x_ncdhw, dtype, dev, pitch=None, off=0):
+    """CPU NCDHW f32 -> device NDHWC (optionally as a channel slice of a wider buffer)."""
+    n, c, d, h, w = x_ncdhw.shape
+    t = x_ncdhw.permute(0, 2, 3, 4, 1).contiguous().to(dev).to(dtype)
+    if pitch is None:
+        return t
+    buf = torch.full((n, d, h, w, pitch), 7.0, dtype=dtype, device=dev)
+    buf[..., off:off + c] = t
+    return buf[..., off:off + c]
+
+
+def _from_ndhwc(t):
+    return t.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _tol(dtype, f32, bf16):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def _q(x, dtype):
+    """Round a CPU f32 tensor through the activation dtype (what the kernel actually sees)."""
+    return x.to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cin,cout,dil,size", [
+    (4, 8, 1, (8, 8, 8)),       # first layer (padded cin), NF=1 ksplit
+    (8, 16, 1, (12, 16, 8)),    # partial tiles in z
+    (16, 32, 1, (8, 8, 16)),    # NF=2 ksplit
+    (32, 64, 2, (8, 8, 8)),     # dilation 2, NF=2 no-split
+    (48, 48, 1, (8, 16, 8)),    # width-48 layer: CK=48 straddling taps, NF=3 ksplit
+    (96, 96, 1, (4, 8, 8)),     # two chunks, NF=3 no-split
+    (64, 8, 1, (4, 4, 4)),      # tiny volume: tile larger than the volume
+])
+def test_conv3d_fwd_dgrad_wgrad(dtype, cin, cout, dil, size):
+    from brats21_amd import ops
+    dev = _dev()
+    n = 2
+    x = _q(_rand((n, cin, *size), 1), dtype)
+    w = _rand((cout, cin, 3, 3, 3), 2, (2.0 / (cin * 27)) ** 0.5)
+    wq = _q(w, dtype)
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, None, 1, dil, dil)
+    dy = _q(_rand(y_ref.shape, 3), dtype)
+    y_ref.backward(dy)
+
+    cpad = cin if cin % 8 == 0 else 8
+    if dtype == torch.float32 and cin == 4:
+        cpad = 4
+    xp = torch.zeros((n, cpad, *size))
+    xp[:, :cin] = x
+    xd = _to_ndhwc(xp, dtype, dev)
+    wd = w.to(dev)
+    wpk = ops.pack_weights(wd, dtype, ops.PACK_FWD, cin_pad=cpad, dil=dil)
+    y, stats = ops.conv3d(xd, wpk, cout, 3, dil, want_stats=True)
+    torch.cuda.synchronize()
+    yh = _from_ndhwc(y)
+    atol = _tol(dtype, 2e-5, 3e-2)
+    torch.testing.assert_close(yh, y_ref.detach(), atol=atol, rtol=_tol(dtype, 1e-5, 2e-2))
+    # tile statistics: sum and sum of squares per (n, channel) of the f32 result
+    s = stats.double().sum(1).cpu()
+    ref1 = y_ref.detach().double().sum((2, 3, 4))
+    ref2 = (y_ref.detach().double() ** 2).sum((2, 3, 4))
+    torch.testing.assert_close(s[..., 0], ref1, atol=_tol(dtype, 1e-3, 2e-2) * y_ref[0, 0].numel() ** 0.5, rtol=1e-3)
+    torch.testing.assert_close(s[..., 1], ref2, atol=1e-2, rtol=_tol(dtype, 1e-4, 1e-3))
+
+    # dgrad = same kernel, weights packed transposed + flipped
+    dyd = _to_ndhwc(dy, dtype, dev)
+    if cin % 8 == 0:
+        wpk_d = ops.pack_weights(wd, dtype, ops.PACK_DGRAD, dil=dil)
+        dx, _ = ops.conv3d(dyd, wpk_d, cin, 3, dil)
+        torch.testing.assert_close(_from_ndhwc(dx), xr.grad, atol=_tol(dtype, 3e-5, 5e-2), rtol=_tol(dtype, 1e-5, 2e-2))
+    # wgrad
+    dw, _ = ops.conv3d_wgrad(xd, dyd, 3, dil)
+    dw = dw[:, :cin].cpu()
+    scale = float(wr.grad.abs().max())
+    torch.testing.assert_close(dw, wr.grad, atol=_tol(dtype, 2e-5, 4e-3) * max(scale, 1.0), rtol=_tol(dtype, 1e-4, 1e-2))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv3d_channel_slice_views(dtype):
+    """Input read from / output written into channel slices of wider buffers (concat removal)."""
+    from brats21_amd import ops
+    dev = _dev()
+    x = _q(_rand((1, 16, 8, 8, 8), 5), dtype)
+    w = _rand((16, 16, 3, 3, 3), 6, 0.07)
+    xd = _to_ndhwc(x, dtype, dev, pitch=40, off=8)
+    out_buf = torch.full((1, 8, 8, 8, 48), 3.0, dtype=dtype, device=dev)
+    wpk = ops.pack_weights(w.to(dev), dtype, ops.PACK_FWD)
+    ops.conv3d(xd, wpk, 16, 3, 1, out=out_buf[..., 16:32])
+    ref = F.conv3d(x, _q(w, dtype), None, 1, 1)
+    torch.testing.assert_close(_from_ndhwc(out_buf[..., 16:32]), ref, atol=_tol(dtype, 2e-5, 3e-2), rtol=_tol(dtype, 1e-5, 2e-2))
+    assert float(out_buf[..., :16].float().min()) == 3.0 and float(out_buf[..., 32:].float().max()) == 3.0  # untouched
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,act", [(8, "relu"), (48, "relu"), (16, "leakyrelu")])
+def test_groupnorm_act_fwd_bwd(dtype, c, act):
+    from brats21_amd import ops
+    dev = _dev()
+    n, size = 2, (8, 8, 8)
+    cin = 8
+    x = _q(_rand((n, cin, *size), 11), dtype)
+    w = _q(_rand((c, cin, 3, 3, 3), 12, 0.1), dtype)
+    gamma = 1.0 + 0.2 * _rand((c,), 13)
+    beta = 0.1 * _rand((c,), 14)
+    # reference: conv -> GN -> act, gradient w.r.t. the conv output
+    y_ref = F.conv3d(x, w, None, 1, 1).detach().requires_grad_(True)
+    g_r, b_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    zn = F.group_norm(y_ref, 8, g_r, b_r, 1e-5)
+    z_ref = F.relu(zn) if act == "relu" else F.leaky_relu(zn, 0.01)
+    dz = _q(_rand(z_ref.shape, 15), dtype)
+    z_ref.backward(dz)
+
+    xd = _to_ndhwc(x, dtype, dev)
+    wpk = ops.pack_weights(w.to(dev), dtype, ops.PACK_FWD)
+    y, stats = ops.conv3d(xd, wpk, c, 3, 1, want_stats=True)
+    mr, ss = ops.gn_finalize(stats, n, c, 8, 512, gamma.to(dev), beta.to(dev))
+    z = ops.affine_act(y, ss, act)
+    torch.testing.assert_close(_from_ndhwc(z), z_ref.detach(), atol=_tol(dtype, 5e-5, 6e-2), rtol=_tol(dtype, 1e-4, 3e-2))
+    dy, dgamma, dbeta = ops.gn_act_bwd(_to_ndhwc(dz, dtype, dev), y, ss, mr, gamma.to(dev), 8, act)
+    torch.testing.assert_close(_from_ndhwc(dy), y_ref.grad, atol=_tol(dtype, 1e-4, 8e-2), rtol=_tol(dtype, 1e-3, 5e-2))
+    torch.testing.assert_close(dgamma.cpu(), g_r.grad, atol=_tol(dtype, 1e-3, 0.5), rtol=_tol(dtype, 1e-4, 3e-2))
+    torch.testing.assert_close(dbeta.cpu(), b_r.grad, atol=_tol(dtype, 1e-3, 0.5), rtol=_tol(dtype, 1e-4, 3e-2))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("with_avg", [False, True])
+def test_pool_fwd_bwd(dtype, with_avg):
+    from brats21_amd import ops
+    dev = _dev()
+    x = _q(_rand((2, 16, 8, 12, 8), 21), dtype)
+    x[:, :, :2] = x[:, :, :2].clamp(min=0)  # exact ties (zeros) like after ReLU
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool3d(xr, 2, 2)
+    if with_avg:
+        y_ref = torch.cat([y_ref, F.avg_pool3d(xr, 2)], 1)
+    dy = _q(_rand(y_ref.shape, 22), dtype)
+    y_ref.backward(dy)
+    skip = _q(_rand(x.shape, 23), dtype)
+    xd = _to_ndhwc(x, dtype, dev, pitch=32, off=0)
+    y = ops.maxpool2(xd, with_avg)
+    torch.testing.assert_close(_from_ndhwc(y), y_ref.detach(), atol=_tol(dtype, 1e-6, 1e-2), rtol=0)
+    dx = ops.maxpool2_bwd(xd, _to_ndhwc(dy, dtype, dev), dx_skip=_to_ndhwc(skip, dtype, dev, pitch=32, off=16), with_avg=with_avg)
+    torch.testing.assert_close(_from_ndhwc(dx), xr.grad + skip, atol=_tol(dtype, 1e-6, 3e-2), rtol=_tol(dtype, 0, 1e-2))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("size,scale", [((4, 4, 4), 2), ((2, 6, 4), 2), ((4, 4, 4), 4)])
+def test_upsample_fwd_bwd(dtype, size, scale):
+    from brats21_amd import ops
+    dev = _dev()
+    x = _q(_rand((2, 8, *size), 31), dtype)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.interpolate(xr, scale_factor=scale, mode="trilinear", align_corners=True)
+    dy = _q(_rand(y_ref.shape, 32), dtype)
+    y_ref.backward(dy)
+    y = ops.upsample(_to_ndhwc(x, dtype, dev), scale)
+    torch.testing.assert_close(_from_ndhwc(y), y_ref.detach(), atol=_tol(dtype, 1e-5, 2e-2), rtol=_tol(dtype, 1e-5, 1e-2))
+    dx = ops.upsample_bwd(_to_ndhwc(dy, dtype, dev, pitch=24, off=8), scale)
+    torch.testing.assert_close(_from_ndhwc(dx), xr.grad, atol=_tol(dtype, 2e-5, 8e-2), rtol=_tol(dtype, 1e-5, 3e-2))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,scale", [(8, 1), (16, 2), (48, 8)])
+def test_head_fwd_bwd(dtype, c, scale):
+    from brats21_amd import ops
+    dev = _dev()
+    size = (4, 4, 4)
+    x = _q(_rand((2, c, *size), 41), dtype)
+    w = _rand((3, c, 1, 1, 1), 42, 0.2)
+    b = _rand((3,), 43, 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    o_ref = F.conv3d(xr, wr, br)
+    if scale > 1:
+        o_ref = F.interpolate(o_ref, scale_factor=scale, mode="trilinear", align_corners=True)
+    do = _rand(o_ref.shape, 44)
+    o_ref.backward(do)
+    xd = _to_ndhwc(x, dtype, dev)
+    o = ops.head(xd, w.to(dev), b.to(dev), scale)
+    torch.testing.assert_close(o.cpu(), o_ref.detach(), atol=1e-5, rtol=1e-5)
+    dx, dw, db = ops.head_bwd(xd, w.to(dev), do.to(dev), scale)
+    torch.testing.assert_close(_from_ndhwc(dx), xr.grad, atol=_tol(dtype, 1e-5, 2e-2), rtol=_tol(dtype, 1e-5, 1e-2))
+    torch.testing.assert_close(dw.cpu(), wr.grad, atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(db.cpu(), br.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_layout_roundtrip():
+    from brats21_amd import ops
+    dev = _dev()
+    x = _rand((2, 4, 8, 8, 8), 51).to(dev)
+    for dtype, cpad in ((torch.float32, 4), (torch.bfloat16, 8)):
+        t = ops.ncdhw_to_ndhwc(x, dtype, cpad)
+        assert t.shape == (2, 8, 8, 8, cpad)
+        back = ops.ndhwc_to_ncdhw(t[..., :4])
+        torch.testing.assert_close(back, x.to(dtype).float(), atol=0, rtol=0)
+        if cpad > 4:
+            assert float(t[..., 4:].float().abs().max()) == 0.0
