@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: train patches/s of EquiUnet width 48 on synthetic
+4x128^3 patches, batch 2 per GPU, bf16 (configs[1]); one "step" = forward + deep-supervision Dice
+loss + backward + gradient all-reduce (N > 1) + Adam step.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def conv_flops(cin, cout, k, n, d, h, w):
+    return 2.0 * cin * k ** 3 * cout * n * d * h * w
+
+
+def cpu_baseline(width, threads):
+    """The CPU oracle (plain torch fp32 restatement of the reference's CPU path, oracle/unet.py) on a
+    bounded sample: ONE 4x64^3 patch (1/8 of the voxels of a 4x128^3 patch), forward + Dice loss +
+    backward, 1 warm-up + 2 timed repetitions.  Reported in the metric's unit (128^3-patches/s)."""
+    from oracle import synth as osynth, unet
+    torch.set_num_threads(threads)
+    size = (64, 64, 64)
+    sd = {k: v.requires_grad_(True) for k, v in osynth.fill_state_dict(unet.equiunet_state_shapes(width)).items()}
+    x, t = osynth.random_image(1, 4, size), osynth.nested_spheres(1, size)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        loss = unet.deep_supervision_loss(unet.equiunet_forward(sd, x), t)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+        if it:
+            times.append(time.perf_counter() - t0)
+    sec = sorted(times)[len(times) // 2]
+    return {"value": (1.0 / 8.0) / sec, "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"1 patch of 4x64^3 (=1/8 of a 4x128^3 patch), fwd+loss+bwd fp32, median of 2: {sec:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=48)
+    ap.add_argument("--batch", type=int, default=2, help="patches per GPU")
+    ap.add_argument("--patch", type=int, default=128)
+    ap.add_argument("--model", default="equiunet")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
+    args = ap.parse_args()
+
+    from brats21_amd import get_model, ops, LIB_PATH
+    from brats21_amd import synth
+    from brats21_amd.ddp import GradientBuckets, init_process_group_from_env
+    from brats21_amd.losses import DiceLoss, deep_supervision_loss
+
+    assert os.path.exists(LIB_PATH), "HIP extension missing"
+    rank, world, local = init_process_group_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    ns = argparse.Namespace(model=args.model, width=args.width, norm="group", act="relu", num_classes=3, dropout=0)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = get_model(ns).to(dev).train()
+    crit = DiceLoss().to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
+    buckets = GradientBuckets(model) if world > 1 else None
+    size = (args.patch,) * 3
+    x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
+    t = synth.nested_spheres(args.batch, size, device=dev)
+    use_amp = args.precision == "bf16"
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
+            out = model(x)
+            loss, _ = deep_supervision_loss(crit, out, t)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    timer = ops.KernelTimer() if rank == 0 else None
+    ops.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel, from HIP events recorded inside the timed steps ----
+    table = timer.summary()
+    fam = {}
+    for key, (cnt, avg, tot) in table.items():
+        fam.setdefault(key[0], [0.0, 0.0])
+        kind, cin, cout, k, dil, n, d, h, w, dt = key
+        fam[kind][0] += tot
+        fam[kind][1] += conv_flops(cin, cout, k, n, d, h, w) * cnt
+    dom_key = max(table, key=lambda k: table[k][2])
+    cnt, avg_ms, tot_ms = table[dom_key]
+    kind, cin, cout, k, dil, n, d, h, w, dt = dom_key
+    fl = conv_flops(cin, cout, k, n, d, h, w)
+    peak = PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS
+    achieved = fl / (avg_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": f"{kind} cin={cin} cout={cout} k={k} dil={dil} @{n}x{d}x{h}x{w}",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": None, "launches": cnt, "avg_ms": round(avg_ms, 4),
+                "families": {f: {"ms_per_step": round(v[0] / args.steps, 3), "TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                             for f, v in fam.items()}}
+    if args.kernel_table:
+        for key in sorted(table, key=lambda k: -table[k][2]):
+            c, a, tt = table[key]
+            kk, ci, co, ks, dl, nn, dd, hh, ww, dt = key
+            tf = conv_flops(ci, co, ks, nn, dd, hh, ww) / (a * 1e-3) / 1e12
+            print(f"# {kk:11s} cin={ci:4d} cout={co:4d} d={dl} @{dd:3d}^3  n={c:3d} avg {a:8.3f} ms  {tf:7.1f} TF/s  total {tt:8.2f} ms",
+                  file=sys.stderr)
+    patches = world * args.batch * args.steps
+    res = {
+        "metric": "train patches/sec (4x128^3, width-48)", "value": round(patches / elapsed, 4), "unit": "patches/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"{args.model} width={args.width}, batch={args.batch}/GPU of 4x{args.patch}^3 synthetic patches, "
+                               f"fwd + deep-supervision Dice + bwd + Adam (BASELINE.json configs[1])",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.width, os.cpu_count() or 1)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

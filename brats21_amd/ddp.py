@@ -1,0 +1,142 @@
+"""Data-parallel training over RCCL / xGMI: one process per GPU, gradients only.
+
+The reference is single-GPU; BASELINE.json's north_star adds: shard patients
+across the 8 GPUs of a node, all-reduce the gradients.  Nothing else is exchanged: GroupNorm /
+EvoNorm / SE are per-sample (no statistic sync) and DiceLoss(batch=True) reduces over the *local*
+batch, so the DDP loss is the mean over ranks of per-rank batch-Dice.
+
+Design for xGMI (7 point-to-point links x ~153 GB/s per GPU, ring collectives are per-link bound):
+few, large buckets (default 32 MiB of f32 gradients -> 3 buckets for EquiUnet-48's 92.6 MB) filled in
+the order the backward program produces gradients; each bucket's all-reduce is launched
+asynchronously the moment its last gradient lands, so it overlaps the remaining backward kernels.
+The accelerated models are a single autograd node, so instead of per-parameter autograd hooks the
+backward program itself pushes every finished gradient into ``GradientBuckets.push`` (the
+``_grad_sink`` attribute of the module).  Statically unused parameters (EvoNorm ``v``, SURVEY.md
+Appendix B) never get a gradient and are simply not part of any bucket.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend=None):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* come from torch.distributed.run (the CLI of the
+    reference stays untouched: new knobs are env-only)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items, rank, world, epoch=0, shuffle=True, seed=0):
+    """Patient sharding (DistributedSampler-style over ``train_files``, src/definer.py:514-522):
+    every rank gets ceil(n/world) indices, the list is padded by wrap-around so ranks stay in step."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        order = torch.randperm(n_items, generator=g).tolist()
+    else:
+        order = list(range(n_items))
+    per = -(-n_items // world)
+    order += order[: per * world - n_items]
+    return order[rank::world]
+
+
+class GradientBuckets:
+    """Bucketed, asynchronous gradient averaging for one model replica."""
+
+    def __init__(self, model, bucket_bytes=32 << 20, process_group=None):
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = list(model.parameters())  # indices = position in model.parameters()
+        self.bucket_bytes = bucket_bytes
+        self._plan = None          # list of buckets: [(param_index, offset, numel), ...]
+        self._where = None         # param_index -> (bucket_id, offset)
+        self._flat = None
+        self._order = []           # production order seen during the first backward
+        self._pending = None
+        self._handles = []
+        self._filled = None
+        if hasattr(model, "_grad_sink"):
+            model._grad_sink = self.push
+
+    # -- planning ---------------------------------------------------------------------------------
+    def _build_plan(self, order):
+        plan, cur, size = [], [], 0
+        for idx in order:
+            n = self.params[idx].numel()
+            if cur and (size + n) * 4 > self.bucket_bytes:
+                plan.append(cur)
+                cur, size = [], 0
+            cur.append((idx, size, n))
+            size += n
+        if cur:
+            plan.append(cur)
+        self._plan = plan
+        self._where = {idx: (b, off) for b, bucket in enumerate(plan) for idx, off, _ in bucket}
+        dev = self.params[0].device
+        self._flat = [torch.zeros(sum(n for _, _, n in bucket), dtype=torch.float32, device=dev) for bucket in plan]
+
+    def _start(self):
+        self._filled = [0] * len(self._plan)
+        self._handles = [None] * len(self._plan)
+
+    def _launch(self, b):
+        if self.world > 1:
+            self._handles[b] = dist.all_reduce(self._flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # -- producer side ----------------------------------------------------------------------------
+    def push(self, param_index, grad):
+        """Called by the backward program as soon as parameter #param_index's gradient exists."""
+        if self._plan is None:
+            self._order.append(param_index)  # first step: learn the production order, reduce in finish()
+            return
+        if self._filled is None:
+            self._start()
+        b, off = self._where[param_index]
+        self._flat[b][off:off + grad.numel()].copy_(grad.reshape(-1))
+        self._filled[b] += 1
+        if self._filled[b] == len(self._plan[b]):
+            self._launch(b)
+
+    # -- consumer side ----------------------------------------------------------------------------
+    def finish(self):
+        """After loss.backward(): make every p.grad the average over ranks."""
+        if self._plan is None:
+            seen = set(self._order)
+            order = self._order + [i for i, p in enumerate(self.params) if i not in seen and p.grad is not None]
+            if not order:
+                order = [i for i, p in enumerate(self.params) if p.grad is not None]
+            order = [i for i in order if self.params[i].grad is not None]
+            self._build_plan(order)
+            self._order = []
+        if self._filled is None:
+            self._start()
+        for b, bucket in enumerate(self._plan):
+            if self._filled[b] != len(bucket):  # not produced through push(): gather from p.grad now
+                for idx, off, n in bucket:
+                    self._flat[b][off:off + n].copy_(self.params[idx].grad.reshape(-1))
+                self._launch(b)
+        inv = 1.0 / self.world
+        for b, bucket in enumerate(self._plan):
+            if self._handles[b] is not None:
+                self._handles[b].wait()
+            for idx, off, n in bucket:
+                p = self.params[idx]
+                g = self._flat[b][off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                torch.mul(g, inv, out=p.grad)
+        self._filled = None
+        self._handles = []
+
+    def payload_bytes(self):
+        return sum(f.numel() for f in self._flat) * 4 if self._flat else 0

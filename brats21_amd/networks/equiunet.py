@@ -79,7 +79,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None):
     return z, (unit, x, y, mean_rstd, scale_shift)
 
 
-def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True):
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None):
     unit, x, y, mean_rstd, scale_shift = rec
     dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), 8, act)
     dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation)
@@ -87,6 +87,9 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True):
     grads[names[unit.conv.weight]] = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
     grads[names[unit.bn.weight]] = dgamma
     grads[names[unit.bn.bias]] = dbeta
+    if sink is not None:  # data-parallel: hand finished gradients to the bucketed all-reduce right away
+        for prm in (unit.conv.weight, unit.bn.weight, unit.bn.bias):
+            sink(names[prm], grads[names[prm]])
     if not need_dx:
         return None
     wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
@@ -154,7 +157,7 @@ class _EquiUnetFn(torch.autograd.Function):
         rec = {r[0]: r for r in tape}
 
         def cbw(unit, dz, need_dx=True):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx)
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
@@ -164,6 +167,9 @@ class _EquiUnetFn(torch.autograd.Function):
             dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
             grads[names[hd.weight]] = dw
             grads[names[hd.bias]] = db
+            if m._grad_sink is not None:
+                m._grad_sink(names[hd.weight], dw)
+                m._grad_sink(names[hd.bias], db)
             key = src.data_ptr()
             dsrc[key] = dx if key not in dsrc else dsrc[key] + dx
 
@@ -218,6 +224,7 @@ class EquiUnet(nn.Module):
         self.features = list(features)
         self.precision = "auto"
         self.skip_deep_heads_in_eval = False
+        self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
         f = self.features
         self.encoder1 = UBlock(inplanes, f[0], f[0])
         self.encoder2 = UBlock(f[0], f[1], f[1])

@@ -13,6 +13,55 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F32, PACK_DGRAD, PACK_FWD
 ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "leakyrelu": ACT_LEAKY}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual library launches on the launch stream (bench.py's
+    live roofline measurement).  ops.TIMER = KernelTimer() enables it; None (default) costs nothing."""
+
+    def __init__(self):
+        self.records = {}  # key -> list of (start_event, end_event)
+
+    def span(self, key):
+        return _Span(self, key)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[key] = (len(ms), sum(ms) / len(ms), sum(ms))
+        return out
+
+
+class _Span:
+    def __init__(self, timer, key):
+        self.timer, self.key = timer, key
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()  # current stream == the stream the library launches on (_stream())
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.timer.records.setdefault(self.key, []).append((self.a, self.b))
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMER = None
+_NOSPAN = _NoSpan()
+
+
+def _span(*key):
+    return TIMER.span(key) if TIMER is not None else _NOSPAN
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -119,9 +168,10 @@ def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=Fa
     stats = None
     if want_stats:
         stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().brats_conv3d_fwd(ptr, c, p, None, 0, 0, packed_w.data_ptr(), _f32(bias), optr, op,
-                                           stats.data_ptr() if stats is not None else None, _code(x.dtype), ksize, dil,
-                                           n, d, h, w, cout, _stream()), "conv3d_fwd")
+    with _span("conv_igemm", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_fwd(ptr, c, p, None, 0, 0, packed_w.data_ptr(), _f32(bias), optr, op,
+                                               stats.data_ptr() if stats is not None else None, _code(x.dtype), ksize,
+                                               dil, n, d, h, w, cout, _stream()), "conv3d_fwd")
     return out, stats
 
 
@@ -135,9 +185,10 @@ def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False):
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, c, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
-    _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, None, 0, 0, dptr, dp, ws.data_ptr(), dw.data_ptr(),
-                                             db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
-                                             cout, _stream()), "conv3d_wgrad")
+    with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, None, 0, 0, dptr, dp, ws.data_ptr(), dw.data_ptr(),
+                                                 db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
+                                                 cout, _stream()), "conv3d_wgrad")
     return dw, db
 
 
