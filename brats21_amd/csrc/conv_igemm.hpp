@@ -71,53 +71,88 @@ constexpr int conv_lds_bytes() {
   return a + TL::SRED_BYTES;
 }
 
+// One Cin chunk of MFMA work, software-pipelined by hand (hipcc does not do it at this register
+// pressure): the weight fragments of step k+1 are requested from L2 before the MFMAs of step k, and the
+// 8 activation fragments are read from LDS in two halves so that 4 ds_read_b128 are always in flight
+// behind 12 MFMAs.
 template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */>
 DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
                          int lane, f32x4 (&acc)[NF][8]) {
   using G = ConvGeom<T, KS, CK, DIL>;
   constexpr int FOZ = G::HY * G::HX * G::S;  // one z-slice
-  static_for<0, G::MS>([&](auto ms_) {
-    constexpr int ms = ms_;
-    if constexpr (PARITY < 0 || (ms & 1) == PARITY) {
-      if constexpr (G::BF) {
-        const bf16x8* wp = (const bf16x8*)wpk_chunk + ((size_t)ms * rows16 + f0) * 64 + lane;
-        bf16x8 a[NF];
+  constexpr int NSTEP = PARITY < 0 ? G::MS : (G::MS - PARITY + 1) / 2;
+  if constexpr (G::BF) {
+    const bf16x8* wp0 = (const bf16x8*)wpk_chunk + (size_t)f0 * 64 + lane;
+    bf16x8 a[2][NF];
+    bf16x8 b[8];
+    auto load_a = [&](auto k_) {
+      constexpr int k = k_;
+      constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) a[f] = wp[f * 64];
-        constexpr int o0 = G::unitoff(4 * ms), o1 = G::unitoff(4 * ms + 1), o2 = G::unitoff(4 * ms + 2),
-                      o3 = G::unitoff(4 * ms + 3);
-        int lb;
-        if constexpr (o1 - o0 == G::UB && o2 - o0 == 2 * G::UB && o3 - o0 == 3 * G::UB) {
-          lb = lane_b + o0;  // lane_b already carries q*UB
-        } else {
-          lb = lane_b + (q == 0 ? o0 : q == 1 ? o1 - G::UB : q == 2 ? o2 - 2 * G::UB : o3 - 3 * G::UB);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const bf16x8 b = *(const bf16x8*)(ldsb + lb + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
-#pragma unroll
-          for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f], b, acc[f][i], 0, 0, 0);
-        }
+      for (int f = 0; f < NF; ++f) a[k & 1][f] = wp0[((size_t)ms * rows16 + f) * 64];
+    };
+    auto read_b = [&](auto k_, auto half_) {
+      constexpr int k = k_, half = half_;
+      constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
+      constexpr int o0 = G::unitoff(4 * ms), o1 = G::unitoff(4 * ms + 1), o2 = G::unitoff(4 * ms + 2),
+                    o3 = G::unitoff(4 * ms + 3);
+      int lb;
+      if constexpr (o1 - o0 == G::UB && o2 - o0 == 2 * G::UB && o3 - o0 == 3 * G::UB) {
+        lb = lane_b + o0;  // lane_b already carries q*UB
       } else {
-        const f32x4* wp = (const f32x4*)wpk_chunk + ((size_t)ms * rows16 + f0) * 64 + lane;
-        f32x4 a[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) a[f] = wp[f * 64];
-        static_for<0, 4>([&](auto j_) {
-          constexpr int j = j_;
-          constexpr int o = G::unitoff(4 * (4 * ms + j));  // CK%4==0: the 4 quarters share the tap
-          if constexpr (4 * (4 * ms + j) < G::UNITS) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float b = *(const float*)(ldsb + lane_b + o + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
-#pragma unroll
-              for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][j], b, acc[f][i], 0, 0, 0);
-            }
-          }
-        });
+        lb = lane_b + (q == 0 ? o0 : q == 1 ? o1 - G::UB : q == 2 ? o2 - 2 * G::UB : o3 - 3 * G::UB);
       }
-    }
-  });
+#pragma unroll
+      for (int i = 4 * half; i < 4 * half + 4; ++i)
+        b[i] = *(const bf16x8*)(ldsb + lb + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
+    };
+    auto mma = [&](auto k_, auto half_) {
+      constexpr int k = k_, half = half_;
+#pragma unroll
+      for (int i = 4 * half; i < 4 * half + 4; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k & 1][f], b[i], acc[f][i], 0, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    load_a(I0{});
+    read_b(I0{}, I0{});
+    static_for<0, NSTEP>([&](auto k_) {
+      constexpr int k = k_;
+      // sched_barrier(0) pins the issue order: without it hipcc sinks every load to just before its
+      // first use (one live B fragment, weights waited for at vmcnt(0)) and the loop runs latency-bound
+      if constexpr (k + 1 < NSTEP) load_a(std::integral_constant<int, k + 1>{});
+      read_b(k_, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(k_, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (k + 1 < NSTEP) read_b(std::integral_constant<int, k + 1>{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(k_, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  } else {
+    static_for<0, NSTEP>([&](auto k_) {
+      constexpr int k = k_;
+      constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
+      const f32x4* wp = (const f32x4*)wpk_chunk + ((size_t)ms * rows16 + f0) * 64 + lane;
+      f32x4 a[NF];
+#pragma unroll
+      for (int f = 0; f < NF; ++f) a[f] = wp[f * 64];
+      static_for<0, 4>([&](auto j_) {
+        constexpr int j = j_;
+        constexpr int o = G::unitoff(4 * (4 * ms + j));  // CK%4==0: the 4 quarters share the tap
+        if constexpr (4 * (4 * ms + j) < G::UNITS) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float bb = *(const float*)(ldsb + lane_b + o + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][j], bb, acc[f][i], 0, 0, 0);
+          }
+        }
+      });
+    });
+  }
 }
 
 template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
