@@ -8,8 +8,8 @@
 //   B operand (MFMA cols)  = activations, read from an LDS halo tile (one ds_read_b128 per fragment)
 //   C/D: lane (q = lane>>4, v = lane&15) holds cout rows 4q..4q+3 of voxel v -> 4 contiguous
 //        NDHWC channels per lane = one 8/16-byte store.
-// Workgroup = 256 threads = 4 waves on a 4x8x8 voxel tile: wave (wm, wn); wm picks 2 z-slices
-// (128 voxels = 8 voxel-fragments), wn picks either the cout half (tile = 2*NF*16 couts) or, when
+// Workgroup = 256 threads = 4 waves on a 4x4x16 (z,y,x) voxel tile: wave (wm, wn); wm picks 2 z-slices
+// (128 voxels = 8 voxel-fragments, each one x-row of 16), wn picks either the cout half (tile = 2*NF*16 couts) or, when
 // the layer has too few couts (KSPLIT), the parity of the K macro-steps (reduced through LDS).
 // Per Cin chunk (CK channels) the halo tile is staged once and all taps read it (27x reuse from
 // LDS; HBM/L2 sees only the ~2x halo amplification).  2 workgroups/CU overlap staging with MFMA.
@@ -23,7 +23,7 @@ struct ConvParams {
   int tz, ty, tx;
 };
 
-constexpr int CONV_TZ = 4, CONV_TY = 8, CONV_TX = 8;
+constexpr int CONV_TZ = 4, CONV_TY = 4, CONV_TX = 16;  // a voxel fragment = one x-row of 16
 
 template <typename T, int KS, int CK, int DIL>
 struct ConvGeom {
@@ -35,7 +35,10 @@ struct ConvGeom {
   static constexpr int HVOX = HZ * HY * HX;
   static constexpr int ROWB = CK * ESZ;
   static constexpr int PPV = ROWB / 16;
-  static constexpr int S = (PPV % 2 == 0) ? ROWB + 16 : ROWB;  // odd number of 16-B slots per voxel
+  // voxel stride in LDS.  bf16: a fragment's 16 voxels are 16 consecutive x, so ds_read_b128 is
+  // bank-conflict-free iff (S/16) % 4 == 2 (32, 96, 160 B ...; CK=48 -> 96 B = no padding at all).
+  // f32 (ds_read_b32 operands, parity mode): odd number of 16-B slots (2-way at worst).
+  static constexpr int S = BF ? 16 * (PPV + ((2 - PPV % 4) + 4) % 4) : ((PPV % 2 == 0) ? ROWB + 16 : ROWB);
   static constexpr int NPIECE = HVOX * PPV;
   static constexpr int NITER = (NPIECE + 255) / 256;
   static constexpr int TAPS = KS * KS * KS;
@@ -104,7 +107,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       }
 #pragma unroll
       for (int i = 4 * half; i < 4 * half + 4; ++i)
-        b[i] = *(const bf16x8*)(ldsb + lb + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
+        b[i] = *(const bf16x8*)(ldsb + lb + ((i >> 2) * FOZ + (i & 3) * G::HX * G::S));
     };
     auto mma = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
@@ -145,7 +148,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
         if constexpr (4 * (4 * ms + j) < G::UNITS) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float bb = *(const float*)(ldsb + lane_b + o + ((i >> 2) * FOZ + 2 * (i & 3) * G::HX * G::S));
+            const float bb = *(const float*)(ldsb + lane_b + o + ((i >> 2) * FOZ + (i & 3) * G::HX * G::S));
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][j], bb, acc[f][i], 0, 0, 0);
           }
@@ -155,12 +158,22 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
   }
 }
 
+// 16-lane (one MFMA row group) all-reduce with DPP row rotations: 4 VALU ops, no LDS crossbar.
+DEVI float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));  // row_ror:4
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));  // row_ror:2
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return x;
+}
+
 template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   using G = ConvGeom<T, KS, CK, DIL>;
   using TL = ConvTile<NF, KSPLIT>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar row math
   const int wm = wave & 1, wn = wave >> 1;
   const int q = lane >> 4, v = lane & 15;
 
@@ -175,17 +188,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int f0 = ct * TL::NFW + (KSPLIT ? 0 : wn * NF);
   const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
 
-  // --- staging descriptors (identical for every Cin chunk) ---
-  int voff[G::NITER];
+  // --- staging: wave w owns halo rows (hz,hy) = w, w+4, ...; a row is HX voxels x PPV 16-byte pieces,
+  //     fetched by IPR wave-instructions.  Row origin / bounds are scalar; the per-lane part (which
+  //     piece of the row, is its x inside the volume) is computed once per kernel.
+  constexpr int NROWS = G::HZ * G::HY;
+  constexpr int PPR = G::HX * G::PPV;          // pieces per row
+  constexpr int IPR = (PPR + 63) / 64;         // wave-instructions per row
+  constexpr int RPW = (NROWS + 3) / 4;         // rows per wave
+  int lds_off[IPR];    // byte offset of the lane's piece inside an LDS row (+ the wave's first row)
+  int hx_part[IPR];    // hx * 65536 + part, or -1 when the lane has no piece / x is outside the volume
 #pragma unroll
-  for (int i = 0; i < G::NITER; ++i) {
-    const int pc = tid + 256 * i;
-    const int hv = pc / G::PPV;
-    const int hz = hv / (G::HY * G::HX), rr = hv % (G::HY * G::HX);
-    const int hy = rr / G::HX, hx = rr % G::HX;
-    const int gz = z0 - G::R + hz, gy = y0 - G::R + hy, gx = x0 - G::R + hx;
-    const bool inb = pc < G::NPIECE && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    voff[i] = inb ? (gz * p.H + gy) * p.W + gx : -1;
+  for (int j = 0; j < IPR; ++j) {
+    const int pc = lane + 64 * j;
+    const int hx = pc / G::PPV, part = pc % G::PPV;
+    const int gx = x0 - G::R + hx;
+    const bool ok = pc < PPR && gx >= 0 && gx < p.W;
+    hx_part[j] = ok ? (hx << 16) | part : -1;
+    lds_off[j] = pc < PPR ? wave * (G::HX * G::S) + hx * G::S + part * 16 : -1;
   }
 
   f32x4 acc[NF][8];
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     for (int i = 0; i < 8; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // lane's voxel inside the halo tile (tap (0,0,0) corner) + quarter offset
-  const int lane_b = ((wm * 2) * G::HY * G::HX + (v >> 3) * G::HX + (v & 7)) * G::S + q * G::UB;
+  const int lane_b = ((wm * 2) * G::HY * G::HX + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;  // bytes of packed weights per chunk
 
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -204,19 +223,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     int pitch;
     if (c0 < p.c1) { src = (const T*)p.x1 + c0; pitch = p.p1; }
     else { src = (const T*)p.x2 + (c0 - p.c1); pitch = p.p2; }
-    src += sample_vox * pitch;
-    u32x4 r[G::NITER];
+    int goff[IPR];  // element offset of the lane's piece from the row origin (gx = x0 - R)
 #pragma unroll
-    for (int i = 0; i < G::NITER; ++i) {
-      const int part = (tid + 256 * i) % G::PPV;
-      r[i] = u32x4{0u, 0u, 0u, 0u};
-      if (voff[i] >= 0) r[i] = *(const u32x4*)(src + (size_t)voff[i] * pitch + part * G::EPL);
+    for (int j = 0; j < IPR; ++j) goff[j] = (hx_part[j] >> 16) * pitch + (hx_part[j] & 0xffff) * G::EPL;
+    u32x4 r[RPW][IPR];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int row = wave + 4 * k;
+      const int hz = row / G::HY, hy = row % G::HY;
+      const int gz = z0 - G::R + hz, gy = y0 - G::R + hy;
+      const bool row_ok = row < NROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;  // scalar
+      const T* rowp = src + ((ptrdiff_t)(sample_vox + (size_t)(gz * p.H + gy) * p.W) + (x0 - G::R)) * pitch;
+#pragma unroll
+      for (int j = 0; j < IPR; ++j) {
+        r[k][j] = u32x4{0u, 0u, 0u, 0u};
+        if (row_ok && hx_part[j] >= 0) r[k][j] = *(const u32x4*)(rowp + goff[j]);
+      }
     }
     if (chunk > 0) __syncthreads();  // all waves finished reading the previous chunk's tile
 #pragma unroll
-    for (int i = 0; i < G::NITER; ++i) {
-      const int pc = tid + 256 * i;
-      if (pc < G::NPIECE) *(u32x4*)(lds + (pc / G::PPV) * G::S + (pc % G::PPV) * 16) = r[i];
+    for (int k = 0; k < RPW; ++k) {
+      if (wave + 4 * k < NROWS) {
+#pragma unroll
+        for (int j = 0; j < IPR; ++j)
+          if (lds_off[j] >= 0) *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = r[k][j];
+      }
     }
     __syncthreads();
     const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
@@ -247,50 +278,84 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
   }
 
-  // --- epilogue: bias, per-channel tile statistics, NDHWC store ---
+  // --- epilogue: bias, per-channel tile statistics, NDHWC store.  A fragment is one x-row, so the row
+  //     pointer / row bounds are scalar and each lane adds a fixed offset: no per-store address math.
   constexpr int LDS_MAIN = ((G::LDS_TILE > TL::RED_BYTES ? G::LDS_TILE : TL::RED_BYTES) + 15) / 16 * 16;
   float* sred = (float*)(lds + LDS_MAIN);  // [2 (wm)][NFW*16][2]
   const bool active = KSPLIT ? (wn == 0) : true;
   if (active) {
-    T* yb = (T*)p.y + sample_vox * p.ypitch;
+    const bool x_ok = x0 + v < p.W;
+    const int lane_o = (x0 + v) * p.ypitch + 4 * q;  // elements from the row origin
+    float bias[NF][4], s1[NF][4], s2[NF][4];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       const int cbase = (f0 + f) * 16 + 4 * q;
-      const bool cok = cbase < p.cout;
-      float bias[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && cok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = p.bias[cbase + r];
+      for (int r = 0; r < 4; ++r) {
+        bias[f][r] = (p.bias && cbase < p.cout) ? p.bias[cbase + r] : 0.f;
+        s1[f][r] = 0.f;
+        s2[f][r] = 0.f;
       }
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    }
+    // interior tiles (the common case) take the mask-free path; edge tiles weight the statistics by a
+    // 0/1 mask instead of branching around the accumulation (a branch makes hipcc copy all 8*NF
+    // running sums through v_mov at every row)
+    const bool full = z0 + CONV_TZ <= p.D && y0 + CONV_TY <= p.H && x0 + CONV_TX <= p.W &&
+                      (ct + 1) * TL::NFW * 16 <= p.cout;  // scalar
+    if (full) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int z = z0 + 2 * wm + (i >> 2), y = y0 + 2 * (i & 3) + (v >> 3), x = x0 + (v & 7);
-        const bool ok = cok && z < p.D && y < p.H && x < p.W;
-        float o[4];
+        const int z = z0 + 2 * wm + (i >> 2), y = y0 + (i & 3);
+        T* rowp = (T*)p.y + (sample_vox + (size_t)(z * p.H + y) * p.W) * p.ypitch;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = acc[f][i][r] + bias[r];
-        if (ok) {
+        for (int f = 0; f < NF; ++f) {
+          float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s1[r] += o[r]; s2[r] += o[r] * o[r]; }
-          Vec<T, 4>::store(yb + ((size_t)(z * p.H + y) * p.W + x) * p.ypitch + cbase, o);
+          for (int r = 0; r < 4; ++r) {
+            o[r] = acc[f][i][r] + bias[f][r];
+            s1[f][r] += o[r];
+            s2[f][r] += o[r] * o[r];
+          }
+          Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
       }
-      if (p.stats) {
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int z = z0 + 2 * wm + (i >> 2), y = y0 + (i & 3);
+        const bool ok = z < p.D && y < p.H && x_ok;
+        const float mk = ok ? 1.f : 0.f;
+        T* rowp = (T*)p.y + (sample_vox + (size_t)(z * p.H + y) * p.W) * p.ypitch;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bool cok = (f0 + f) * 16 + 4 * q < p.cout;
+          const float mf = cok ? mk : 0.f;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = acc[f][i][r] + bias[f][r];
+            const float om = o[r] * mf;
+            s1[f][r] += om;
+            s2[f][r] += om * o[r];
+          }
+          if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
+        }
+      }
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s1[r] += __shfl_xor(s1[r], m);
-            s2[r] += __shfl_xor(s2[r], m);
-          }
+          s1[f][r] = row16_sum(s1[f][r]);
+          s2[f][r] = row16_sum(s2[f][r]);
         }
         if (v == 0) {
           const int cl = (f0 + f - ct * TL::NFW) * 16 + 4 * q;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 0] = s1[r];
-            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 1] = s2[r];
+            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 0] = s1[f][r];
+            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 1] = s2[f][r];
           }
         }
       }

@@ -22,7 +22,7 @@ struct WgradParams {
   int tz, ty, tx, ntiles, nsplit;
 };
 
-constexpr int WG_TZ = 4, WG_TY = 8, WG_TX = 8, WG_VOX = 256;
+constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // rows of 16 x-voxels
 
 template <typename T, int DIL, int COF, int CIF>
 struct WgGeom {
@@ -33,7 +33,10 @@ struct WgGeom {
   static constexpr int HVOX = HZ * HY * HX;
   static constexpr int CI_T = 16 * CIF, CO_T = 16 * COF;
   static constexpr int XROWB = CI_T * ESZ, YROWB = CO_T * ESZ;
-  static constexpr int SX = XROWB + 16, SY = YROWB + 16;
+  // voxel strides: the transposing reads of a 32-lane half touch 8 consecutive x-voxels x 32 B, which is
+  // bank-conflict-free iff the stride is 32, 96 or 160 B (CI_T/CO_T = 48 bf16 -> 96 B, no padding)
+  static constexpr int SX = BF ? (CIF == 1 ? 32 : (CIF <= 3 ? 96 : XROWB + 32)) : XROWB + 16;
+  static constexpr int SY = BF ? (COF == 1 ? 32 : (COF <= 3 ? 96 : YROWB + 32)) : YROWB + 16;
   static constexpr int XPPV = XROWB / 16, YPPV = YROWB / 16;
   static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;
   static constexpr int XITER = (XPIECES + 255) / 256, YITER = (YPIECES + 255) / 256;
@@ -84,7 +87,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
     tapo[j] = t < 27 ? ((((t / 9) * DIL) * G::HY + ((t / 3) % 3) * DIL) * G::HX + (t % 3) * DIL) * G::SX : 0;
   }
 
-  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+  // global -> register prefetch of one tile (zero-filled outside the volume / channel range)
+  u32x4 rx[G::XITER], ry[G::YITER];
+  auto prefetch = [&](int tile) {
     int bt = tile;
     const int txi = bt % p.tx; bt /= p.tx;
     const int tyi = bt % p.ty; bt /= p.ty;
@@ -92,11 +97,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
     const int n = bt / p.tz;
     const int z0 = tzi * WG_TZ, y0 = tyi * WG_TY, x0 = txi * WG_TX;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
-    // ---- stage X halo tile and dY tile (zero-filled outside the volume / channel range) ----
-    u32x4 rx[G::XITER], ry[G::YITER];
+    // opaque copy of the thread id: stops hipcc from hoisting ~6 loop-invariant address terms per piece
+    // out of the tile loop (126 VGPRs -> spills -> every prefetch load waited for at vmcnt(0))
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
 #pragma unroll
     for (int i = 0; i < G::XITER; ++i) {
-      const int pc = tid + 256 * i;
+      const int pc = tid_o + 256 * i;
       const int hv = pc / G::XPPV, part = pc % G::XPPV;
       const int hz = hv / (G::HY * G::HX), rr = hv % (G::HY * G::HX);
       const int hy = rr / G::HX, hx = rr % G::HX;
@@ -108,58 +115,82 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
     }
 #pragma unroll
     for (int i = 0; i < G::YITER; ++i) {
-      const int pc = tid + 256 * i;
+      const int pc = tid_o + 256 * i;
       const int vx = pc / G::YPPV, part = pc % G::YPPV;
-      const int gz = z0 + vx / 64, gy = y0 + (vx / 8) % 8, gx = x0 + vx % 8;
+      const int gz = z0 + vx / 64, gy = y0 + (vx / 16) % 4, gx = x0 + vx % 16;
       const bool ok = pc < G::YPIECES && gz < p.D && gy < p.H && gx < p.W && part * G::EPL < co_lim;
       ry[i] = u32x4{0u, 0u, 0u, 0u};
       if (ok) ry[i] = *(const u32x4*)((const T*)p.dy + (sample_vox + (size_t)(gz * p.H + gy) * p.W + gx) * p.dyp + co0 + part * G::EPL);
     }
-    __syncthreads();  // previous tile's reads are done
+  };
+
+  if (split < p.ntiles) prefetch(split);
+  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+    __syncthreads();  // previous tile's LDS reads are done
+    int tid_w = tid;
+    asm volatile("" : "+v"(tid_w));
 #pragma unroll
     for (int i = 0; i < G::XITER; ++i) {
-      const int pc = tid + 256 * i;
+      const int pc = tid_w + 256 * i;
       if (pc < G::XPIECES) *(u32x4*)(ldx + (pc / G::XPPV) * G::SX + (pc % G::XPPV) * 16) = rx[i];
     }
 #pragma unroll
     for (int i = 0; i < G::YITER; ++i) {
-      const int pc = tid + 256 * i;
+      const int pc = tid_w + 256 * i;
       if (pc < G::YPIECES) *(u32x4*)(ldy + (pc / G::YPPV) * G::SY + (pc % G::YPPV) * 16) = ry[i];
     }
     __syncthreads();
+    // the next tile's HBM/L2 loads fly underneath this tile's MFMA phase (1 workgroup per CU: nobody
+    // else would hide them)
+    if (tile + p.nsplit < p.ntiles) prefetch(tile + p.nsplit);
 
     // ---- MFMA over the 256 voxels of the tile ----
     if constexpr (G::BF) {
-      // k-step s = voxels of flattened rows 4s..4s+3 (row = z*8+y), quarter q -> row 4s+q; the two
-      // transposing reads fetch x = 0..3 and x = 4..7 (lane 4q'+p of a quarter: voxel x=q', chans 4p..4p+3)
+      // k-step s = the two x-rows 2s, 2s+1 of the tile (row = z*4 + y, 16 voxels each).  MFMA k = 8q + e:
+      // e = 0..3 come from the first transposing read (row 2s, x = 4q + e), e = 4..7 from the second
+      // (row 2s+1, same x); lane 4qq+pp of a quarter supplies voxel x = 4q + qq, channels 4pp..4pp+3.
+      // Software pipeline over the 8 x 7 (k-step, tap) pairs: the fragments of pair u+1 are read while
+      // the COF*CIF MFMAs of pair u issue.  Wave 3's 7th tap slot is a dummy (tap 27): computed, never stored.
       const int qq = v >> 2, pp = v & 3;
-      const int ybase = ((q * 8) + qq) * G::SY + pp * 8;
-      const int xbase = (q * G::HX + qq) * G::SX + pp * 8;  // tap (0,0,0) corner; tapo[] adds the tap shift
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
+      const int ybase = (4 * q + qq) * G::SY + pp * 8;
+      const int xbase = (4 * q + qq) * G::SX + pp * 8;  // tap (0,0,0) corner; tapo[] adds the tap shift
+      bf16x8 a[2][COF], b[2][CIF];
+      auto read_a = [&](auto s_) {
+        constexpr int s = s_;
         const int yoff = ybase + (32 * s) * G::SY;
-        const int xoff = xbase + (((s >> 1) * G::HY + 4 * (s & 1)) * G::HX) * G::SX;
-        bf16x8 a[COF];
 #pragma unroll
-        for (int m = 0; m < COF; ++m) a[m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 4 * G::SY + m * 32);
+        for (int m = 0; m < COF; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
+      };
+      auto read_b = [&](auto u_) {
+        constexpr int u = u_;
+        constexpr int s = u / G::TPW, j = u % G::TPW;
+        const int xoff = xbase + (((s >> 1) * G::HY + 2 * (s & 1)) * G::HX) * G::SX + tapo[j];
 #pragma unroll
-        for (int j = 0; j < G::TPW; ++j) {
-          if (wave + 4 * j < 27) {
-#pragma unroll
-            for (int n = 0; n < CIF; ++n) {
-              const bf16x8 b = tr_pair(ldx + xoff + tapo[j] + n * 32, ldx + xoff + tapo[j] + 4 * G::SX + n * 32);
-#pragma unroll
-              for (int m = 0; m < COF; ++m) acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b, acc[j][m][n], 0, 0, 0);
-            }
-          }
+        for (int n = 0; n < CIF; ++n) b[u & 1][n] = tr_pair(ldx + xoff + n * 32, ldx + xoff + G::HX * G::SX + n * 32);
+      };
+      read_a(std::integral_constant<int, 0>{});
+      read_b(std::integral_constant<int, 0>{});
+      static_for<0, 8 * G::TPW>([&](auto u_) {
+        constexpr int u = u_;
+        constexpr int s = u / G::TPW, j = u % G::TPW;
+        if constexpr (u + 1 < 8 * G::TPW) {
+          read_b(std::integral_constant<int, u + 1>{});
+          if constexpr ((u + 1) % G::TPW == 0) read_a(std::integral_constant<int, (u + 1) / G::TPW>{});
         }
-      }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < CIF; ++n)
+#pragma unroll
+          for (int m = 0; m < COF; ++m)
+            acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u & 1][n], acc[j][m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     } else {
       // f32: k-step s' = voxels 4s'..4s'+3 of the flattened tile, quarter q -> voxel 4s'+q
-#pragma unroll 4
+#pragma unroll 2
       for (int s = 0; s < 64; ++s) {
         const int vx = 4 * s + q;
-        const int z = vx >> 6, y = (vx >> 3) & 7, x = vx & 7;
+        const int z = vx >> 6, y = (vx >> 4) & 3, x = vx & 15;
         const int yoff = vx * G::SY + v * 4;
         const int xoff = ((z * G::HY + y) * G::HX + x) * G::SX + v * 4;
         float a[COF];
@@ -167,13 +198,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
         for (int m = 0; m < COF; ++m) a[m] = *(const float*)(ldy + yoff + m * 64);
 #pragma unroll
         for (int j = 0; j < G::TPW; ++j) {
-          if (wave + 4 * j < 27) {
 #pragma unroll
-            for (int n = 0; n < CIF; ++n) {
-              const float b = *(const float*)(ldx + xoff + tapo[j] + n * 64);
+          for (int n = 0; n < CIF; ++n) {
+            const float b = *(const float*)(ldx + xoff + tapo[j] + n * 64);
 #pragma unroll
-              for (int m = 0; m < COF; ++m) acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[j][m][n], 0, 0, 0);
-            }
+            for (int m = 0; m < COF; ++m) acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[j][m][n], 0, 0, 0);
           }
         }
       }
