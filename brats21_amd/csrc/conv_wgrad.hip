@@ -230,16 +230,19 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
   }
 }
 
-// dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order)
+// dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order; 16-byte loads)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int cout, int cin) {
   const size_t per = (size_t)27 * cout * cin;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * per + i];
+  const size_t per4 = per / 4;  // cin % 4 == 0
+  for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < per4; i4 += (size_t)gridDim.x * blockDim.x) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(ws + (size_t)k * per + i4 * 4);
+    const size_t i = i4 * 4;
     const int ci = i % cin;
     const int co = (i / cin) % cout;
     const int tap = (int)(i / ((size_t)cin * cout));
-    dw[((size_t)co * cin + ci) * 27 + tap] = s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dw[((size_t)co * cin + ci + j) * 27 + tap] = s[j];
   }
 }
 
@@ -260,7 +263,7 @@ __global__ void dbias_kernel(const T* __restrict__ dy, int pitch, float* __restr
 }
 
 static int wgrad_nsplit(int ntiles, int cotiles, int citiles) {
-  int ns = ceil_div(512, cotiles * citiles);
+  int ns = ceil_div(256, cotiles * citiles);  // the kernel runs 1 workgroup per CU (acc in ~252 registers)
   if (ns > ntiles) ns = ntiles;
   if (ns < 1) ns = 1;
   return ns;
@@ -346,7 +349,7 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);
   if (rc) return rc;
   const size_t per = (size_t)27 * cout * p.cin;
-  size_t blocks = (per + 255) / 256;
+  size_t blocks = (per / 4 + 255) / 256;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, (const float*)ws, dw,
                      p.nsplit, cout, p.cin);
   if (dbias) {

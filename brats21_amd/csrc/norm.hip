@@ -5,21 +5,46 @@
 // group variance, x*sigmoid(x) numerator).
 #include "common.hpp"
 
-// ---- statistics finalize: one block per (n, group) ---------------------------------------------
-__global__ void gn_finalize_kernel(const float* __restrict__ stats, int tps, int C, int groups, double count_per_channel,
+// ---- statistics finalize ---------------------------------------------------------------------------
+// stage 1: chan[n][c] = sum over tiles of the conv epilogue's per-tile partials (f64), one block per
+// (n, 16-channel slab): 16 x 16 threads, coalesced 128-byte rows.  stage 2: one block per (n, group).
+__global__ void gn_chan_reduce_kernel(const float* __restrict__ stats, int tps, int C, double* __restrict__ chan) {
+  const int n = blockIdx.y, c0 = blockIdx.x * 16;
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int c = c0 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int t = tl; t < tps; t += 16) {
+      const f32x2 v = *(const f32x2*)(stats + (((size_t)n * tps + t) * C + c) * 2);
+      s1 += v[0];
+      s2 += v[1];
+    }
+  }
+  __shared__ double r1[256], r2[256];
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int m = 128; m >= 16; m >>= 1) {
+    if ((int)threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+    __syncthreads();
+  }
+  if (threadIdx.x < 16 && c < C) {
+    chan[((size_t)n * C + c) * 2] = r1[threadIdx.x];
+    chan[((size_t)n * C + c) * 2 + 1] = r2[threadIdx.x];
+  }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ chan, int C, int groups, double count_per_channel,
                                    float eps, int unbiased, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ mean_rstd, float* __restrict__ scale_shift) {
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cpg = C / groups;
-  double s1 = 0.0, s2 = 0.0;
-  const int items = tps * cpg;
-  for (int it = threadIdx.x; it < items; it += blockDim.x) {
-    const int t = it / cpg, j = it % cpg;
-    const f32x2 v = *(const f32x2*)(stats + (((size_t)n * tps + t) * C + g * cpg + j) * 2);
-    s1 += v[0];
-    s2 += v[1];
-  }
   __shared__ double r1[256], r2[256];
+  double s1 = 0.0, s2 = 0.0;
+  if ((int)threadIdx.x < cpg) {
+    s1 = chan[((size_t)n * C + g * cpg + threadIdx.x) * 2];
+    s2 = chan[((size_t)n * C + g * cpg + threadIdx.x) * 2 + 1];
+  }
   r1[threadIdx.x] = s1;
   r2[threadIdx.x] = s2;
   __syncthreads();
@@ -47,10 +72,11 @@ __global__ void gn_finalize_kernel(const float* __restrict__ stats, int tps, int
 
 extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
                                  double count_per_channel, float eps, const float* gamma, const float* beta,
-                                 float* mean_rstd, float* scale_shift, brats_stream_t s) {
-  if (!stats || !mean_rstd || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
+                                 float* mean_rstd, float* scale_shift, double* chan_ws, brats_stream_t s) {
+  if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
   if (scale_shift && (!gamma || !beta)) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: scale_shift needs gamma/beta");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, stats, tiles_per_sample, C, groups,
+  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N), dim3(256), 0, (hipStream_t)s, stats, tiles_per_sample, C, chan_ws);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, (const double*)chan_ws, C, groups,
                      count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift);
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -196,9 +196,10 @@ def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False):
 def gn_finalize(stats, n, c, groups, voxels, gamma, beta, eps=1e-5):
     mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)
     scale_shift = torch.empty((n, c, 2), dtype=torch.float32, device=stats.device)
+    chan = torch.empty((n, c, 2), dtype=torch.float64, device=stats.device)
     _lib.check(_lib.lib().brats_gn_finalize(stats.data_ptr(), stats.shape[1], n, c, groups, float(voxels), eps,
                                             _f32(gamma), _f32(beta), mean_rstd.data_ptr(), scale_shift.data_ptr(),
-                                            _stream()), "gn_finalize")
+                                            chan.data_ptr(), _stream()), "gn_finalize")
     return mean_rstd, scale_shift
 
 

@@ -80,7 +80,7 @@ int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c
 int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
                       double count_per_channel, float eps, const float* gamma, const float* beta,
                       float* mean_rstd /*[N][groups][2]*/, float* scale_shift /*[N][C][2]*/,
-                      brats_stream_t s);
+                      double* chan_ws /*[N][C][2] f64 workspace: per-channel sums*/, brats_stream_t s);
 int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
                          int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
