@@ -121,6 +121,26 @@ int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout,
                    void* dx, int dxpitch, float* dw, float* db, int dtype, int N, int C, int K,
                    int D, int H, int W, int scale, brats_stream_t s);
 
+/* ---- sliding-window inference on the GPU (utils/inferers.py:103-162; the reference stitches on
+ * the CPU, learning/engine.py:305-307).  NCDHW f32.  `windows` = device int32 [B][4] = (n, z, y, x)
+ * window origins in the *padded* image; pad_* = leading constant padding (inferers.py:103-109). */
+int brats_sw_gather(const float* src, float* dst, const int* windows, int B, int C, int D, int H, int W,
+                    int rd, int rh, int rw, int pad_z, int pad_y, int pad_x, float cval, brats_stream_t s);
+/* out[n][:, window] += importance * prob ; count[...] += importance (inferers.py:149-151) */
+int brats_sw_accumulate(const float* prob, const float* importance, float* out, float* count, int K,
+                        int Dp, int Hp, int Wp, int rd, int rh, int rw, int n, int z0, int y0, int x0,
+                        brats_stream_t s);
+/* dst = crop(out / count) (inferers.py:154-162) */
+int brats_sw_finalize(const float* out, const float* count, float* dst, int NK, int Dp, int Hp, int Wp,
+                      int D, int H, int W, int pad_z, int pad_y, int pad_x, brats_stream_t s);
+
+/* ---- test-time augmentation (tta/transforms.py:16-74,149-173): any chain of OnAxes permute, flips
+ * and rot90 is a signed permutation of the spatial axes.  dst axis a <- src axis p_a, reversed when
+ * f_a.  mode 0: dst = v; 1: dst += v; 2: dst += sigmoid(v) (the on-GPU running sum of
+ * learning/engine.py:239-249).  src dims (s0,s1,s2); `planes` = N*C. */
+int brats_spatial_signed_perm(const float* src, float* dst, int planes, int s0, int s1, int s2,
+                              int p0, int p1, int p2, int f0, int f1, int f2, int mode, brats_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

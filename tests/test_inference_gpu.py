@@ -1,0 +1,84 @@
+"""-m gpu: on-GPU sliding-window stitching and TTA against the golden vectors produced by the reference's
+utils/inferers.py / tta package, and end-to-end against the CPU oracle with the real network."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import inference as oinf
+from oracle import synth, unet
+
+pytestmark = pytest.mark.gpu
+
+
+def _analytic_predictor(dev):
+    w = synth.closed_form("swpred", (3, 4), 0.5).to(dev)
+
+    def predictor(p):
+        zz = torch.arange(p.shape[2], dtype=torch.float32, device=p.device).view(1, 1, -1, 1, 1) * 0.01
+        out = torch.einsum("oc,ncdhw->nodhw", w, p) + zz
+        return out, [out * 2]
+    return predictor
+
+
+def test_sliding_window_matches_reference_golden(golden_dir):
+    from brats21_amd.inferers import sliding_window_inference
+    g = np.load(os.path.join(golden_dir, "inference.npz"))
+    dev = torch.device("cuda:0")
+    x = synth.closed_form_image(1, 4, (20, 27, 17), "swx").to(dev)
+    pred = _analytic_predictor(dev)
+    for mode in ("constant", "gaussian"):
+        for ov in (0.25, 0.5):
+            y = sliding_window_inference(x, (16, 16, 16), 1, pred, overlap=ov, mode=mode)
+            np.testing.assert_allclose(y.cpu().numpy(), g[f"sw_{mode}_{int(ov * 100)}"], atol=2e-6)
+    y = sliding_window_inference(x[..., :12].contiguous(), (16, 16, 16), 2, pred, overlap=0.5)  # roi > image
+    np.testing.assert_allclose(y.cpu().numpy(), g["sw_pad"], atol=2e-6)
+    y = sliding_window_inference(x, (16, 16, 16), 4, pred, overlap=0.5, device=torch.device("cpu"))
+    assert y.device.type == "cpu"
+    np.testing.assert_allclose(y.numpy(), g["sw_constant_50"], atol=2e-6)
+    with pytest.raises(AssertionError):
+        sliding_window_inference(x, (16, 16, 16), 1, pred, overlap=1.0)
+
+
+def test_tta_kernels_match_reference_golden(golden_dir):
+    from brats21_amd import tta
+    g = np.load(os.path.join(golden_dir, "inference.npz"))
+    dev = torch.device("cuda:0")
+    comp = tta.Compose([tta.OnAxes(axes=["zxy", "xyz"]), tta.HorizontalFlip(), tta.Rotate90(angles=[0, 90, 180, 270])])
+    v = synth.closed_form("ttav", (1, 2, 4, 6, 6)).to(dev)
+    acc = torch.zeros_like(v)
+    for i, tr in enumerate(comp):
+        a = tr.augment_image(v)
+        np.testing.assert_array_equal(a.cpu().numpy().ravel(), g["tta_aug"][i])
+        np.testing.assert_array_equal(tr.deaugment_mask(a).cpu().numpy(), g["tta_roundtrip"][i])
+        tr.accumulate_probability(a, acc)
+    torch.testing.assert_close(acc / 16, torch.sigmoid(v), atol=1e-6, rtol=1e-6)
+
+
+def test_network_sliding_window_tta_graph_vs_oracle():
+    """EquiUnet w8 through hipGraph-captured patch steps, on-GPU stitching and 16-pass TTA vs the CPU oracle."""
+    from brats21_amd import get_model, tta
+    from brats21_amd.inferers import GraphedPredictor, sliding_window_inference, tta_predict
+    dev = torch.device("cuda:0")
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(8))
+    m = get_model(argparse.Namespace(model="equiunet", width=8, norm="group", act="relu", num_classes=3, dropout=0))
+    m.load_state_dict(sd)
+    m.precision = "fp32"
+    m = m.to(dev).eval()
+    m.skip_deep_heads_in_eval = True
+    x = synth.closed_form_image(1, 4, (24, 24, 24), "swnet")
+    ref_pred = lambda p: unet.equiunet_forward(sd, p)  # noqa: E731
+    with torch.no_grad():
+        y_ref = oinf.sliding_window_inference(x, (16, 16, 16), 1, ref_pred, overlap=0.5)
+        graphed = GraphedPredictor(m)
+        y = sliding_window_inference(x.to(dev), (16, 16, 16), 1, graphed, overlap=0.5)
+        assert len(graphed.graphs) == 1  # one capture, 8 replays
+        assert float((y.cpu() - y_ref).abs().max()) < 1e-3
+        # TTA on a cubic patch: 16 passes, probabilities averaged on the GPU
+        comp = tta.Compose([tta.OnAxes(axes=["zxy", "xyz"]), tta.HorizontalFlip(), tta.Rotate90(angles=[0, 90, 180, 270])])
+        xp = x[..., :16, :16, :16].contiguous()
+        p = tta_predict(xp.to(dev), graphed, comp)
+        p_ref = oinf.tta_predict(xp, ref_pred)
+        assert float((p.cpu() - p_ref).abs().max()) < 5e-4
