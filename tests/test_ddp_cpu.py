@@ -1,0 +1,92 @@
+"""-m "not gpu": the multi-GPU path (brats21_amd.ddp) on CPU with the gloo backend, world_size 2:
+bucketed gradient averaging (both the post-backward path and the in-backward push() path used by the
+accelerated models), bucket planning, patient sharding."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from brats21_amd.ddp import GradientBuckets, shard_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(6, 5)
+        self.b = nn.Linear(5, 3)
+        self.unused = nn.Parameter(torch.ones(4))  # statically unused, like EvoNorm `v`
+        self._grad_sink = None
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def _worker(rank, world, port, use_push, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _Net()  # identical initial weights on every rank (seeded inside)
+    torch.manual_seed(100 + rank)  # ... but a different data shard per rank
+    buckets = GradientBuckets(net, bucket_bytes=64)  # tiny buckets -> several all-reduces
+    out = []
+    for step in range(3):
+        x = torch.randn(4, 6)
+        net.zero_grad(set_to_none=True)
+        loss = net(x).pow(2).mean()
+        loss.backward()
+        local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        if use_push and step > 0:
+            # emulate the accelerated models: the backward program pushes finished gradients (reverse order)
+            for idx in reversed(range(len(local))):
+                if local[idx] is not None:
+                    net._grad_sink(idx, local[idx])
+        buckets.finish()
+        # reference: explicit all-reduce of the local gradients
+        for p, g in zip(net.parameters(), local):
+            if g is None:
+                assert p.grad is None
+                continue
+            dist.all_reduce(g)
+            torch.testing.assert_close(p.grad, g / world, atol=1e-7, rtol=1e-6)
+        out.append(float(loss.detach()))
+    assert len(buckets._plan) > 1 and buckets.payload_bytes() == 4 * sum(p.numel() for p in (net.a.weight, net.a.bias, net.b.weight, net.b.bias))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+@pytest.mark.parametrize("use_push", [False, True])
+def test_gradient_buckets_gloo_world2(use_push):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, use_push, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got[0][0] == 0 and got[1][0] == 1 and got[0][1] != got[1][1]  # different shards -> different losses
+
+
+def test_patient_sharding():
+    world = 8
+    shards = [shard_indices(21, r, world, epoch=3) for r in range(world)]
+    assert all(len(s) == 3 for s in shards)                        # ceil(21/8) each, ranks stay in step
+    assert set(i for s in shards for i in s) == set(range(21))     # every patient seen
+    assert shard_indices(21, 0, world, epoch=3) == shards[0]       # deterministic
+    assert shard_indices(21, 0, world, epoch=4) != shards[0]       # reshuffled per epoch
+    assert shard_indices(5, 1, 2, shuffle=False) == [1, 3, 0]      # wrap-around padding
