@@ -295,3 +295,329 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   BRATS_CHECK_LAUNCH();
   return 0;
 }
+
+// =================================================================================================
+// EvoNorm-S0 (networks/equiunet2021.py:95-103 with group_std :48-52):
+//     z = x*sigmoid(x) * rstd_g * gamma_c + beta_c,   rstd_g = 1/sqrt(var_unbiased(group) + eps)
+// Statistics come from the convolution epilogue like GroupNorm's; brats_evonorm_finalize only differs
+// in the unbiased variance.  `chansum` (optional) accumulates sum_v z per (n, c): the global average
+// pool of the following ResidualSELayer for free.
+// =================================================================================================
+extern "C" int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
+                                      double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
+                                      brats_stream_t s) {
+  if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "evonorm_finalize: bad argument");
+  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N), dim3(256), 0, (hipStream_t)s, stats, tiles_per_sample, C, chan_ws);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, (const double*)chan_ws, C, groups,
+                     count_per_channel, eps, 1, (const float*)nullptr, (const float*)nullptr, mean_rstd, (float*)nullptr);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+DEVI float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
+                                   int zpitch, float* __restrict__ chansum, int voxels, int C, int groups) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];  // sc[C] = rstd*gamma, be[C], then reduction scratch
+  float* sc = sm;
+  float* be = sm + C;
+  const int n = blockIdx.y, cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    sc[c] = mean_rstd[(n * groups + c / cpg) * 2 + 1] * gamma[c];
+    be[c] = beta[c];
+  }
+  __syncthreads();
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  float acc[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  if (myvl < vl_n) {
+    const T* xb = x + (size_t)n * voxels * xpitch;
+    T* zb = z + (size_t)n * voxels * zpitch;
+    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
+      float a[VW];
+      Vec<T, VW>::load(xb + vox * xpitch + c0, a);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        a[j] = a[j] * sigmoidf_(a[j]) * sc[c0 + j] + be[c0 + j];
+        acc[j] += a[j];
+      }
+      Vec<T, VW>::store(zb + vox * zpitch + c0, a);
+    }
+  }
+  if (chansum) {
+    float* scr = sm + 2 * C;  // [vl_n][C]
+    __syncthreads();
+    if (myvl < vl_n) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) scr[myvl * C + c0 + j] = acc[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float t = 0.f;
+      for (int l = 0; l < vl_n; ++l) t += scr[l * C + c];
+      atomicAdd(chansum + (size_t)n * C + c, t);
+    }
+  }
+}
+
+extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
+                                 void* z, int zpitch, float* chansum, int dtype, int N, int voxels, int C, int groups,
+                                 brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !z || !mean_rstd || !gamma || !beta || C % vw || C % groups || xpitch % vw || zpitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_fwd: bad argument (C, pitches multiples of %d)", vw);
+  hipStream_t st = (hipStream_t)s;
+  if (chansum) {
+    hipError_t e = hipMemsetAsync(chansum, 0, (size_t)N * C * sizeof(float), st);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "evonorm_fwd: memset: %s", hipGetErrorString(e));
+  }
+  const int cv = C / vw, vl = 256 / cv;
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  const size_t lds = (size_t)(2 * C + vl * C) * sizeof(float);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(evonorm_fwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
+                       (bf16_t*)z, zpitch, chansum, voxels, C, groups);
+  else
+    hipLaunchKernelGGL(evonorm_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, mean_rstd, gamma, beta,
+                       (float*)z, zpitch, chansum, voxels, C, groups);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward pass 1: red[n][c] = { sum_v dz, sum_v dz * x*sigmoid(x) }
+template <typename T>
+__global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
+                                          float* __restrict__ red, int voxels, int C) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];
+  const int n = blockIdx.y;
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  float a1[VW], a2[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) a1[j] = a2[j] = 0.f;
+  if (myvl < vl_n) {
+    const T* dzb = dz + (size_t)n * voxels * dzpitch;
+    const T* xb = x + (size_t)n * voxels * xpitch;
+    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
+      float g[VW], xx[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
+      Vec<T, VW>::load(xb + vox * xpitch + c0, xx);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        a1[j] += g[j];
+        a2[j] += g[j] * xx[j] * sigmoidf_(xx[j]);
+      }
+    }
+  }
+  float* scr = sm;  // [vl_n][C][2]
+  if (myvl < vl_n) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      scr[(myvl * C + c0 + j) * 2] = a1[j];
+      scr[(myvl * C + c0 + j) * 2 + 1] = a2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += scr[l * C * 2 + i];
+    atomicAdd(red + (size_t)n * C * 2 + i, t);
+  }
+}
+
+// pass 2: dx = dz*gamma*r*num'(x) - r^3 * A_g * (x - mean_g)/(M-1),  A_g = sum_{c in g} gamma_c * red[n][c][1]
+template <typename T>
+__global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
+                                         const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                         const float* __restrict__ red, T* __restrict__ dx, int dxpitch,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int voxels, int C,
+                                         int groups) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];
+  float* gr = sm;          // [C] gamma * r
+  float* mu = sm + C;      // [C] group mean
+  float* kk = sm + 2 * C;  // [C] r^3 * A_g / (M-1)
+  const int n = blockIdx.y, cpg = C / groups;
+  const float Mm1 = (float)cpg * (float)voxels - 1.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float r = mean_rstd[(n * groups + g) * 2 + 1];
+    float A = 0.f;
+    for (int j = 0; j < cpg; ++j) A += gamma[g * cpg + j] * red[((size_t)n * C + g * cpg + j) * 2 + 1];
+    gr[c] = gamma[c] * r;
+    mu[c] = mean_rstd[(n * groups + g) * 2];
+    kk[c] = r * r * r * A / Mm1;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float b = 0.f, g = 0.f;
+      for (int m = 0; m < N; ++m) {
+        b += red[((size_t)m * C + c) * 2];
+        g += red[((size_t)m * C + c) * 2 + 1] * mean_rstd[(m * groups + c / cpg) * 2 + 1];
+      }
+      dbeta[c] = b;
+      dgamma[c] = g;
+    }
+  }
+  __syncthreads();
+  const int cv = C / VW;
+  const size_t total = (size_t)voxels * cv;
+  const T* dzb = dz + (size_t)n * voxels * dzpitch;
+  const T* xb = x + (size_t)n * voxels * xpitch;
+  T* dxb = dx + (size_t)n * voxels * dxpitch;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const size_t vox = it / cv;
+    const int c0 = (int)(it % cv) * VW;
+    float g[VW], xx[VW], o[VW];
+    Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
+    Vec<T, VW>::load(xb + vox * xpitch + c0, xx);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int c = c0 + j;
+      const float sg = sigmoidf_(xx[j]);
+      const float dnum = sg * (1.f + xx[j] * (1.f - sg));
+      o[j] = g[j] * gr[c] * dnum - kk[c] * (xx[j] - mu[c]);
+    }
+    Vec<T, VW>::store(dxb + vox * dxpitch + c0, o);
+  }
+}
+
+extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
+                                 const float* gamma, void* dx, int dxpitch, float* red, float* dgamma, float* dbeta, int dtype,
+                                 int N, int voxels, int C, int groups, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dz || !x || !dx || !red || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: null pointer");
+  if (C % vw || C % groups || dzpitch % vw || xpitch % vw || dxpitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: C=%d / pitches must be multiples of %d", C, vw);
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * C * 2 * sizeof(float), st);
+  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "evonorm_bwd: memset: %s", hipGetErrorString(e));
+  const int cv = C / vw, vl = 256 / cv;
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
+  dim3 g2(stream_grid((size_t)voxels * cv, 256), N);
+  const size_t lds2 = (size_t)3 * C * sizeof(float);
+  if (dtype == BRATS_BF16) {
+    hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
+                       xpitch, red, voxels, C);
+    hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, N, voxels, C, groups);
+  } else {
+    hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)x,
+                       xpitch, red, voxels, C);
+    hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
+                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, N, voxels, C, groups);
+  }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// per-(n, channel) reduction over voxels: out[n][c] = sum_v a[v][c] * (b ? b[v][c] : 1)
+// (global average pool of the SE layer and its backward dot product)
+template <typename T>
+__global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T* __restrict__ b, int bpitch,
+                                   float* __restrict__ out, int voxels, int C) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];
+  const int n = blockIdx.y;
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  float acc[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  if (myvl < vl_n) {
+    const T* ab = a + (size_t)n * voxels * apitch;
+    const T* bb = b ? b + (size_t)n * voxels * bpitch : nullptr;
+    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
+      float x[VW], y[VW];
+      Vec<T, VW>::load(ab + vox * apitch + c0, x);
+      if (bb) {
+        Vec<T, VW>::load(bb + vox * bpitch + c0, y);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += x[j] * y[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += x[j];
+      }
+    }
+  }
+  if (myvl < vl_n) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) sm[myvl * C + c0 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += sm[l * C + c];
+    atomicAdd(out + (size_t)n * C + c, t);
+  }
+}
+
+extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int bpitch, float* out, int dtype, int N, int voxels,
+                                 int C, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!a || !out || C % vw || apitch % vw || (b && bpitch % vw) || C / vw > 256) BRATS_FAIL(BRATS_E_ARG, "channel_dot: bad argument");
+  hipStream_t st = (hipStream_t)s;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)N * C * sizeof(float), st);
+  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "channel_dot: memset: %s", hipGetErrorString(e));
+  const int cv = C / vw, vl = 256 / cv;
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  const size_t lds = (size_t)vl * C * sizeof(float);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(channel_dot_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)a, apitch, (const bf16_t*)b, bpitch, out, voxels, C);
+  else
+    hipLaunchKernelGGL(channel_dot_kernel<float>, grid, dim3(256), lds, st, (const float*)a, apitch, (const float*)b, bpitch, out, voxels, C);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst[v][c] = a[v][c]*sa[n][c] (+ b[v][c]*sb[n][c]) (+ add[n][c])  -- SE scale / residual and their backward
+template <typename T>
+__global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const float* __restrict__ sa, const float* __restrict__ add,
+                                     T* __restrict__ dst, int dpitch, int voxels, int C) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];  // sa[C], add[C]
+  const int n = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    sm[c] = sa[(size_t)n * C + c];
+    sm[C + c] = add ? add[(size_t)n * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int cv = C / VW;
+  const size_t total = (size_t)voxels * cv;
+  const T* ab = a + (size_t)n * voxels * apitch;
+  T* db = dst + (size_t)n * voxels * dpitch;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const size_t vox = it / cv;
+    const int c0 = (int)(it % cv) * VW;
+    float x[VW];
+    Vec<T, VW>::load(ab + vox * apitch + c0, x);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) x[j] = x[j] * sm[c0 + j] + sm[C + c0 + j];
+    Vec<T, VW>::store(db + vox * dpitch + c0, x);
+  }
+}
+
+extern "C" int brats_channel_scale(const void* a, int apitch, const float* scale, const float* add, void* dst, int dpitch,
+                                   int dtype, int N, int voxels, int C, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!a || !scale || !dst || C % vw || apitch % vw || dpitch % vw) BRATS_FAIL(BRATS_E_ARG, "channel_scale: bad argument");
+  dim3 grid(stream_grid((size_t)voxels * (C / vw), 256), N);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)a, apitch,
+                       scale, add, (bf16_t*)dst, dpitch, voxels, C);
+  else
+    hipLaunchKernelGGL(channel_scale_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)a, apitch,
+                       scale, add, (float*)dst, dpitch, voxels, C);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}

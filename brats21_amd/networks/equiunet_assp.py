@@ -1,0 +1,329 @@
+"""EquiUnetASSPEvo (EvoNorm-S0 + MaxAvgPool + ResidualSE + dilated ASPP head) on the HIP kernels.
+
+Drop-in for ``networks.equiunet2021.EquiUnetASSPEvo`` of the reference (networks/equiunet2021.py:225-333):
+same constructor signature (``norm_layer`` / ``act`` are accepted and ignored exactly like the reference
+does, :233), same ``state_dict`` keys / shapes -- including the statically unused EvoNorm ``v`` parameter
+and ``running_var`` buffer (:76-83) -- same ``forward(x) -> (logits, [deep3, deep2])`` contract.
+One autograd node; explicit forward / backward programs over NDHWC activations (see equiunet.py).
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import PACK_DGRAD, PACK_FWD, BratsHipError
+from .equiunet import _ConvParams
+
+
+# ------------------------------------------------------------------------------------------ parameter holders
+class EvoNorm3D(nn.Module):
+    """Parameters of networks/equiunet2021.py:55-118 (S0, affine, non_linear): gamma, beta, v + running_var."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(1, c, 1, 1, 1))
+        self.beta = nn.Parameter(torch.zeros(1, c, 1, 1, 1))
+        self.v = nn.Parameter(torch.ones(1, c, 1, 1, 1))  # unused on the efficient S0 path (:101-103)
+        self.register_buffer("running_var", torch.ones(1, c, 1, 1, 1))
+
+
+class _SEParams(nn.Module):
+    """MONAI ResidualSELayer(3, C, r=2) parameters: fc.0 / fc.2 Linear layers."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.fc = nn.ModuleList([nn.Linear(c, c // 2), nn.Identity(), nn.Linear(c // 2, c), nn.Identity()])
+
+
+class ConvEvoBlockCorrected(nn.Module):
+    """conv3+bias -> EvoNorm -> conv3+bias -> EvoNorm -> ResidualSE (networks/equiunet2021.py:192-209).
+    ``conv_conv_se`` is indexed like the reference's nn.Sequential (0,1,3,4,6; 2 and 5 are Dropout)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv_conv_se = nn.ModuleList([
+            _ConvParams(cin, cout, 3, True), EvoNorm3D(cout), nn.Identity(),
+            _ConvParams(cout, cout, 3, True), EvoNorm3D(cout), nn.Identity(), _SEParams(cout)])
+
+
+class ConvEvo(nn.Module):
+    """1x1x1 conv + bias -> EvoNorm (networks/equiunet2021.py:212-222)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _ConvParams(cin, cout, 1, True)
+        self.evo = EvoNorm3D(cout)
+
+
+class SimpleASPPEVO(nn.Module):
+    """networks/equiunet2021.py:121-189: four parallel convs (k1, k3 d2/d4/d6) -> cat -> ConvEvo 1x1."""
+
+    def __init__(self, cin, cout_each, kernel_sizes=(1, 3, 3, 3), dilations=(1, 2, 4, 6)):
+        super().__init__()
+        self.kernel_sizes, self.dilations = tuple(kernel_sizes), tuple(dilations)
+        self.convs = nn.ModuleList([_ConvParams(cin, cout_each, k, True) for k in kernel_sizes])
+        self.conv_k1 = ConvEvo(cout_each * len(kernel_sizes), cout_each * len(kernel_sizes))
+
+
+# ------------------------------------------------------------------------------------------ unit programs
+def _flat(p):
+    return p.detach().reshape(-1).contiguous()
+
+
+class _Ctx:
+    """Per-forward state shared by the unit programs."""
+
+    def __init__(self, model, dtype):
+        self.m, self.dtype = model, dtype
+        self.names = {p: i for i, p in enumerate(model.parameters())}
+        self.grads = {}
+
+    def put(self, param, grad):
+        i = self.names[param]
+        self.grads[i] = grad.reshape(param.shape)
+        if self.m._grad_sink is not None:
+            self.m._grad_sink(i, self.grads[i])
+
+
+def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
+    """conv (3x3x3 any dilation or 1x1x1) + bias.  Returns (y, stats, saved) with what backward needs."""
+    w = conv.weight
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    if k == 3 and dil > 2:  # halo too large for LDS: im2col + 1x1 implicit GEMM over 27*C channels
+        col = ops.im2col3(x, dil)
+        w1 = w.detach().permute(0, 2, 3, 4, 1).reshape(cout, 27 * cin, 1, 1, 1)
+        wpk = ops.pack_weights(w1, cx.dtype, PACK_FWD)
+        y, stats = ops.conv3d(col, wpk, cout, 1, 1, bias=_flat(conv.bias), out=out, want_stats=want_stats)
+        return y, stats, ("col", col, dil)
+    wpk = ops.pack_weights(w, cx.dtype, PACK_FWD, cin_pad=x.shape[-1], dil=dil)
+    y, stats = ops.conv3d(x, wpk, cout, k, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
+    return y, stats, ("direct", x, dil)
+
+
+def _conv_any_bwd(cx, conv, saved, dy, need_dx=True):
+    kind, xin, dil = saved
+    w = conv.weight
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    db = ops.channel_dot(dy).sum(0)
+    if kind == "col":
+        dw1 = ops.wgrad_1x1(xin, dy)  # [cout, 27*cin] in (tap, ci) order
+        cx.put(conv.weight, dw1.view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3).contiguous())
+        cx.put(conv.bias, db)
+        if not need_dx:
+            return None
+        w1 = w.detach().permute(0, 2, 3, 4, 1).reshape(cout, 27 * cin, 1, 1, 1)
+        dcol, _ = ops.conv3d(dy, ops.pack_weights(w1, cx.dtype, PACK_DGRAD), 27 * cin, 1, 1)
+        return ops.col2im3(dcol, cin, dil)
+    if k == 1:
+        cx.put(conv.weight, ops.wgrad_1x1(xin, dy))
+    else:
+        dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil)
+        cx.put(conv.weight, dw[:, :cin].contiguous() if dw.shape[1] != cin else dw)
+    cx.put(conv.bias, db)
+    if not need_dx:
+        return None
+    dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil)
+    return dx
+
+
+def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
+    y, stats, saved = _conv_any_fwd(cx, conv, x, 1, True)
+    n, d, h, w, c = y.shape
+    mr = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
+    z, cs = ops.evonorm(y, mr, _flat(evo.gamma), _flat(evo.beta), 8, out=out, want_chansum=want_chansum)
+    return z, cs, (conv, evo, saved, y, mr)
+
+
+def _conv_evo_bwd(cx, rec, dz, need_dx=True):
+    conv, evo, saved, y, mr = rec
+    dy, dgamma, dbeta = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8)
+    cx.put(evo.gamma, dgamma)
+    cx.put(evo.beta, dbeta)
+    return _conv_any_bwd(cx, conv, saved, dy, need_dx)
+
+
+def _block_fwd(cx, blk, x, out=None):
+    s = blk.conv_conv_se
+    z1, _, r1 = _conv_evo_fwd(cx, s[0], s[1], x)
+    z2, cs, r2 = _conv_evo_fwd(cx, s[3], s[4], z1, want_chansum=True)
+    # ResidualSELayer: out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2); the two FCs are [N, C] GEMVs -> torch
+    n, d, h, w, c = z2.shape
+    fc1, fc2 = s[6].fc[0], s[6].fc[2]
+    with torch.enable_grad(), torch.autocast("cuda", enabled=False):  # [N, C] GEMVs stay f32
+        gap = (cs / float(d * h * w)).detach().requires_grad_(True)
+        gate = torch.sigmoid(F.linear(F.relu(F.linear(gap, fc1.weight, fc1.bias)), fc2.weight, fc2.bias))
+    o = ops.channel_scale(z2, (1.0 + gate.detach()), out=out)
+    return o, (blk, r1, r2, z2, gap, gate)
+
+
+def _block_bwd(cx, rec, do, need_dx=True):
+    blk, r1, r2, z2, gap, gate = rec
+    s = blk.conv_conv_se
+    fc1, fc2 = s[6].fc[0], s[6].fc[2]
+    n, d, h, w, c = z2.shape
+    dgate = ops.channel_dot(do, z2)  # [N, C] = sum_v do * z2
+    dgap, dw1, db1, dw2, db2 = torch.autograd.grad(gate, [gap, fc1.weight, fc1.bias, fc2.weight, fc2.bias], dgate)
+    for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2)):
+        cx.put(prm, g)
+    dz2 = ops.channel_scale(do, 1.0 + gate.detach(), add=dgap / float(d * h * w))
+    dz1 = _conv_evo_bwd(cx, r2, dz2)
+    return _conv_evo_bwd(cx, r1, dz1, need_dx)
+
+
+class _AsspFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, dtype, *params):
+        m = model
+        f = m.features
+        cx = _Ctx(m, dtype)
+        n, _, d, h, w = x.shape
+        dev = x.device
+        h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
+        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
+        # encoder (networks/equiunet2021.py:291-298)
+        down1, rb1 = _block_fwd(cx, m.encoder1, x0)
+        down2, rb2 = _block_fwd(cx, m.encoder2, ops.maxpool2(down1, with_avg=True))
+        down3, rb3 = _block_fwd(cx, m.encoder3, ops.maxpool2(down2, with_avg=True))
+        down4, rb4 = _block_fwd(cx, m.encoder4, ops.maxpool2(down3, with_avg=True))
+        # ASPP (:299, :187-189): the four branches write into channel slices of one buffer
+        q4 = f[3] // 4
+        acat = ops.new_act(n, d // 8, h // 8, w // 8, f[3], dtype, dev)
+        ra = []
+        for i, (k, dl) in enumerate(zip(m.aspp.kernel_sizes, m.aspp.dilations)):
+            _, _, sv = _conv_any_fwd(cx, m.aspp.convs[i], down4, dl, False, out=acat[..., i * q4:(i + 1) * q4])
+            ra.append(sv)
+        assp, _, rk1 = _conv_evo_fwd(cx, m.aspp.conv_k1.conv, m.aspp.conv_k1.evo, acat)
+        # bridges (:302-304) and decoder (:306-320): bridge / up-sample outputs land in concat buffers
+        cat1 = ops.new_act(n, d, h, w, 2 * h0, dtype, dev)
+        cat2 = ops.new_act(n, d // 2, h // 2, w // 2, 2 * h1, dtype, dev)
+        cat3 = ops.new_act(n, d // 4, h // 4, w // 4, 2 * h2, dtype, dev)
+        _, _, rbr1 = _conv_evo_fwd(cx, m.bridge1.conv, m.bridge1.evo, down1, out=cat1[..., :h0])
+        _, _, rbr2 = _conv_evo_fwd(cx, m.bridge2.conv, m.bridge2.evo, down2, out=cat2[..., :h1])
+        _, _, rbr3 = _conv_evo_fwd(cx, m.bridge3.conv, m.bridge3.evo, down3, out=cat3[..., :h2])
+        uc3, _, ru3 = _conv_evo_fwd(cx, m.upconv3.conv, m.upconv3.evo, assp)
+        ops.upsample(uc3, 2, out=cat3[..., h2:])
+        up3, rd3 = _block_fwd(cx, m.decoder3, cat3)
+        uc2, _, ru2 = _conv_evo_fwd(cx, m.upconv2.conv, m.upconv2.evo, up3)
+        ops.upsample(uc2, 2, out=cat2[..., h1:])
+        up2, rd2 = _block_fwd(cx, m.decoder2, cat2)
+        uc1, _, ru1 = _conv_evo_fwd(cx, m.upconv1.conv, m.upconv1.evo, up2)
+        ops.upsample(uc1, 2, out=cat1[..., h0:])
+        up1, rd1 = _block_fwd(cx, m.decoder1, cat1)
+        outs = [ops.head(up1, m.out_conv.weight, m.out_conv.bias, 1)]
+        heads = [(m.out_conv, up1, 1)]
+        if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
+            for hd, src, sc in ((m.deep3[0], up3, 4), (m.deep2[0], up2, 2)):
+                outs.append(ops.head(src, hd.weight, hd.bias, sc))
+                heads.append((hd, src, sc))
+        ctx.cx, ctx.heads, ctx.nparams = cx, heads, len(params)
+        ctx.recs = dict(rb1=rb1, rb2=rb2, rb3=rb3, rb4=rb4, ra=ra, rk1=rk1, rbr1=rbr1, rbr2=rbr2, rbr3=rbr3, ru3=ru3,
+                        ru2=ru2, ru1=ru1, rd3=rd3, rd2=rd2, rd1=rd1)
+        ctx.bufs = (down1, down2, down3, up3, up2, up1)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        cx, R = ctx.cx, ctx.recs
+        m = cx.m
+        f = m.features
+        h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
+        down1, down2, down3, up3, up2, up1 = ctx.bufs
+        dsrc = {}
+        for (hd, src, sc), dout in zip(ctx.heads, douts):
+            if dout is None:
+                continue
+            dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
+            cx.put(hd.weight, dw)
+            cx.put(hd.bias, db)
+            dsrc[src.data_ptr()] = dx
+
+        def plus(a, t):
+            b = dsrc.get(t.data_ptr())
+            return a if b is None else a + b
+
+        dcat1 = _block_bwd(cx, R["rd1"], dsrc[up1.data_ptr()])
+        d_up2 = plus(_conv_evo_bwd(cx, R["ru1"], ops.upsample_bwd(dcat1[..., h0:], 2)), up2)
+        dcat2 = _block_bwd(cx, R["rd2"], d_up2)
+        d_up3 = plus(_conv_evo_bwd(cx, R["ru2"], ops.upsample_bwd(dcat2[..., h1:], 2)), up3)
+        dcat3 = _block_bwd(cx, R["rd3"], d_up3)
+        d_assp = _conv_evo_bwd(cx, R["ru3"], ops.upsample_bwd(dcat3[..., h2:], 2))
+        d_acat = _conv_evo_bwd(cx, R["rk1"], d_assp)
+        q4 = f[3] // 4
+        d_down4 = None
+        for i in range(len(m.aspp.convs)):
+            dxi = _conv_any_bwd(cx, m.aspp.convs[i], R["ra"][i], d_acat[..., i * q4:(i + 1) * q4])
+            d_down4 = dxi if d_down4 is None else d_down4 + dxi
+        d_p3 = _block_bwd(cx, R["rb4"], d_down4)
+        d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=_conv_evo_bwd(cx, R["rbr3"], dcat3[..., :h2]), with_avg=True)
+        d_p2 = _block_bwd(cx, R["rb3"], d_down3)
+        d_down2 = ops.maxpool2_bwd(down2, d_p2, dx_skip=_conv_evo_bwd(cx, R["rbr2"], dcat2[..., :h1]), with_avg=True)
+        d_p1 = _block_bwd(cx, R["rb2"], d_down2)
+        d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=_conv_evo_bwd(cx, R["rbr1"], dcat1[..., :h0]), with_avg=True)
+        _block_bwd(cx, R["rb1"], d_down1, need_dx=False)
+        grads = cx.grads
+        ctx.recs = ctx.bufs = ctx.cx = None
+        return (None, None, None) + tuple(grads.get(i) for i in range(ctx.nparams))
+
+
+# ------------------------------------------------------------------------------------------ module
+class EquiUnetASSPEvo(nn.Module):
+    """Constructor signature of networks/equiunet2021.py:230-231."""
+    name = "EquiUnetASSPEvo"
+
+    def __init__(self, inplanes, num_classes, features, norm_layer=None, act="relu", deep_supervision=False, dropout=0,
+                 refinement=False):
+        super().__init__()
+        warnings.warn("norm layer and activation specified will not be used ! only EVO !!")
+        if dropout:
+            raise NotImplementedError("dropout > 0 is not implemented (the published configs use 0)")
+        if refinement:
+            raise NotImplementedError("equiunet_assp_evo_ref raises AttributeError in the reference too (SURVEY App. B)")
+        if inplanes != 4 or num_classes > 4 or any(c % 16 for c in features):
+            raise NotImplementedError("EquiUnetASSPEvo needs inplanes=4, num_classes<=4, widths multiple of 16 (F10)")
+        print(f"EquiUnetASSP features: {features}")
+        self.deep_supervision = deep_supervision
+        self.act = act.upper()
+        self.features = list(features)
+        self.precision = "auto"
+        self.skip_deep_heads_in_eval = False
+        self._grad_sink = None
+        f = self.features
+        self.encoder1 = ConvEvoBlockCorrected(inplanes, f[0])
+        self.encoder2 = ConvEvoBlockCorrected(2 * f[0], f[1])
+        self.encoder3 = ConvEvoBlockCorrected(2 * f[1], f[2])
+        self.encoder4 = ConvEvoBlockCorrected(2 * f[2], f[3])
+        self.bridge1 = ConvEvo(f[0], f[0] // 2)
+        self.bridge2 = ConvEvo(f[1], f[1] // 2)
+        self.bridge3 = ConvEvo(f[2], f[2] // 2)
+        self.aspp = SimpleASPPEVO(f[3], f[3] // 4)
+        self.upconv3 = ConvEvo(f[3], f[3] // 4)
+        self.decoder3 = ConvEvoBlockCorrected(f[2], f[2])
+        self.upconv2 = ConvEvo(f[2], f[2] // 4)
+        self.decoder2 = ConvEvoBlockCorrected(f[1], f[1])
+        self.upconv1 = ConvEvo(f[1], f[1] // 4)
+        self.decoder1 = ConvEvoBlockCorrected(f[0], f[0])
+        self.out_conv = _ConvParams(f[0], num_classes, 1, bias=True)
+        if deep_supervision:
+            self.deep3 = nn.ModuleList([_ConvParams(f[2], num_classes, 1, bias=True)])
+            self.deep2 = nn.ModuleList([_ConvParams(f[1], num_classes, 1, bias=True)])
+        # (the reference leaves torch's default init here: init_weights is commented out, :287)
+
+    def _dtype(self):
+        if self.precision == "bf16":
+            return torch.bfloat16
+        if self.precision == "fp32":
+            return torch.float32
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise BratsHipError("brats21_amd.EquiUnetASSPEvo runs on the GPU only (no CPU fallback)")
+        if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
+            raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
+        outs = _AsspFn.apply(self, x.float(), self._dtype(), *tuple(self.parameters()))
+        if self.deep_supervision:
+            return outs[0], list(outs[1:])
+        return outs[0]

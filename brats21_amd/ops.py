@@ -310,3 +310,99 @@ def head_bwd(x, weight, dout, scale=1, want_dx=True):
                                          dx.data_ptr() if dx is not None else None, c, dw.data_ptr(), db.data_ptr(),
                                          _code(x.dtype), n, c, k, d, h, w, scale, _stream()), "head_bwd")
     return dx, dw.reshape(k, c, 1, 1, 1), db
+
+
+# ------------------------------------------------------------------------------------------ EvoNorm-S0 / SE helpers
+def evonorm_finalize(stats, n, c, groups, voxels, eps=1e-5):
+    mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)
+    chan = torch.empty((n, c, 2), dtype=torch.float64, device=stats.device)
+    _lib.check(_lib.lib().brats_evonorm_finalize(stats.data_ptr(), stats.shape[1], n, c, groups, float(voxels), eps,
+                                                 mean_rstd.data_ptr(), chan.data_ptr(), _stream()), "evonorm_finalize")
+    return mean_rstd
+
+
+def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False):
+    """z = y*sigmoid(y) * rstd_g * gamma + beta; optionally also sum_v z per (n, c) (SE's pooling)."""
+    ptr, c, p = _desc(y)
+    n, d, h, w, _ = y.shape
+    if out is None:
+        out = new_act(n, d, h, w, c, y.dtype, y.device)
+    optr, _, op = _desc(out)
+    cs = torch.empty((n, c), dtype=torch.float32, device=y.device) if want_chansum else None
+    _lib.check(_lib.lib().brats_evonorm_fwd(ptr, p, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), optr, op,
+                                            cs.data_ptr() if cs is not None else None, _code(y.dtype), n, d * h * w, c,
+                                            groups, _stream()), "evonorm_fwd")
+    return out, cs
+
+
+def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8):
+    dzp, c, dzpitch = _desc(dz)
+    yp, _, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    dy = new_act(n, d, h, w, c, y.dtype, y.device)
+    red = torch.empty((n, c, 2), dtype=torch.float32, device=y.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().brats_evonorm_bwd(dzp, dzpitch, yp, ypitch, mean_rstd.data_ptr(), _f32(gamma), dy.data_ptr(), c,
+                                            red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _code(y.dtype), n,
+                                            d * h * w, c, groups, _stream()), "evonorm_bwd")
+    return dy, dgamma, dbeta
+
+
+def channel_dot(a, b=None):
+    """[N, C] f32 = sum over voxels of a (* b)."""
+    ap, c, apitch = _desc(a)
+    bp, bpitch = (None, 0)
+    if b is not None:
+        bp, _, bpitch = _desc(b)
+    n, d, h, w, _ = a.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().brats_channel_dot(ap, apitch, bp, bpitch, out.data_ptr(), _code(a.dtype), n, d * h * w, c,
+                                            _stream()), "channel_dot")
+    return out
+
+
+def channel_scale(a, scale, add=None, out=None):
+    """out[v][c] = a[v][c] * scale[n][c] (+ add[n][c])."""
+    ap, c, apitch = _desc(a)
+    n, d, h, w, _ = a.shape
+    if out is None:
+        out = new_act(n, d, h, w, c, a.dtype, a.device)
+    optr, _, op = _desc(out)
+    _lib.check(_lib.lib().brats_channel_scale(ap, apitch, _f32(scale.contiguous()), _f32(add.contiguous()) if add is not None else None,
+                                              optr, op, _code(a.dtype), n, d * h * w, c, _stream()), "channel_scale")
+    return out
+
+
+def im2col3(x, dil):
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    col = new_act(n, d, h, w, 27 * c, x.dtype, x.device)
+    _lib.check(_lib.lib().brats_im2col3(ptr, p, col.data_ptr(), _code(x.dtype), n, c, d, h, w, dil, _stream()), "im2col3")
+    return col
+
+
+def col2im3(dcol, c, dil):
+    n, d, h, w, _ = dcol.shape
+    dx = new_act(n, d, h, w, c, dcol.dtype, dcol.device)
+    _lib.check(_lib.lib().brats_col2im3(dcol.data_ptr(), dx.data_ptr(), c, _code(dcol.dtype), n, c, d, h, w, dil, _stream()),
+               "col2im3")
+    return dx
+
+
+def wgrad_1x1(x, dy):
+    """dW [cout, cin] f32 of a 1x1x1 conv: a plain GEMM dy^T @ x over the voxels -> library GEMM
+    (rocBLAS through torch.matmul; the design rules reserve hand-written MFMA for the fused hot ops)."""
+    c, co = x.shape[-1], dy.shape[-1]
+    x2 = x.reshape(-1, c) if x.is_contiguous() else x.contiguous().reshape(-1, c)
+    d2 = dy.reshape(-1, co) if dy.is_contiguous() else dy.contiguous().reshape(-1, co)
+    if x2.dtype == torch.float32:
+        return torch.matmul(d2.t(), x2)
+    # bf16: split the voxel axis so each GEMM output (rounded to bf16 by the library) sums few voxels,
+    # then add the slabs in f32
+    v = x2.shape[0]
+    s = 64
+    while v % s:
+        s //= 2
+    part = torch.bmm(d2.view(s, v // s, co).transpose(1, 2), x2.view(s, v // s, c))
+    return part.float().sum(0)

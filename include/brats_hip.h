@@ -92,6 +92,33 @@ int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, con
                      int dtype, int act, float slope, int N, int voxels, int C, int groups,
                      brats_stream_t s);
 
+/* ---- EvoNorm-S0 (EvoNorm3D networks/equiunet2021.py:55-118, group_std :48-52; groups = 8) ---------
+ * z = x*sigmoid(x) * rstd_g * gamma_c + beta_c with the UNBIASED group variance.  `stats` are the
+ * conv epilogue's tile partials; mean_rstd [N][groups][2].  chansum (may be NULL) [N][C] receives
+ * sum_v z = the global-average-pool numerator of the following ResidualSELayer (:204-205). */
+int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
+                           double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
+                           brats_stream_t s);
+int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma,
+                      const float* beta, void* z, int zpitch, float* chansum, int dtype, int N,
+                      int voxels, int C, int groups, brats_stream_t s);
+int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
+                      const float* gamma, void* dx, int dxpitch, float* red /*[N][C][2]*/,
+                      float* dgamma, float* dbeta, int dtype, int N, int voxels, int C, int groups,
+                      brats_stream_t s);
+/* ---- squeeze-excite helpers (MONAI ResidualSELayer, equiunet2021.py:204-205): per-(n,channel)
+ * reductions over voxels and per-(n,channel) scale(+add) passes; the two tiny FC layers stay in torch. */
+int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,
+                      int dtype, int N, int voxels, int C, brats_stream_t s);
+int brats_channel_scale(const void* a, int apitch, const float* scale /*[N][C]*/, const float* add /*[N][C] or NULL*/,
+                        void* dst, int dpitch, int dtype, int N, int voxels, int C, brats_stream_t s);
+/* ---- im2col / col2im for dilations whose halo does not fit LDS (ASPP d = 4, 6, equiunet2021.py:257-259):
+ * col [N][D*H*W][27*C] dense; the dilated conv becomes brats_conv3d_fwd(ksize = 1) over 27*C channels. */
+int brats_im2col3(const void* x, int xpitch, void* col, int dtype, int N, int C, int D, int H, int W,
+                  int dil, brats_stream_t s);
+int brats_col2im3(const void* dcol, void* dx, int dxpitch, int dtype, int N, int C, int D, int H, int W,
+                  int dil, brats_stream_t s);
+
 /* ---- pooling (nn.MaxPool3d(2,2) equiunet2020.py:433; MONAI MaxAvgPool equiunet2021.py:261) ---- */
 int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C,
                        int D, int H, int W, int with_avg, brats_stream_t s);
