@@ -28,17 +28,21 @@ def conv_flops(cin, cout, k, n, d, h, w):
     return 2.0 * cin * k ** 3 * cout * n * d * h * w
 
 
-def cpu_baseline(width, threads):
+def cpu_baseline(width, cores):
     """The CPU oracle (plain torch fp32 restatement of the reference's CPU path, oracle/unet.py) on a
     bounded sample: ONE 4x64^3 patch (1/8 of the voxels of a 4x128^3 patch), forward + Dice loss +
-    backward, 1 warm-up + 2 timed repetitions.  Reported in the metric's unit (128^3-patches/s)."""
+    backward, 1 warm-up + 5 timed repetitions, median.  Reported in the metric's unit (128^3-patches/s).
+    Threads: torch/mkldnn 3D convolutions scale to ~16 threads on this host and get SLOWER beyond
+    (measured on the GPU box, scripts/cpu_threads.py: 8 thr 0.14 s, 16 thr 0.10 s, 32 thr 0.15 s,
+    64 thr 0.43 s, 128 thr 2.1 s per 32^3 patch), so the baseline uses min(16, cores) threads."""
     from oracle import synth as osynth, unet
+    threads = min(16, cores)
     torch.set_num_threads(threads)
     size = (64, 64, 64)
     sd = {k: v.requires_grad_(True) for k, v in osynth.fill_state_dict(unet.equiunet_state_shapes(width)).items()}
     x, t = osynth.random_image(1, 4, size), osynth.nested_spheres(1, size)
     times = []
-    for it in range(3):
+    for it in range(6):
         t0 = time.perf_counter()
         loss = unet.deep_supervision_loss(unet.equiunet_forward(sd, x), t)
         loss.backward()
@@ -47,8 +51,9 @@ def cpu_baseline(width, threads):
         if it:
             times.append(time.perf_counter() - t0)
     sec = sorted(times)[len(times) // 2]
-    return {"value": (1.0 / 8.0) / sec, "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"1 patch of 4x64^3 (=1/8 of a 4x128^3 patch), fwd+loss+bwd fp32, median of 2: {sec:.2f} s"}
+    return {"value": round((1.0 / 8.0) / sec, 5), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"1 patch of 4x64^3 (=1/8 of a 4x128^3 patch), fwd+Dice+bwd fp32 torch CPU, median of 5: {sec:.2f} s; "
+                      f"host has {cores} cores, {threads} threads used (fastest setting)"}
 
 
 def main():

@@ -9,12 +9,15 @@
 // stage 1: chan[n][c] = sum over tiles of the conv epilogue's per-tile partials (f64), one block per
 // (n, 16-channel slab): 16 x 16 threads, coalesced 128-byte rows.  stage 2: one block per (n, group).
 __global__ void gn_chan_reduce_kernel(const float* __restrict__ stats, int tps, int C, double* __restrict__ chan) {
+  // grid (C/16, N, splits): each block reduces a slice of the tiles and adds it to chan (zeroed by the caller)
   const int n = blockIdx.y, c0 = blockIdx.x * 16;
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int c = c0 + cl;
+  const int per = (tps + gridDim.z - 1) / gridDim.z;
+  const int t0 = blockIdx.z * per, t1 = min(tps, t0 + per);
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int t = tl; t < tps; t += 16) {
+    for (int t = t0 + tl; t < t1; t += 16) {
       const f32x2 v = *(const f32x2*)(stats + (((size_t)n * tps + t) * C + c) * 2);
       s1 += v[0];
       s2 += v[1];
@@ -29,9 +32,18 @@ __global__ void gn_chan_reduce_kernel(const float* __restrict__ stats, int tps, 
     __syncthreads();
   }
   if (threadIdx.x < 16 && c < C) {
-    chan[((size_t)n * C + c) * 2] = r1[threadIdx.x];
-    chan[((size_t)n * C + c) * 2 + 1] = r2[threadIdx.x];
+    atomicAdd(chan + ((size_t)n * C + c) * 2, r1[threadIdx.x]);
+    atomicAdd(chan + ((size_t)n * C + c) * 2 + 1, r2[threadIdx.x]);
   }
+}
+
+static int chan_reduce_launch(const float* stats, int tps, int N, int C, double* chan_ws, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(chan_ws, 0, (size_t)N * C * 2 * sizeof(double), st);
+  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "chan_reduce: memset: %s", hipGetErrorString(e));
+  int splits = tps / 64;
+  splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, splits), dim3(256), 0, st, stats, tps, C, chan_ws);
+  return 0;
 }
 
 __global__ void gn_finalize_kernel(const double* __restrict__ chan, int C, int groups, double count_per_channel,
@@ -75,7 +87,7 @@ extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N
                                  float* mean_rstd, float* scale_shift, double* chan_ws, brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
   if (scale_shift && (!gamma || !beta)) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: scale_shift needs gamma/beta");
-  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N), dim3(256), 0, (hipStream_t)s, stats, tiles_per_sample, C, chan_ws);
+  if (int rc = chan_reduce_launch(stats, tiles_per_sample, N, C, chan_ws, (hipStream_t)s)) return rc;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, (const double*)chan_ws, C, groups,
                      count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift);
   BRATS_CHECK_LAUNCH();
@@ -307,7 +319,7 @@ extern "C" int brats_evonorm_finalize(const float* stats, int tiles_per_sample, 
                                       double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
                                       brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "evonorm_finalize: bad argument");
-  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N), dim3(256), 0, (hipStream_t)s, stats, tiles_per_sample, C, chan_ws);
+  if (int rc = chan_reduce_launch(stats, tiles_per_sample, N, C, chan_ws, (hipStream_t)s)) return rc;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, (const double*)chan_ws, C, groups,
                      count_per_channel, eps, 1, (const float*)nullptr, (const float*)nullptr, mean_rstd, (float*)nullptr);
   BRATS_CHECK_LAUNCH();

@@ -113,11 +113,21 @@ def test_equiunet_autocast_selects_bf16_and_width48_runs():
     assert out_b.dtype == torch.float32
     assert float((out_b.detach().cpu().double() - out_ref[0].detach()).abs().max()) < 0.25
     assert abs(loss_b.item() - loss_ref.item()) < 5e-3
-    worst = 0.0
+    # yardstick for "what bf16 storage costs": torch's own CPU bf16 autocast of the oracle on the same
+    # inputs (measured here: median 4-9 %, worst 24-27 % relative gradient error vs f64 -- far-from-loss
+    # encoder gradients carry the most rounding noise).  The HIP bf16 path must be in that league.
+    sd_b = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        out_c = unet.equiunet_forward(sd_b, x)
+    unet.deep_supervision_loss(out_c, t).backward()
+    e_hip, e_ref = [], []
     for k, p in m.named_parameters():
         ref = sd_ref[k].grad
-        worst = max(worst, float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30)))
-    assert worst < 0.12, worst  # bf16 activations + bf16 gradients end to end
+        e_hip.append(float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-30)))
+        e_ref.append(float((sd_b[k].grad.double() - ref).norm() / (ref.norm() + 1e-30)))
+    med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+    assert med(e_hip) <= 1.5 * med(e_ref) + 0.02, (med(e_hip), med(e_ref))
+    assert max(e_hip) <= 1.5 * max(e_ref) + 0.05, (max(e_hip), max(e_ref))
 
 
 def test_cpu_input_fails_loudly():
