@@ -67,13 +67,15 @@ def main():
     ap.add_argument("--model", default="equiunet")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-dice", dest="fused_dice", action="store_false",
+                    help="use the PyTorch Dice loss (reference path) instead of the fused HIP Dice passes")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
     args = ap.parse_args()
 
     from brats21_amd import get_model, ops, LIB_PATH
     from brats21_amd import synth
     from brats21_amd.ddp import GradientBuckets, init_process_group_from_env
-    from brats21_amd.losses import DiceLoss, deep_supervision_loss
+    from brats21_amd.losses import DiceLoss, deep_supervision_loss, fused_deep_supervision_dice
 
     assert os.path.exists(LIB_PATH), "HIP extension missing"
     rank, world, local = init_process_group_from_env()
@@ -97,7 +99,7 @@ def main():
         model.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
             out = model(x)
-            loss, _ = deep_supervision_loss(crit, out, t)
+            loss = fused_deep_supervision_dice(out, t) if args.fused_dice else deep_supervision_loss(crit, out, t)[0]
         loss.backward()
         if buckets is not None:
             buckets.finish()

@@ -168,6 +168,14 @@ int brats_sw_finalize(const float* out, const float* count, float* dst, int NK, 
 int brats_spatial_signed_perm(const float* src, float* dst, int planes, int s0, int s1, int s2,
                               int p0, int p1, int p2, int f0, int f1, int f2, int mode, brats_stream_t s);
 
+/* ---- fused sigmoid-Dice / Jaccard passes (semantics of monai DiceLoss(sigmoid,
+ * squared_pred, batch=True), src/definer.py:184-203).  NCDHW f32 logits / target [N][K][voxels].
+ * stats: sums[k] = {sum t*p, sum p*p, sum t*t}; grad: dx = (coef[k][0]*t + coef[k][1]*2p) * p*(1-p). */
+int brats_dice_stats(const float* logits, const float* target, float* sums /*[K][3]*/, int N, int K,
+                     size_t voxels, brats_stream_t s);
+int brats_dice_grad(const float* logits, const float* target, const float* coef /*[K][2]*/,
+                    float* dlogits, int N, int K, size_t voxels, brats_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,23 @@ def test_layout_roundtrip():
         torch.testing.assert_close(back, x.to(dtype).float(), atol=0, rtol=0)
         if cpad > 4:
             assert float(t[..., 4:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("jaccard", [False, True])
+def test_fused_dice_matches_torch_dice(jaccard):
+    """Fused HIP Dice passes == the PyTorch Dice of brats21_amd.losses == the oracle's dice_loss."""
+    from brats21_amd.losses import DiceLoss, deep_supervision_loss, fused_deep_supervision_dice
+    from oracle import unet
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    heads = [torch.randn(2, 3, 8, 12, 10, generator=g).to(dev).requires_grad_(True) for _ in range(3)]
+    t = (torch.rand(2, 3, 8, 12, 10, generator=g) > 0.6).float().to(dev)
+    ref, _ = deep_supervision_loss(DiceLoss(jaccard=jaccard), (heads[0], heads[1:]), t)
+    gref = torch.autograd.grad(ref, heads)
+    loss = fused_deep_supervision_dice((heads[0], heads[1:]), t, jaccard=jaccard)
+    gfused = torch.autograd.grad(loss, heads)
+    assert abs(loss.item() - ref.item()) < 1e-6
+    cpu = torch.stack([unet.dice_loss(h.detach().cpu(), t.cpu(), jaccard) for h in heads]).mean()
+    assert abs(loss.item() - cpu.item()) < 1e-6
+    for a, b in zip(gfused, gref):
+        torch.testing.assert_close(a, b, atol=1e-9, rtol=1e-4)
