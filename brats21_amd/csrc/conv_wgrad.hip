@@ -10,6 +10,7 @@
 // and a dY tile are staged once per tile and reused by 27 taps x COF x CIF MFMAs per k-step.
 // Split-K over workgroups writes f32 slabs ws[split][tap][co][ci]; a second kernel reduces them in a
 // fixed order (bitwise reproducible, no float atomics) into torch's [co][ci][tap] layout.
+#include <stdlib.h>
 #include "common.hpp"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -20,29 +21,37 @@ struct WgradParams {
   float* ws;
   int N, D, H, W, cin, cout;
   int tz, ty, tx, ntiles, nsplit;
+  int stagger;  // de-phasing delay in units of s_sleep(16) = 1024 cycles (BRATS_WGRAD_STAGGER)
+  int debug;  // ablation bits (BRATS_WGRAD_DEBUG): 1 skip global loads, 2 skip MMA, 8 skip LDS writes+barriers
 };
 
-constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // rows of 16 x-voxels
+constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // tile = 16 x-rows of 16 voxels
 
+// A workgroup owns ONE z-plane of taps (tzg in 0..2, 9 taps): its X tile then needs no z halo
+// (4 x (4+2d) x (16+2d) voxels), X + dY tiles fit twice per CU, and two workgroups per CU overlap each
+// other's staging and MFMA phases.  The three tzg workgroups of a tile group sit on the same XCD
+// (block ids b, b+8, b+16) so the shared dY / X lines come from that XCD's L2.
 template <typename T, int DIL, int COF, int CIF>
 struct WgGeom {
   static constexpr bool BF = std::is_same<T, bf16_t>::value;
   static constexpr int ESZ = sizeof(T);
   static constexpr int EPL = 16 / ESZ;
-  static constexpr int HZ = WG_TZ + 2 * DIL, HY = WG_TY + 2 * DIL, HX = WG_TX + 2 * DIL;
-  static constexpr int HVOX = HZ * HY * HX;
+  static constexpr int HY = WG_TY + 2 * DIL, HX = WG_TX + 2 * DIL;
+  static constexpr int HVOX = WG_TZ * HY * HX;
   static constexpr int CI_T = 16 * CIF, CO_T = 16 * COF;
   static constexpr int XROWB = CI_T * ESZ, YROWB = CO_T * ESZ;
   // voxel strides: the transposing reads of a 32-lane half touch 8 consecutive x-voxels x 32 B, which is
   // bank-conflict-free iff the stride is 32, 96 or 160 B (CI_T/CO_T = 48 bf16 -> 96 B, no padding)
-  static constexpr int SX = BF ? (CIF == 1 ? 32 : (CIF <= 3 ? 96 : XROWB + 32)) : XROWB + 16;
-  static constexpr int SY = BF ? (COF == 1 ? 32 : (COF <= 3 ? 96 : YROWB + 32)) : YROWB + 16;
+  static constexpr int SX = BF ? (CIF == 1 ? 32 : 96) : XROWB + 16;
+  static constexpr int SY = BF ? (COF == 1 ? 32 : 96) : YROWB + 16;
   static constexpr int XPPV = XROWB / 16, YPPV = YROWB / 16;
-  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;
-  static constexpr int XITER = (XPIECES + 255) / 256, YITER = (YPIECES + 255) / 256;
+  static constexpr int XPPR = HX * XPPV, XIPR = (XPPR + 63) / 64, XROWS = WG_TZ * HY, XRPW = (XROWS + 3) / 4;
+  static constexpr int YPPR = WG_TX * YPPV, YIPR = (YPPR + 63) / 64, YROWS = WG_TZ * WG_TY, YRPW = YROWS / 4;
   static constexpr int LDS_X = HVOX * SX, LDS_Y = WG_VOX * SY;
   static constexpr int LDS = LDS_X + LDS_Y;
-  static constexpr int TPW = 7;  // taps per wave (27 = 7+7+7+6)
+  static constexpr int PAIRS = 9 * CIF;          // (tap-in-plane, ci fragment) pairs
+  static constexpr int PPW = (PAIRS + 3) / 4;    // pairs per wave (wave w: w, w+4, ...)
+  static constexpr int NB = BF ? 32 : 64;        // bytes between consecutive ci / co fragments in a voxel row
 };
 
 DEVI bf16x8 tr_pair(const char* p0, const char* p1) {
@@ -54,7 +63,7 @@ DEVI bf16x8 tr_pair(const char* p0, const char* p1) {
 }
 
 template <typename T, int DIL, int COF, int CIF>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
   using G = WgGeom<T, DIL, COF, CIF>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldx = lds;
@@ -62,7 +71,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, v = lane & 15;
-  const int split = blockIdx.x, cot = blockIdx.y, cit = blockIdx.z;
+  // ---- schedule: blockIdx.x = lane8 + 8*r, r = 3*gsub + tzg ----
+  const int lane8 = blockIdx.x & 7, rr = blockIdx.x >> 3;
+  const int tzg = rr % 3, gsub = rr / 3, g8 = gridDim.x / 24;
+  const int split = lane8 + 8 * gsub;
+  const int tpx = (p.ntiles + 7) / 8;
+  const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
+  const int cot = blockIdx.y, cit = blockIdx.z;
   const int co0 = cot * G::CO_T, ci0 = cit * G::CI_T;
   const T* xsrc;
   int xpitch;
@@ -71,90 +86,149 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
   const int ci_lim = (ci0 < p.c1 ? p.c1 : p.c1 + p.c2) - ci0;  // valid channels from this source in the tile
   const int co_lim = p.cout - co0;
 
-  f32x4 acc[G::TPW][COF][CIF];
+  // ---- per-lane staging constants (row-per-wave: row origin and row bounds are scalar) ----
+  int xhx[G::XIPR], xgo[G::XIPR], xlo[G::XIPR];
 #pragma unroll
-  for (int j = 0; j < G::TPW; ++j)
-#pragma unroll
-    for (int m = 0; m < COF; ++m)
-#pragma unroll
-      for (int n = 0; n < CIF; ++n) acc[j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // per-wave tap offsets into the halo tile (bytes)
-  int tapo[G::TPW];
-#pragma unroll
-  for (int j = 0; j < G::TPW; ++j) {
-    const int t = wave + 4 * j;
-    tapo[j] = t < 27 ? ((((t / 9) * DIL) * G::HY + ((t / 3) % 3) * DIL) * G::HX + (t % 3) * DIL) * G::SX : 0;
+  for (int j = 0; j < G::XIPR; ++j) {
+    const int pc = lane + 64 * j;
+    const int hx = pc / G::XPPV, part = pc % G::XPPV;
+    const bool ok = pc < G::XPPR && part * G::EPL < ci_lim;
+    xhx[j] = ok ? hx : -100000;
+    xgo[j] = hx * xpitch + part * G::EPL;
+    xlo[j] = pc < G::XPPR ? wave * (G::HX * G::SX) + hx * G::SX + part * 16 : -1;
   }
+  int yvx[G::YIPR], ygo[G::YIPR], ylo[G::YIPR];
+#pragma unroll
+  for (int j = 0; j < G::YIPR; ++j) {
+    const int pc = lane + 64 * j;
+    const int vx = pc / G::YPPV, part = pc % G::YPPV;
+    const bool ok = pc < G::YPPR && part * G::EPL < co_lim;
+    yvx[j] = ok ? vx : 100000;
+    ygo[j] = vx * p.dyp + part * G::EPL;
+    ylo[j] = pc < G::YPPR ? wave * (WG_TX * G::SY) + vx * G::SY + part * 16 : -1;
+  }
+  // interior fast path: element offsets of every staged piece from the tile's halo origin.  For a tile whose
+  // halo lies inside the volume the per-tile staging is then just XRPW*XIPR + YRPW*YIPR loads off one scalar
+  // base (no per-row bounds / pointer arithmetic: that per-tile scalar+vector overhead cost as much as the MFMAs)
+  int xvo[G::XRPW][G::XIPR], yvo[G::YRPW][G::YIPR];
+#pragma unroll
+  for (int k = 0; k < G::XRPW; ++k) {
+    const int row = wave + 4 * k;
+#pragma unroll
+    for (int j = 0; j < G::XIPR; ++j)
+      xvo[k][j] = (lane + 64 * j < G::XPPR && row < G::XROWS) ? ((row / G::HY) * p.H + row % G::HY) * p.W * xpitch + xgo[j] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < G::YRPW; ++k) {
+    const int row = wave + 4 * k;
+#pragma unroll
+    for (int j = 0; j < G::YIPR; ++j)
+      yvo[k][j] = (lane + 64 * j < G::YPPR) ? ((row / WG_TY) * p.H + row % WG_TY) * p.W * p.dyp + ygo[j] : 0;
+  }
+  const bool chan_full = ci_lim >= G::CI_T && co_lim >= G::CO_T;
 
-  // global -> register prefetch of one tile (zero-filled outside the volume / channel range)
-  u32x4 rx[G::XITER], ry[G::YITER];
-  auto prefetch = [&](int tile) {
+  // ---- the wave's (tap-in-plane, ci-fragment) pairs ----
+  int poff[G::PPW];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 4 * jj;
+    const int t9 = pid / CIF, nn = pid % CIF;
+    poff[jj] = pid < G::PAIRS ? (((t9 / 3) * DIL) * G::HX + (t9 % 3) * DIL) * G::SX + nn * G::NB : 0;
+  }
+  f32x4 acc[G::PPW][COF];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj)
+#pragma unroll
+    for (int m = 0; m < COF; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // De-phase the two workgroups sharing a CU (they run identical per-tile sequences and would otherwise stay in
+  // lockstep: both waiting on loads, then both contending for the matrix pipe).  The SIMD wave slot (HW_ID
+  // bits 3:0) of co-resident workgroups differs; odd slots start half a tile period late.  Speed only.
+  if (p.stagger > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
+    if (hwid & 1u) for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  for (int tile = lane8 * tpx + gsub; tile < tile_end; tile += g8) {
     int bt = tile;
-    const int txi = bt % p.tx; bt /= p.tx;
-    const int tyi = bt % p.ty; bt /= p.ty;
-    const int tzi = bt % p.tz;
+    const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
+    const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
+    const int z0 = (bt % p.tz) * WG_TZ;
     const int n = bt / p.tz;
-    const int z0 = tzi * WG_TZ, y0 = tyi * WG_TY, x0 = txi * WG_TX;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
-    // opaque copy of the thread id: stops hipcc from hoisting ~6 loop-invariant address terms per piece
-    // out of the tile loop (126 VGPRs -> spills -> every prefetch load waited for at vmcnt(0))
-    int tid_o = tid;
-    asm volatile("" : "+v"(tid_o));
+    u32x4 rx[G::XRPW][G::XIPR], ry[G::YRPW][G::YIPR];
+    const int gz0 = z0 + (tzg - 1) * DIL;
+    const bool interior = chan_full && gz0 >= 0 && gz0 + WG_TZ <= p.D && y0 >= DIL && y0 + WG_TY + DIL <= p.H &&
+                          x0 >= DIL && x0 + WG_TX + DIL <= p.W && !(p.debug & 1);
+    if (interior) {
+      const T* xb = xsrc + (sample_vox + ((size_t)gz0 * p.H + (y0 - DIL)) * p.W + (x0 - DIL)) * xpitch;
+      const T* yb = (const T*)p.dy + (sample_vox + ((size_t)z0 * p.H + y0) * p.W + x0) * p.dyp + co0;
 #pragma unroll
-    for (int i = 0; i < G::XITER; ++i) {
-      const int pc = tid_o + 256 * i;
-      const int hv = pc / G::XPPV, part = pc % G::XPPV;
-      const int hz = hv / (G::HY * G::HX), rr = hv % (G::HY * G::HX);
-      const int hy = rr / G::HX, hx = rr % G::HX;
-      const int gz = z0 - DIL + hz, gy = y0 - DIL + hy, gx = x0 - DIL + hx;
-      const bool ok = pc < G::XPIECES && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W &&
-                      part * G::EPL < ci_lim;
-      rx[i] = u32x4{0u, 0u, 0u, 0u};
-      if (ok) rx[i] = *(const u32x4*)(xsrc + (sample_vox + (size_t)(gz * p.H + gy) * p.W + gx) * xpitch + part * G::EPL);
-    }
+      for (int k = 0; k < G::XRPW; ++k)
 #pragma unroll
-    for (int i = 0; i < G::YITER; ++i) {
-      const int pc = tid_o + 256 * i;
-      const int vx = pc / G::YPPV, part = pc % G::YPPV;
-      const int gz = z0 + vx / 64, gy = y0 + (vx / 16) % 4, gx = x0 + vx % 16;
-      const bool ok = pc < G::YPIECES && gz < p.D && gy < p.H && gx < p.W && part * G::EPL < co_lim;
-      ry[i] = u32x4{0u, 0u, 0u, 0u};
-      if (ok) ry[i] = *(const u32x4*)((const T*)p.dy + (sample_vox + (size_t)(gz * p.H + gy) * p.W + gx) * p.dyp + co0 + part * G::EPL);
+        for (int j = 0; j < G::XIPR; ++j) rx[k][j] = *(const u32x4*)(xb + xvo[k][j]);
+#pragma unroll
+      for (int k = 0; k < G::YRPW; ++k)
+#pragma unroll
+        for (int j = 0; j < G::YIPR; ++j) ry[k][j] = *(const u32x4*)(yb + yvo[k][j]);
+    } else {
+    // ---- global -> registers (zero outside the volume / channel range) ----
+  #pragma unroll
+      for (int k = 0; k < G::XRPW; ++k) {
+        const int row = wave + 4 * k;
+        const int gz = z0 + row / G::HY + (tzg - 1) * DIL, gy = y0 - DIL + row % G::HY;
+        const bool row_ok = row < G::XROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
+        const T* rowp = xsrc + ((ptrdiff_t)(sample_vox + (size_t)(gz * p.H + gy) * p.W) + (x0 - DIL)) * xpitch;
+  #pragma unroll
+        for (int j = 0; j < G::XIPR; ++j) {
+          const int gx = x0 - DIL + xhx[j];
+          rx[k][j] = u32x4{0u, 0u, 0u, 0u};
+          if (row_ok && gx >= 0 && gx < p.W && !(p.debug & 1)) rx[k][j] = *(const u32x4*)(rowp + xgo[j]);
+        }
+      }
+  #pragma unroll
+      for (int k = 0; k < G::YRPW; ++k) {
+        const int row = wave + 4 * k;
+        const int gz = z0 + row / WG_TY, gy = y0 + row % WG_TY;
+        const bool row_ok = gz < p.D && gy < p.H;
+        const T* rowp = (const T*)p.dy + (sample_vox + (size_t)(gz * p.H + gy) * p.W + x0) * p.dyp + co0;
+  #pragma unroll
+        for (int j = 0; j < G::YIPR; ++j) {
+          ry[k][j] = u32x4{0u, 0u, 0u, 0u};
+          if (row_ok && x0 + yvx[j] < p.W && !(p.debug & 1)) ry[k][j] = *(const u32x4*)(rowp + ygo[j]);
+        }
+      }
     }
-  };
-
-  if (split < p.ntiles) prefetch(split);
-  for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+    if (!(p.debug & 8)) {
     __syncthreads();  // previous tile's LDS reads are done
-    int tid_w = tid;
-    asm volatile("" : "+v"(tid_w));
 #pragma unroll
-    for (int i = 0; i < G::XITER; ++i) {
-      const int pc = tid_w + 256 * i;
-      if (pc < G::XPIECES) *(u32x4*)(ldx + (pc / G::XPPV) * G::SX + (pc % G::XPPV) * 16) = rx[i];
+    for (int k = 0; k < G::XRPW; ++k) {
+      if (wave + 4 * k < G::XROWS) {
+#pragma unroll
+        for (int j = 0; j < G::XIPR; ++j)
+          if (xlo[j] >= 0) *(u32x4*)(ldx + xlo[j] + k * 4 * (G::HX * G::SX)) = rx[k][j];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < G::YITER; ++i) {
-      const int pc = tid_w + 256 * i;
-      if (pc < G::YPIECES) *(u32x4*)(ldy + (pc / G::YPPV) * G::SY + (pc % G::YPPV) * 16) = ry[i];
+    for (int k = 0; k < G::YRPW; ++k) {
+#pragma unroll
+      for (int j = 0; j < G::YIPR; ++j)
+        if (ylo[j] >= 0) *(u32x4*)(ldy + ylo[j] + k * 4 * (WG_TX * G::SY)) = ry[k][j];
     }
     __syncthreads();
-    // the next tile's HBM/L2 loads fly underneath this tile's MFMA phase (1 workgroup per CU: nobody
-    // else would hide them)
-    if (tile + p.nsplit < p.ntiles) prefetch(tile + p.nsplit);
+    } else { asm volatile("" :: "v"(rx[0][0][0]), "v"(ry[0][0][0])); }
 
     // ---- MFMA over the 256 voxels of the tile ----
+    if (p.debug & 2) continue;
     if constexpr (G::BF) {
-      // k-step s = the two x-rows 2s, 2s+1 of the tile (row = z*4 + y, 16 voxels each).  MFMA k = 8q + e:
-      // e = 0..3 come from the first transposing read (row 2s, x = 4q + e), e = 4..7 from the second
-      // (row 2s+1, same x); lane 4qq+pp of a quarter supplies voxel x = 4q + qq, channels 4pp..4pp+3.
-      // Software pipeline over the 8 x 7 (k-step, tap) pairs: the fragments of pair u+1 are read while
-      // the COF*CIF MFMAs of pair u issue.  Wave 3's 7th tap slot is a dummy (tap 27): computed, never stored.
+      // k-step s = the two x-rows 2s, 2s+1 of the tile (row = z*4 + y).  MFMA k = 8q + e: e = 0..3 from the
+      // first transposing read (row 2s, x = 4q + e), e = 4..7 from the second (row 2s+1, same x); lane
+      // 4qq+pp of a quarter supplies voxel x = 4q + qq, channels 4pp..4pp+3.  Software pipeline over the
+      // 8 x PPW (k-step, pair) steps: fragments of step u+1 are read while the COF MFMAs of step u issue.
       const int qq = v >> 2, pp = v & 3;
       const int ybase = (4 * q + qq) * G::SY + pp * 8;
-      const int xbase = (4 * q + qq) * G::SX + pp * 8;  // tap (0,0,0) corner; tapo[] adds the tap shift
-      bf16x8 a[2][COF], b[2][CIF];
+      const int xbase = (4 * q + qq) * G::SX + pp * 8;
+      constexpr int PD = 3;  // B-fragment prefetch distance in steps (3 MFMAs each): covers LDS latency
+      bf16x8 a[2][COF], b[PD + 1];
       auto read_a = [&](auto s_) {
         constexpr int s = s_;
         const int yoff = ybase + (32 * s) * G::SY;
@@ -163,30 +237,26 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
       };
       auto read_b = [&](auto u_) {
         constexpr int u = u_;
-        constexpr int s = u / G::TPW, j = u % G::TPW;
-        const int xoff = xbase + (((s >> 1) * G::HY + 2 * (s & 1)) * G::HX) * G::SX + tapo[j];
-#pragma unroll
-        for (int n = 0; n < CIF; ++n) b[u & 1][n] = tr_pair(ldx + xoff + n * 32, ldx + xoff + G::HX * G::SX + n * 32);
+        constexpr int s = u / G::PPW, jj = u % G::PPW;
+        const int xoff = xbase + (((s >> 1) * G::HY + 2 * (s & 1)) * G::HX) * G::SX + poff[jj];
+        b[u % (PD + 1)] = tr_pair(ldx + xoff, ldx + xoff + G::HX * G::SX);
       };
+      constexpr int NU = 8 * G::PPW;
       read_a(std::integral_constant<int, 0>{});
-      read_b(std::integral_constant<int, 0>{});
-      static_for<0, 8 * G::TPW>([&](auto u_) {
+      static_for<0, PD>([&](auto u_) { read_b(u_); });
+      static_for<0, NU>([&](auto u_) {
         constexpr int u = u_;
-        constexpr int s = u / G::TPW, j = u % G::TPW;
-        if constexpr (u + 1 < 8 * G::TPW) {
-          read_b(std::integral_constant<int, u + 1>{});
-          if constexpr ((u + 1) % G::TPW == 0) read_a(std::integral_constant<int, (u + 1) / G::TPW>{});
-        }
+        constexpr int s = u / G::PPW, jj = u % G::PPW;
+        if constexpr (u + PD < NU) read_b(std::integral_constant<int, u + PD>{});
+        if constexpr (jj == 0 && s + 1 < 8) read_a(std::integral_constant<int, s + 1>{});  // a whole k-step ahead
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < CIF; ++n)
-#pragma unroll
-          for (int m = 0; m < COF; ++m)
-            acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u & 1][n], acc[j][m][n], 0, 0, 0);
+        for (int m = 0; m < COF; ++m)
+          acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
-      // f32: k-step s' = voxels 4s'..4s'+3 of the flattened tile, quarter q -> voxel 4s'+q
+      // f32: k-step s' = voxels 4s'..4s'+3 of the flattened tile (x fastest), quarter q -> voxel 4s'+q
 #pragma unroll 2
       for (int s = 0; s < 64; ++s) {
         const int vx = 4 * s + q;
@@ -197,34 +267,29 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int m = 0; m < COF; ++m) a[m] = *(const float*)(ldy + yoff + m * 64);
 #pragma unroll
-        for (int j = 0; j < G::TPW; ++j) {
+        for (int jj = 0; jj < G::PPW; ++jj) {
+          const float b = *(const float*)(ldx + xoff + poff[jj]);
 #pragma unroll
-          for (int n = 0; n < CIF; ++n) {
-            const float b = *(const float*)(ldx + xoff + tapo[j] + n * 64);
-#pragma unroll
-            for (int m = 0; m < COF; ++m) acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[j][m][n], 0, 0, 0);
-          }
+          for (int m = 0; m < COF; ++m) acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[jj][m], 0, 0, 0);
         }
       }
     }
   }
 
-  // ---- write the split's slab: ws[split][tap][co][ci] ----
+  // ---- write the slab part of this workgroup: ws[split][tap = 9*tzg + t9][co][ci] ----
 #pragma unroll
-  for (int j = 0; j < G::TPW; ++j) {
-    const int t = wave + 4 * j;
-    if (t < 27) {
-      float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 4 * jj;
+    if (pid < G::PAIRS) {
+      const int t9 = pid / CIF, nn = pid % CIF;
+      float* base = p.ws + ((size_t)split * 27 + tzg * 9 + t9) * p.cout * p.cin;
+      const int ci = ci0 + nn * 16 + v;
 #pragma unroll
       for (int m = 0; m < COF; ++m)
 #pragma unroll
-        for (int n = 0; n < CIF; ++n) {
-          const int ci = ci0 + n * 16 + v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = co0 + m * 16 + 4 * q + r;
-            if (co < p.cout && n * 16 + v < ci_lim) base[(size_t)co * p.cin + ci] = acc[j][m][n][r];
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + m * 16 + 4 * q + r;
+          if (co < p.cout && nn * 16 + v < ci_lim) base[(size_t)co * p.cin + ci] = acc[jj][m][r];
         }
     }
   }
@@ -262,12 +327,15 @@ __global__ void dbias_kernel(const T* __restrict__ dy, int pitch, float* __restr
   if (threadIdx.x == 0) db[c] = red[0];
 }
 
-static int wgrad_nsplit(int ntiles, int cotiles, int citiles) {
-  int ns = ceil_div(256, cotiles * citiles);  // the kernel runs 1 workgroup per CU (acc in ~252 registers)
-  if (ns > ntiles) ns = ntiles;
-  if (ns < 1) ns = 1;
-  return ns;
+// spatial groups: 8 XCD ranges x g8 sub-groups; total workgroups = 3 (tap planes) * 8 * g8 * cot * cit ~ 2 per CU
+static int wgrad_g8(int ntiles, int cotiles, int citiles) {
+  int g8 = ceil_div(512, 24 * cotiles * citiles);
+  const int cap = ceil_div(ntiles, 8);
+  if (g8 > cap) g8 = cap;
+  if (g8 < 1) g8 = 1;
+  return g8;
 }
+static int wgrad_nsplit(int ntiles, int cotiles, int citiles) { return 8 * wgrad_g8(ntiles, cotiles, citiles); }
 static void wgrad_tiles(int dtype, int c1, int c2, int cout, int* cof, int* cif) {
   const int co16 = ceil_div(cout, 16);
   *cof = co16 % 3 == 0 ? 3 : (co16 % 2 == 0 ? 2 : 1);
@@ -335,6 +403,8 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   const int cot = ceil_div(cout, 16 * cof);
   const int cit = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
   p.nsplit = wgrad_nsplit(p.ntiles, cot, cit);
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("BRATS_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("BRATS_WGRAD_STAGGER"); stg = e ? atoi(e) : 5; } p.stagger = stg; }
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
   hipStream_t st = (hipStream_t)s;
@@ -343,7 +413,7 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * 27 * cout * p.cin * sizeof(float), st);
     if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: memset: %s", hipGetErrorString(e));
   }
-  dim3 grid(p.nsplit, cot, cit);
+  dim3 grid(3 * p.nsplit, cot, cit);  // x = lane8 + 8*(3*gsub + tzg)
   int rc;
   if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
   else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);
