@@ -56,6 +56,43 @@ def cpu_baseline(width, cores):
                       f"host has {cores} cores, {threads} threads used (fastest setting)"}
 
 
+def inference_bench(model, dev, args):
+    """BASELINE.json configs[3]: sliding-window inference of one synthetic 4x240x240x155 volume (padded to a
+    multiple of 8 like learning/engine.py:217 -> 160), 128^3 window, overlap 0.5 (18 windows), 8-flip TTA
+    (all subsets of the three spatial axes) = 144 patch forwards, everything on the GPU: fused gather,
+    hipGraph-replayed bf16 patch step without the deep heads, fused de-augment + sigmoid + accumulate."""
+    import itertools
+    from brats21_amd import synth
+    from brats21_amd.inferers import GraphedPredictor, sliding_window_inference, tta_predict
+    from brats21_amd.tta.base import SignedPerm, Transformer
+    model.eval()
+    model.skip_deep_heads_in_eval = True
+    prec = model.precision
+    model.precision = args.precision
+    flips = [Transformer(SignedPerm((0, 1, 2), f), SignedPerm((0, 1, 2), f)) for f in itertools.product([False, True], repeat=3)]
+    vol = synth.random_image(1, 4, (240, 240, 160), seed=99, device=dev)
+    graphed = GraphedPredictor(model)
+
+    def predictor(x):
+        return sliding_window_inference(x, (128, 128, 128), 1, graphed, overlap=0.5)
+
+    with torch.no_grad():
+        tta_predict(vol, predictor, flips[:1])  # capture + warm-up (18 windows)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prob = tta_predict(vol, predictor, flips)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+    model.precision = prec
+    model.train()
+    fwd_tf = 144 * (1995.7e9 if args.model == "equiunet" else 1689.8e9) / sec / 1e12
+    return {"metric": "inference volumes/sec", "value": round(1.0 / sec, 4), "unit": "volumes/s",
+            "config": "4x240x240x155(->160), window 128^3, overlap 0.5, 18 windows x 8-flip TTA = 144 patch forwards, "
+                      f"{args.precision}, hipGraph patch step", "s_per_volume": round(sec, 3),
+            "ms_per_patch_forward": round(sec / 144 * 1e3, 2), "TFLOPs": round(fwd_tf, 1),
+            "mean_prob": round(float(prob.mean()), 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +104,7 @@ def main():
     ap.add_argument("--model", default="equiunet")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="skip the sliding-window + TTA inference measurement")
     ap.add_argument("--torch-dice", dest="fused_dice", action="store_false",
                     help="use the PyTorch Dice loss (reference path) instead of the fused HIP Dice passes")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
@@ -89,7 +127,7 @@ def main():
         model = get_model(ns).to(dev).train()
     crit = DiceLoss().to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
-    buckets = GradientBuckets(model) if world > 1 else None
+    buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None
     size = (args.patch,) * 3
     x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
     t = synth.nested_spheres(args.batch, size, device=dev)
@@ -166,6 +204,8 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
         "roofline": roofline,
     }
+    if world == 1 and not args.no_infer:
+        res["inference"] = inference_bench(model, dev, args)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.width, os.cpu_count() or 1)
     print(json.dumps(res))
