@@ -86,13 +86,14 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
   constexpr int NSTEP = PARITY < 0 ? G::MS : (G::MS - PARITY + 1) / 2;
   if constexpr (G::BF) {
     const bf16x8* wp0 = (const bf16x8*)wpk_chunk + (size_t)f0 * 64 + lane;
-    bf16x8 a[2][NF];
+    constexpr int WD = 2;  // weight prefetch distance in macro-steps (L2 latency under load > one step of 24 MFMAs)
+    bf16x8 a[WD + 1][NF];
     bf16x8 b[8];
     auto load_a = [&](auto k_) {
       constexpr int k = k_;
       constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
 #pragma unroll
-      for (int f = 0; f < NF; ++f) a[k & 1][f] = wp0[((size_t)ms * rows16 + f) * 64];
+      for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
     };
     auto read_b = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
@@ -114,17 +115,17 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
 #pragma unroll
       for (int i = 4 * half; i < 4 * half + 4; ++i)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k & 1][f], b[i], acc[f][i], 0, 0, 0);
+        for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    load_a(I0{});
+    static_for<0, (WD < NSTEP ? WD : NSTEP)>([&](auto k_) { load_a(k_); });
     read_b(I0{}, I0{});
     static_for<0, NSTEP>([&](auto k_) {
       constexpr int k = k_;
       // sched_barrier(0) pins the issue order: without it hipcc sinks every load to just before its
       // first use (one live B fragment, weights waited for at vmcnt(0)) and the loop runs latency-bound
-      if constexpr (k + 1 < NSTEP) load_a(std::integral_constant<int, k + 1>{});
+      if constexpr (k + WD < NSTEP) load_a(std::integral_constant<int, k + WD>{});
       read_b(k_, I1{});
       __builtin_amdgcn_sched_barrier(0);
       mma(k_, I0{});
