@@ -98,14 +98,16 @@ extern "C" int brats_conv3d_pack_weights(const float* w, void* packed, int dtype
 }
 
 // ---- forward / dgrad ---------------------------------------------------------------------------
+extern "C" int brats_conv3d_split_granule(int cout) { return conv_choose_tile(ceil_div(cout, 16)).nf * 16; }
+
 extern "C" int brats_conv3d_tiles_per_sample(int D, int H, int W) {
   return ceil_div(D, CONV_TZ) * ceil_div(H, CONV_TY) * ceil_div(W, CONV_TX);
 }
 
 extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
-                                const void* packed_w, const float* bias, void* y, int ypitch, float* stats,
-                                int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
-                                brats_stream_t s) {
+                                const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
+                                int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
+                                int cout, brats_stream_t s) {
   if (!x1 || !packed_w || !y || c1 <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0)
     BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: null pointer or non-positive size");
   if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: c2 > 0 but x2 is NULL");
@@ -119,6 +121,12 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
   ConvParams p;
   p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
   p.wpk = packed_w; p.bias = bias; p.y = y; p.ypitch = ypitch; p.stats = stats;
+  p.y2 = y2; p.y2pitch = y2pitch; p.ysplit = ysplit;
+  if (y2) {
+    const ConvTileChoice tc = conv_choose_tile(ceil_div(cout, 16));
+    if (ysplit <= 0 || ysplit >= cout || ysplit % (tc.nf * 16) || y2pitch % 4)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: ysplit=%d must be a multiple of %d inside (0, cout)", ysplit, tc.nf * 16);
+  }
   p.N = N; p.D = D; p.H = H; p.W = W; p.cout = cout; p.rows16 = ceil_div(cout, 16);
   p.nchunks = (c1 + c2) / ck;
   p.tz = ceil_div(D, CONV_TZ); p.ty = ceil_div(H, CONV_TY); p.tx = ceil_div(W, CONV_TX);

@@ -19,6 +19,7 @@
 struct ConvParams {
   const void* x1; const void* x2; int c1, c2, p1, p2;
   const void* wpk; const float* bias; void* y; int ypitch; float* stats;
+  void* y2; int y2pitch; int ysplit;  // optional second destination for output channels >= ysplit (dgrad of a concat input)
   int N, D, H, W, cout, rows16, nchunks;
   int tz, ty, tx;
 };
@@ -286,7 +287,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const bool active = KSPLIT ? (wn == 0) : true;
   if (active) {
     const bool x_ok = x0 + v < p.W;
-    const int lane_o = (x0 + v) * p.ypitch + 4 * q;  // elements from the row origin
+    // dual destination (dgrad of a conv whose input was the virtual concat [x1 | x2]): channels >= ysplit
+    // go to y2.  ysplit is a multiple of the wave's NF*16 channels, so the choice is per wave.
+    const bool second = p.y2 != nullptr && f0 * 16 >= p.ysplit;
+    T* const ydst = second ? (T*)p.y2 : (T*)p.y;
+    const int ypit = second ? p.y2pitch : p.ypitch;
+    const int csub = second ? p.ysplit : 0;
+    const int lane_o = (x0 + v) * ypit + 4 * q - csub;  // elements from the row origin
     float bias[NF][4], s1[NF][4], s2[NF][4];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int z = z0 + 2 * wm + (i >> 2), y = y0 + (i & 3);
-        T* rowp = (T*)p.y + (sample_vox + (size_t)(z * p.H + y) * p.W) * p.ypitch;
+        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           float o[4];
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         const int z = z0 + 2 * wm + (i >> 2), y = y0 + (i & 3);
         const bool ok = z < p.D && y < p.H && x_ok;
         const float mk = ok ? 1.f : 0.f;
-        T* rowp = (T*)p.y + (sample_vox + (size_t)(z * p.H + y) * p.W) * p.ypitch;
+        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const bool cok = (f0 + f) * 16 + 4 * q < p.cout;

@@ -66,23 +66,28 @@ def _head(cin, k):
 
 
 # ------------------------------------------------------------------------------------------ programs
-def _cgr_fwd(unit, x, dtype, act, out=None):
-    """One ConvBnRelu: pack -> implicit-GEMM conv (+ tile statistics) -> finalize -> normalise+act."""
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None):
+    """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
+    -> finalize -> normalise+act."""
     w = unit.conv.weight
-    cout, cin = w.shape[0], w.shape[1]
-    cin_pad = x.shape[-1]
-    wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation)
-    y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True)
+    cout = w.shape[0]
+    cin_pad = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+    wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=x.shape[-1] if x2 is not None else None)
+    y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
     n, d, h, wd, _ = y.shape
     mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, 8, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
     z = ops.affine_act(y, scale_shift, act, out=out)
-    return z, (unit, x, y, mean_rstd, scale_shift)
+    return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
 def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None):
-    unit, x, y, mean_rstd, scale_shift = rec
+    """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit."""
+    unit, x, x2, y, mean_rstd, scale_shift = rec
     dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), 8, act)
-    dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation)
+    if x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
+        dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
+    else:
+        dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2)
     cin = unit.conv.weight.shape[1]
     grads[names[unit.conv.weight]] = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
     grads[names[unit.bn.weight]] = dgamma
@@ -93,8 +98,15 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None):
     if not need_dx:
         return None
     wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
-    dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation)
-    return dx
+    if x2 is None:
+        dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation)
+        return dx
+    c1 = x.shape[-1]
+    if c1 % ops.split_granule(cin) == 0:
+        dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation, split=c1)  # (dx1, dx2): two dense tensors, one launch
+        return dx
+    dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation)  # narrow test widths: slice views of one tensor
+    return dx[..., :c1], dx[..., c1:]
 
 
 class _EquiUnetFn(torch.autograd.Function):
@@ -107,34 +119,25 @@ class _EquiUnetFn(torch.autograd.Function):
         dev = x.device
         tape = []
 
-        def cgr(unit, xin, out=None):
-            z, rec = _cgr_fwd(unit, xin, dtype, act, out)
+        def cgr(unit, xin, x2=None):
+            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2)
             tape.append(rec)
             return z
 
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
-        cat1 = ops.new_act(n, d, h, w, 2 * f[0], dtype, dev)
-        cat2 = ops.new_act(n, d // 2, h // 2, w // 2, 2 * f[1], dtype, dev)
-        cat3 = ops.new_act(n, d // 4, h // 4, w // 4, 2 * f[2], dtype, dev)
-        cat4 = ops.new_act(n, d // 8, h // 8, w // 8, 2 * f[3], dtype, dev)
-        # encoder (networks/equiunet2020.py:469-475)
-        down1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0), cat1[..., :f[0]])
-        p1 = ops.maxpool2(down1)
-        down2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, p1), cat2[..., :f[1]])
-        p2 = ops.maxpool2(down2)
-        down3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, p2), cat3[..., :f[2]])
-        p3 = ops.maxpool2(down3)
-        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, p3), cat4[..., :f[3]])
+        # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
+        # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
+        down1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0))
+        down2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, ops.maxpool2(down1)))
+        down3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, ops.maxpool2(down2)))
+        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, ops.maxpool2(down3)))
         # bottom (:477-478): dilated block, then conv over cat[down4, bottom]
-        bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4), cat4[..., f[3]:])
-        bottom_2 = cgr(m.bottom_2, cat4)
-        # decoder (:481-486): up-sample straight into the second half of the concat buffers
-        ops.upsample(bottom_2, 2, out=cat3[..., f[2]:])
-        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, cat3))
-        ops.upsample(up3, 2, out=cat2[..., f[1]:])
-        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, cat2))
-        ops.upsample(up2, 2, out=cat1[..., f[0]:])
-        up1 = cgr(m.decoder1.ConvBnRelu2, cgr(m.decoder1.ConvBnRelu1, cat1))
+        bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4))
+        bottom_2 = cgr(m.bottom_2, down4, x2=bottom)
+        # decoder (:481-486)
+        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, down3, x2=ops.upsample(bottom_2, 2)))
+        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, down2, x2=ops.upsample(up3, 2)))
+        up1 = cgr(m.decoder1.ConvBnRelu2, cgr(m.decoder1.ConvBnRelu1, down1, x2=ops.upsample(up2, 2)))
         outs = [ops.head(up1, m.outconv.weight, m.outconv.bias, 1)]
         heads = [(m.outconv, up1, 1)]
         if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
@@ -180,21 +183,21 @@ class _EquiUnetFn(torch.autograd.Function):
             return a if b is None else a + b
 
         d_up1 = extra(up1)
-        dcat1 = cbw(m.decoder1.ConvBnRelu1, cbw(m.decoder1.ConvBnRelu2, d_up1))
-        d_up2 = plus(ops.upsample_bwd(dcat1[..., f[0]:], 2), extra(up2))
-        dcat2 = cbw(m.decoder2.ConvBnRelu1, cbw(m.decoder2.ConvBnRelu2, d_up2))
-        d_up3 = plus(ops.upsample_bwd(dcat2[..., f[1]:], 2), extra(up3))
-        dcat3 = cbw(m.decoder3.ConvBnRelu1, cbw(m.decoder3.ConvBnRelu2, d_up3))
-        d_b2 = plus(ops.upsample_bwd(dcat3[..., f[2]:], 2), extra(bottom_2))
-        dcat4 = cbw(m.bottom_2, d_b2)
-        d_bottom = plus(dcat4[..., f[3]:], extra(bottom))
-        d_down4 = dcat4[..., :f[3]] + cbw(m.bottom.ConvBnRelu1, cbw(m.bottom.ConvBnRelu2, d_bottom))
+        d_skip1, d_u1 = cbw(m.decoder1.ConvBnRelu1, cbw(m.decoder1.ConvBnRelu2, d_up1))
+        d_up2 = plus(ops.upsample_bwd(d_u1, 2), extra(up2))
+        d_skip2, d_u2 = cbw(m.decoder2.ConvBnRelu1, cbw(m.decoder2.ConvBnRelu2, d_up2))
+        d_up3 = plus(ops.upsample_bwd(d_u2, 2), extra(up3))
+        d_skip3, d_u3 = cbw(m.decoder3.ConvBnRelu1, cbw(m.decoder3.ConvBnRelu2, d_up3))
+        d_b2 = plus(ops.upsample_bwd(d_u3, 2), extra(bottom_2))
+        d_skip4, d_bot = cbw(m.bottom_2, d_b2)
+        d_bottom = plus(d_bot, extra(bottom))
+        d_down4 = d_skip4 + cbw(m.bottom.ConvBnRelu1, cbw(m.bottom.ConvBnRelu2, d_bottom))
         d_p3 = cbw(m.encoder4.ConvBnRelu1, cbw(m.encoder4.ConvBnRelu2, d_down4))
-        d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=dcat3[..., :f[2]])
+        d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=d_skip3)
         d_p2 = cbw(m.encoder3.ConvBnRelu1, cbw(m.encoder3.ConvBnRelu2, d_down3))
-        d_down2 = ops.maxpool2_bwd(down2, d_p2, dx_skip=dcat2[..., :f[1]])
+        d_down2 = ops.maxpool2_bwd(down2, d_p2, dx_skip=d_skip2)
         d_p1 = cbw(m.encoder2.ConvBnRelu1, cbw(m.encoder2.ConvBnRelu2, d_down2))
-        d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=dcat1[..., :f[0]])
+        d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=d_skip1)
         cbw(m.encoder1.ConvBnRelu1, cbw(m.encoder1.ConvBnRelu2, d_down1), need_dx=False)
         ctx.tape = ctx.bufs = None
         return (None, None, None) + tuple(grads.get(i) for i in range(ctx.nparams))

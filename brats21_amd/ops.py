@@ -126,7 +126,7 @@ def conv_chunk(dtype, ksize, dil, c1, c2=0):
     return ck
 
 
-def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1):
+def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c1=None):
     """w: torch-layout [Cout, Cin, k, k, k] f32 parameter -> packed MFMA-fragment buffer.
     mode PACK_FWD: GEMM rows = Cout, K = Cin (zero-padded to cin_pad); PACK_DGRAD: rows = Cin slice,
     K = Cout, taps flipped."""
@@ -143,7 +143,8 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1):
         kdim, rows = cin_cnt, cout_w
     else:
         kdim, rows = cout_w, cin_cnt
-    ck = conv_chunk(dtype, k, dil, kdim)
+    # the K chunk must be the one the kernel will pick for the (possibly two-source) input it reads
+    ck = conv_chunk(dtype, k, dil, kdim) if (c1 is None or mode != PACK_FWD) else conv_chunk(dtype, k, dil, c1, kdim - c1)
     nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
     packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     _lib.check(_lib.lib().brats_conv3d_pack_weights(w.data_ptr(), packed.data_ptr(), code, mode, k, cout_w, cin_w,
@@ -151,42 +152,60 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1):
     return packed
 
 
+def split_granule(cout):
+    return _lib.lib().brats_conv3d_split_granule(cout)
+
+
 def tiles_per_sample(d, h, w):
     return _lib.lib().brats_conv3d_tiles_per_sample(d, h, w)
 
 
-def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False):
-    """y[N,D,H,W,cout] = conv(x) with weights from pack_weights().  Returns (y, stats|None) where
-    stats = [N, tiles, cout, 2] per-tile per-channel (sum, sum of squares) of the f32 result."""
+def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False, x2=None, split=None):
+    """y[N,D,H,W,cout] = conv([x | x2]) with weights from pack_weights().  Returns (y, stats|None) where
+    stats = [N, tiles, cout, 2] per-tile per-channel (sum, sum of squares) of the f32 result.
+    x2: optional second input (virtual concat, no torch.cat).  split: write output channels
+    [0, split) and [split, cout) to two dense tensors (returns (y, y2) as y)."""
     ptr, c, p = _desc(x)
     n, d, h, w, _ = x.shape
-    if out is None:
+    ptr2, c2, p2 = (None, 0, 0)
+    if x2 is not None:
+        ptr2, c2, p2 = _desc(x2)
+    y2 = None
+    if split is not None:
+        out = new_act(n, d, h, w, split, x.dtype, x.device)
+        y2 = new_act(n, d, h, w, cout - split, x.dtype, x.device)
+    elif out is None:
         out = new_act(n, d, h, w, cout, x.dtype, x.device)
     optr, oc, op = _desc(out)
-    if oc != cout or out.dtype != x.dtype:
+    if (y2 is None and oc != cout) or out.dtype != x.dtype:
         raise _lib.BratsHipError("conv3d: bad output tensor")
     stats = None
     if want_stats:
         stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
-    with _span("conv_igemm", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
-        _lib.check(_lib.lib().brats_conv3d_fwd(ptr, c, p, None, 0, 0, packed_w.data_ptr(), _f32(bias), optr, op,
+    with _span("conv_igemm", c + c2, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_fwd(ptr, c, p, ptr2, c2, p2, packed_w.data_ptr(), _f32(bias), optr, op,
+                                               y2.data_ptr() if y2 is not None else None,
+                                               (cout - split) if y2 is not None else 0, split or 0,
                                                stats.data_ptr() if stats is not None else None, _code(x.dtype), ksize,
                                                dil, n, d, h, w, cout, _stream()), "conv3d_fwd")
-    return out, stats
+    return ((out, y2) if y2 is not None else out), stats
 
 
-def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False):
-    """dW [cout, cin, k,k,k] f32 (and dbias) from the layer input x and the output gradient dy."""
+def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
+    """dW [cout, cin (+cin2), k,k,k] f32 (and dbias) from the layer input [x | x2] and the output gradient dy."""
     ptr, c, p = _desc(x)
+    ptr2, c2, p2 = (None, 0, 0)
+    if x2 is not None:
+        ptr2, c2, p2 = _desc(x2)
     dptr, cout, dp = _desc(dy)
     n, d, h, w, _ = x.shape
     code = _code(x.dtype)
-    nbytes = _lib.lib().brats_conv3d_wgrad_ws_bytes(code, ksize, n, d, h, w, c, 0, cout)
+    nbytes = _lib.lib().brats_conv3d_wgrad_ws_bytes(code, ksize, n, d, h, w, c, c2, cout)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty((cout, c, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, c + c2, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
-    with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
-        _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, None, 0, 0, dptr, dp, ws.data_ptr(), dw.data_ptr(),
+    with _span("conv_wgrad", c + c2, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, ptr2, c2, p2, dptr, dp, ws.data_ptr(), dw.data_ptr(),
                                                  db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
                                                  cout, _stream()), "conv3d_wgrad")
     return dw, db

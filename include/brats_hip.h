@@ -61,8 +61,14 @@ int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2);
 int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize,
                               int cout_w, int cin_w, int cin_off, int cin_cnt, int ck, brats_stream_t s);
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
+/* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
+int brats_conv3d_split_granule(int cout);
+/* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
+ * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2
+ * as two dense tensors in one launch. */
 int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
-                     const void* packed_w, const float* bias, void* y, int ypitch, float* stats,
+                     const void* packed_w, const float* bias, void* y, int ypitch,
+                     void* y2, int y2pitch, int ysplit, float* stats,
                      int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                      brats_stream_t s);
 /* wgrad: dW[co][ci][tap] = sum_v dy[v][co] * x[v + off(tap)][ci]  (x = virtual concat as above).

@@ -34,7 +34,7 @@ def test_host_side_queries_and_argument_errors():
     assert l.brats_conv3d_packed_bytes(_lib.BF16, 3, 48, 48, 48) == 1 * 41 * 3 * 64 * 16
     assert l.brats_conv3d_packed_bytes(_lib.F32, 3, 16, 16, 16) == 1 * 27 * 1 * 64 * 16
     # NULL pointers are rejected with an error string, never dereferenced
-    rc = l.brats_conv3d_fwd(None, 8, 8, None, 0, 0, None, None, None, 8, None, _lib.BF16, 3, 1, 1, 8, 8, 8, 8, None)
+    rc = l.brats_conv3d_fwd(None, 8, 8, None, 0, 0, None, None, None, 8, None, 0, 0, None, _lib.BF16, 3, 1, 1, 8, 8, 8, 8, None)
     assert rc == -1 and b"conv3d_fwd" in l.brats_last_error()
     rc = l.brats_maxpool2_fwd(None, 8, None, 8, _lib.BF16, 1, 8, 8, 8, 8, 0, None)
     assert rc == -1
