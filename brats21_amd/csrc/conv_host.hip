@@ -1,5 +1,6 @@
 // C-ABI entry points for the implicit-GEMM convolution: weight packing + forward/dgrad launch.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "conv_igemm.hpp"
 
 static thread_local char g_err[512] = "";
@@ -15,6 +16,9 @@ extern "C" int brats_abi_version(void) { return 1; }
 // ---- chunk selection ---------------------------------------------------------------------------
 extern "C" int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2) {
   (void)ksize; (void)dil;
+  static int pref16 = -1;  // experiment switch: smaller K chunks -> smaller LDS tile -> more workgroups per CU
+  if (pref16 < 0) { const char* e = getenv("BRATS_CONV_CK16"); pref16 = e ? atoi(e) : 0; }
+  if (pref16 && dtype == BRATS_BF16 && c1 % 16 == 0 && (c2 <= 0 || c2 % 16 == 0)) return 16;
   static const int bf[] = {48, 32, 16, 8};
   static const int f32[] = {16, 8, 4};
   const int* cand = dtype == BRATS_BF16 ? bf : f32;

@@ -402,7 +402,8 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
   return 0;
 }
 
-// backward pass 1: red[n][c] = { sum_v dz, sum_v dz * x*sigmoid(x) }
+// backward pass 1: red[n][c] = { sum_v dz, sum_v dz * x*sigmoid(x), sum_v dz * d/dx[x*sigmoid(x)] }
+// (the third sum gives the bias gradient of the preceding convolution without another pass over dx)
 template <typename T>
 __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                           float* __restrict__ red, int voxels, int C) {
@@ -411,9 +412,9 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
   const int n = blockIdx.y;
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
-  float a1[VW], a2[VW];
+  float a1[VW], a2[VW], a3[VW];
 #pragma unroll
-  for (int j = 0; j < VW; ++j) a1[j] = a2[j] = 0.f;
+  for (int j = 0; j < VW; ++j) a1[j] = a2[j] = a3[j] = 0.f;
   if (myvl < vl_n) {
     const T* dzb = dz + (size_t)n * voxels * dzpitch;
     const T* xb = x + (size_t)n * voxels * xpitch;
@@ -423,24 +424,27 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
       Vec<T, VW>::load(xb + vox * xpitch + c0, xx);
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
+        const float sg = sigmoidf_(xx[j]);
         a1[j] += g[j];
-        a2[j] += g[j] * xx[j] * sigmoidf_(xx[j]);
+        a2[j] += g[j] * xx[j] * sg;
+        a3[j] += g[j] * sg * (1.f + xx[j] * (1.f - sg));
       }
     }
   }
-  float* scr = sm;  // [vl_n][C][2]
+  float* scr = sm;  // [vl_n][C][3]
   if (myvl < vl_n) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      scr[(myvl * C + c0 + j) * 2] = a1[j];
-      scr[(myvl * C + c0 + j) * 2 + 1] = a2[j];
+      scr[(myvl * C + c0 + j) * 3] = a1[j];
+      scr[(myvl * C + c0 + j) * 3 + 1] = a2[j];
+      scr[(myvl * C + c0 + j) * 3 + 2] = a3[j];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
     float t = 0.f;
-    for (int l = 0; l < vl_n; ++l) t += scr[l * C * 2 + i];
-    atomicAdd(red + (size_t)n * C * 2 + i, t);
+    for (int l = 0; l < vl_n; ++l) t += scr[l * C * 3 + i];
+    atomicAdd(red + (size_t)n * C * 3 + i, t);
   }
 }
 
@@ -449,8 +453,8 @@ template <typename T>
 __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                          const float* __restrict__ red, T* __restrict__ dx, int dxpitch,
-                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int voxels, int C,
-                                         int groups) {
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta, const double* __restrict__ chan,
+                                         float* __restrict__ dconvbias, int N, int voxels, int C, int groups) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   float* gr = sm;          // [C] gamma * r
@@ -462,7 +466,7 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
     const int g = c / cpg;
     const float r = mean_rstd[(n * groups + g) * 2 + 1];
     float A = 0.f;
-    for (int j = 0; j < cpg; ++j) A += gamma[g * cpg + j] * red[((size_t)n * C + g * cpg + j) * 2 + 1];
+    for (int j = 0; j < cpg; ++j) A += gamma[g * cpg + j] * red[((size_t)n * C + g * cpg + j) * 3 + 1];
     gr[c] = gamma[c] * r;
     mu[c] = mean_rstd[(n * groups + g) * 2];
     kk[c] = r * r * r * A / Mm1;
@@ -470,12 +474,20 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
   if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float b = 0.f, g = 0.f;
+      float dbc = 0.f;  // sum_v dx = bias gradient of the convolution that produced x
       for (int m = 0; m < N; ++m) {
-        b += red[((size_t)m * C + c) * 2];
-        g += red[((size_t)m * C + c) * 2 + 1] * mean_rstd[(m * groups + c / cpg) * 2 + 1];
+        const int gg = c / cpg;
+        const float r = mean_rstd[(m * groups + gg) * 2 + 1], mean = mean_rstd[(m * groups + gg) * 2];
+        b += red[((size_t)m * C + c) * 3];
+        g += red[((size_t)m * C + c) * 3 + 1] * r;
+        float A = 0.f;
+        for (int j = 0; j < cpg; ++j) A += gamma[gg * cpg + j] * red[((size_t)m * C + gg * cpg + j) * 3 + 1];
+        const float sumx = chan ? (float)chan[((size_t)m * C + c) * 2] : 0.f;
+        dbc += gamma[c] * r * red[((size_t)m * C + c) * 3 + 2] - r * r * r * A / Mm1 * (sumx - (float)voxels * mean);
       }
       dbeta[c] = b;
       dgamma[c] = g;
+      if (dconvbias) dconvbias[c] = dbc;
     }
   }
   __syncthreads();
@@ -502,31 +514,33 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
 }
 
 extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
-                                 const float* gamma, void* dx, int dxpitch, float* red, float* dgamma, float* dbeta, int dtype,
-                                 int N, int voxels, int C, int groups, brats_stream_t s) {
+                                 const float* gamma, void* dx, int dxpitch, float* red, float* dgamma, float* dbeta,
+                                 const double* chan_sums, float* dconvbias, int dtype, int N, int voxels, int C, int groups,
+                                 brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !x || !dx || !red || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: null pointer");
+  if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: dconvbias needs the forward per-channel sums");
   if (C % vw || C % groups || dzpitch % vw || xpitch % vw || dxpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: C=%d / pitches must be multiples of %d", C, vw);
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * C * 2 * sizeof(float), st);
+  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * C * 3 * sizeof(float), st);
   if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "evonorm_bwd: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
   dim3 g1((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
-  const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
+  const size_t lds1 = (size_t)(vl * C * 3) * sizeof(float);
   dim3 g2(stream_grid((size_t)voxels * cv, 256), N);
   const size_t lds2 = (size_t)3 * C * sizeof(float);
   if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
                        xpitch, red, voxels, C);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, N, voxels, C, groups);
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups);
   } else {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)x,
                        xpitch, red, voxels, C);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
-                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, N, voxels, C, groups);
+                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups);
   }
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -103,11 +103,12 @@ def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
     return y, stats, ("direct", x, dil)
 
 
-def _conv_any_bwd(cx, conv, saved, dy, need_dx=True):
+def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     kind, xin, dil = saved
     w = conv.weight
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-    db = ops.channel_dot(dy).sum(0)
+    if db is None:
+        db = ops.channel_dot(dy).sum(0)
     if kind == "col":
         dw1 = ops.wgrad_1x1(xin, dy)  # [cout, 27*cin] in (tap, ci) order
         cx.put(conv.weight, dw1.view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3).contiguous())
@@ -132,17 +133,17 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True):
 def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
     y, stats, saved = _conv_any_fwd(cx, conv, x, 1, True)
     n, d, h, w, c = y.shape
-    mr = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
+    mr, chan = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
     z, cs = ops.evonorm(y, mr, _flat(evo.gamma), _flat(evo.beta), 8, out=out, want_chansum=want_chansum)
-    return z, cs, (conv, evo, saved, y, mr)
+    return z, cs, (conv, evo, saved, y, mr, chan)
 
 
 def _conv_evo_bwd(cx, rec, dz, need_dx=True):
-    conv, evo, saved, y, mr = rec
-    dy, dgamma, dbeta = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8)
+    conv, evo, saved, y, mr, chan = rec
+    dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan)
     cx.put(evo.gamma, dgamma)
     cx.put(evo.beta, dbeta)
-    return _conv_any_bwd(cx, conv, saved, dy, need_dx)
+    return _conv_any_bwd(cx, conv, saved, dy, need_dx, db=dcb)
 
 
 def _block_fwd(cx, blk, x, out=None):

@@ -333,11 +333,12 @@ def head_bwd(x, weight, dout, scale=1, want_dx=True):
 
 # ------------------------------------------------------------------------------------------ EvoNorm-S0 / SE helpers
 def evonorm_finalize(stats, n, c, groups, voxels, eps=1e-5):
+    """Returns (mean_rstd [N, groups, 2], chan [N, C, 2] f64 per-channel sums kept for the backward)."""
     mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)
     chan = torch.empty((n, c, 2), dtype=torch.float64, device=stats.device)
     _lib.check(_lib.lib().brats_evonorm_finalize(stats.data_ptr(), stats.shape[1], n, c, groups, float(voxels), eps,
                                                  mean_rstd.data_ptr(), chan.data_ptr(), _stream()), "evonorm_finalize")
-    return mean_rstd
+    return mean_rstd, chan
 
 
 def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False):
@@ -354,18 +355,22 @@ def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False):
     return out, cs
 
 
-def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8):
+def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None):
+    """Returns (dy, dgamma, dbeta, dconvbias|None); dconvbias = sum_v dy needs the forward's `chan` sums."""
     dzp, c, dzpitch = _desc(dz)
     yp, _, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
     dy = new_act(n, d, h, w, c, y.dtype, y.device)
-    red = torch.empty((n, c, 2), dtype=torch.float32, device=y.device)
+    red = torch.empty((n, c, 3), dtype=torch.float32, device=y.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    dcb = torch.empty(c, dtype=torch.float32, device=y.device) if chan is not None else None
     _lib.check(_lib.lib().brats_evonorm_bwd(dzp, dzpitch, yp, ypitch, mean_rstd.data_ptr(), _f32(gamma), dy.data_ptr(), c,
-                                            red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _code(y.dtype), n,
+                                            red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                            chan.data_ptr() if chan is not None else None,
+                                            dcb.data_ptr() if dcb is not None else None, _code(y.dtype), n,
                                             d * h * w, c, groups, _stream()), "evonorm_bwd")
-    return dy, dgamma, dbeta
+    return dy, dgamma, dbeta, dcb
 
 
 def channel_dot(a, b=None):

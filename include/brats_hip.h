@@ -108,10 +108,12 @@ int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int 
 int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma,
                       const float* beta, void* z, int zpitch, float* chansum, int dtype, int N,
                       int voxels, int C, int groups, brats_stream_t s);
+/* chan_sums = the f64 [N][C][2] per-channel sums brats_evonorm_finalize left in chan_ws; with it the
+ * kernel also emits dconvbias[c] = sum_v dx (bias gradient of the producing conv) at no extra pass. */
 int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
-                      const float* gamma, void* dx, int dxpitch, float* red /*[N][C][2]*/,
-                      float* dgamma, float* dbeta, int dtype, int N, int voxels, int C, int groups,
-                      brats_stream_t s);
+                      const float* gamma, void* dx, int dxpitch, float* red /*[N][C][3]*/,
+                      float* dgamma, float* dbeta, const double* chan_sums, float* dconvbias,
+                      int dtype, int N, int voxels, int C, int groups, brats_stream_t s);
 /* ---- squeeze-excite helpers (MONAI ResidualSELayer, equiunet2021.py:204-205): per-(n,channel)
  * reductions over voxels and per-(n,channel) scale(+add) passes; the two tiny FC layers stay in torch. */
 int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,

@@ -42,12 +42,13 @@ def test_evonorm_fwd_bwd_matches_reference_golden(golden_dir):
     xd = _to_ndhwc(x)
     y, stats = ops.conv3d(xd, ops.pack_weights(w, torch.float32, ops.PACK_FWD), 16, 1, 1, want_stats=True)
     torch.testing.assert_close(_from_ndhwc(y), x, atol=1e-6, rtol=0)
-    mr = ops.evonorm_finalize(stats, 1, 16, 8, 12 ** 3)
+    mr, chan = ops.evonorm_finalize(stats, 1, 16, 8, 12 ** 3)
     z, cs = ops.evonorm(y, mr, gamma, beta, 8, want_chansum=True)
     np.testing.assert_allclose(_from_ndhwc(z).numpy(), g["evo_y"], atol=2e-5)
     np.testing.assert_allclose(cs.cpu().numpy()[0], g["evo_y"].sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
     go = synth.closed_form("evo_go", (1, 16, 12, 12, 12))
-    dx, dgamma, dbeta = ops.evonorm_bwd(_to_ndhwc(go), y, mr, gamma, 8)
+    dx, dgamma, dbeta, dcb = ops.evonorm_bwd(_to_ndhwc(go), y, mr, gamma, 8, chan=chan)
+    np.testing.assert_allclose(dcb.cpu().numpy(), g["evo_dx"].sum((0, 2, 3, 4)), rtol=1e-3, atol=2e-3)  # = conv bias gradient
     np.testing.assert_allclose(_from_ndhwc(dx).numpy(), g["evo_dx"], atol=2e-5)
     np.testing.assert_allclose(dgamma.cpu().numpy(), g["evo_dgamma"].ravel(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(dbeta.cpu().numpy(), g["evo_dbeta"].ravel(), rtol=1e-4, atol=1e-3)

@@ -135,3 +135,41 @@ def test_cpu_input_fails_loudly():
     m = _model(8)
     with pytest.raises(BratsHipError):
         m(torch.zeros(1, 4, 16, 16, 16))
+
+
+@pytest.mark.parametrize("size,batch", [((24, 40, 16), 1), ((16, 16, 48), 3)])
+def test_equiunet_ragged_volumes_and_batches(size, batch):
+    """Non-cubic volumes (partial tiles in every dimension of the 4x4x16 tiling) and odd batch sizes, f32 mode,
+    forward + gradients vs the CPU oracle."""
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(8))
+    m = _model(8, sd, "fp32").train()
+    x = synth.random_image(batch, 4, size, seed=11)
+    t = synth.nested_spheres(batch, size)
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = unet.equiunet_forward(sd_ref, x)
+    loss_ref = unet.deep_supervision_loss(out_ref, t)
+    loss_ref.backward()
+    out, deeps = m(x.cuda())
+    assert float((out.detach().cpu() - out_ref[0].detach()).abs().max()) < LOGIT_ATOL
+    for d, dr in zip(deeps, out_ref[1]):
+        assert float((d.detach().cpu() - dr.detach()).abs().max()) < LOGIT_ATOL
+    loss = unet.deep_supervision_loss((out, deeps), t.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4
+    worst = max(float((p.grad.cpu() - sd_ref[k].grad).norm() / (sd_ref[k].grad.norm() + 1e-12)) for k, p in m.named_parameters())
+    assert worst < 1e-2, worst
+
+
+def test_state_dict_roundtrip_and_eval_fast_path():
+    """load_state_dict(strict) from reference-shaped tensors, eval() without deep heads, determinism."""
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(8))
+    m = _model(8, sd, "fp32").eval()
+    for k, v in m.state_dict().items():
+        torch.testing.assert_close(v.cpu(), sd[k])
+    x = synth.random_image(1, 4, (16, 16, 16)).cuda()
+    with torch.no_grad():
+        a, deeps = m(x)
+        m.skip_deep_heads_in_eval = True
+        b, none = m(x)
+    assert len(deeps) == 4 and len(none) == 0
+    assert torch.equal(a, b)  # bitwise reproducible (no float atomics on the logits path)
