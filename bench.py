@@ -63,34 +63,35 @@ def inference_bench(model, dev, args):
     hipGraph-replayed bf16 patch step without the deep heads, fused de-augment + sigmoid + accumulate."""
     import itertools
     from brats21_amd import synth
-    from brats21_amd.inferers import GraphedPredictor, sliding_window_inference, tta_predict
+    from brats21_amd.evaluate import Evaluator
     from brats21_amd.tta.base import SignedPerm, Transformer
     model.eval()
     model.skip_deep_heads_in_eval = True
-    prec = model.precision
-    model.precision = args.precision
     flips = [Transformer(SignedPerm((0, 1, 2), f), SignedPerm((0, 1, 2), f)) for f in itertools.product([False, True], repeat=3)]
-    vol = synth.random_image(1, 4, (240, 240, 160), seed=99, device=dev)
-    graphed = GraphedPredictor(model)
-
-    def predictor(x):
-        return sliding_window_inference(x, (128, 128, 128), 1, graphed, overlap=0.5)
-
+    vol = synth.random_image(1, 4, (240, 240, 155), seed=99, device=dev)
+    vol = vol * (synth.nested_spheres(1, (240, 240, 155), device=dev)[:, 0:1] > 0)  # zero background outside the "brain"
+    ev = Evaluator(model, tta_transforms=flips, sliding_window_size=(128, 128, 128), sw_batch_size=1, overlap=0.5,
+                   k_divisible=8, amp=args.precision == "bf16")
     with torch.no_grad():
-        tta_predict(vol, predictor, flips[:1])  # capture + warm-up (18 windows)
+        Evaluator(model, tta_transforms=flips[:1], sliding_window_size=(128, 128, 128), overlap=0.5,
+                  amp=args.precision == "bf16", use_graph=False)(vol)  # warm-up outside the graph (allocator, lazy init)
+        ev.tta = flips[:1]
+        ev(vol)  # graph capture + 18 windows
+        ev.tta = flips
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        prob = tta_predict(vol, predictor, flips)
+        out = ev(vol, want_labels=True)
         torch.cuda.synchronize()
         sec = time.perf_counter() - t0
-    model.precision = prec
     model.train()
+    assert tuple(out["labels"].shape) == (1, 1, 240, 240, 155)
     fwd_tf = 144 * (1995.7e9 if args.model == "equiunet" else 1689.8e9) / sec / 1e12
     return {"metric": "inference volumes/sec", "value": round(1.0 / sec, 4), "unit": "volumes/s",
-            "config": "4x240x240x155(->160), window 128^3, overlap 0.5, 18 windows x 8-flip TTA = 144 patch forwards, "
-                      f"{args.precision}, hipGraph patch step", "s_per_volume": round(sec, 3),
+            "config": "4x240x240x155 padded to 160 (learning/engine.py:217), window 128^3, overlap 0.5, 18 windows x 8-flip TTA "
+                      f"= 144 patch forwards, {args.precision}, hipGraph patch step, on-GPU mean + threshold + background "
+                      "removal + BraTS labels + crop", "s_per_volume": round(sec, 3),
             "ms_per_patch_forward": round(sec / 144 * 1e3, 2), "TFLOPs": round(fwd_tf, 1),
-            "mean_prob": round(float(prob.mean()), 5)}
+            "foreground_fraction": round(float((out["labels"] != 0).float().mean()), 5)}
 
 
 def main():
@@ -107,13 +108,18 @@ def main():
     ap.add_argument("--no-infer", action="store_true", help="skip the sliding-window + TTA inference measurement")
     ap.add_argument("--torch-dice", dest="fused_dice", action="store_false",
                     help="use the PyTorch Dice loss (reference path) instead of the fused HIP Dice passes")
+    ap.add_argument("--optimizer", default="ranger", choices=["ranger", "adam"],
+                    help="ranger = the reference's default (--optimizer ranger, src/arguments_train.py:120), fused HIP step")
+    ap.add_argument("--use-gc", action="store_true", help="Ranger gradient centralisation (reference default: off)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
     args = ap.parse_args()
 
     from brats21_amd import get_model, ops, LIB_PATH
     from brats21_amd import synth
     from brats21_amd.ddp import GradientBuckets, init_process_group_from_env
-    from brats21_amd.losses import DiceLoss, deep_supervision_loss, fused_deep_supervision_dice
+    from brats21_amd.engine import TrainStep
+    from brats21_amd.losses import DiceLoss
+    from brats21_amd.optim import Ranger2020
 
     assert os.path.exists(LIB_PATH), "HIP extension missing"
     rank, world, local = init_process_group_from_env()
@@ -126,23 +132,21 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         model = get_model(ns).to(dev).train()
     crit = DiceLoss().to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
+    if args.optimizer == "ranger":  # src/definer.py:316-331 + the CLI defaults lr 1e-4, weight_decay 1e-5
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = Ranger2020(model.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5,
+                             weight_decay=1e-5, use_gc=args.use_gc)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
     buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None
     size = (args.patch,) * 3
     x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
     t = synth.nested_spheres(args.batch, size, device=dev)
     use_amp = args.precision == "bf16"
+    train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets)
 
     def step():
-        model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp):
-            out = model(x)
-            loss = fused_deep_supervision_dice(out, t) if args.fused_dice else deep_supervision_loss(crit, out, t)[0]
-        loss.backward()
-        if buckets is not None:
-            buckets.finish()
-        opt.step()
-        return loss
+        return train_step(x, t)
 
     for _ in range(args.warmup):
         step()
@@ -200,7 +204,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.model} width={args.width}, batch={args.batch}/GPU of 4x{args.patch}^3 synthetic patches, "
-                               f"fwd + deep-supervision Dice + bwd + Adam (BASELINE.json configs[1])",
+                               f"fwd + deep-supervision Dice + bwd + {args.optimizer} (BASELINE.json configs[1])",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
         "roofline": roofline,
     }

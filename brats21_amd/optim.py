@@ -1,0 +1,133 @@
+"""Ranger2020 with the reference's constructor and state layout (learning/optimizer.py:62-135), stepped by
+two HIP launches over all parameters (csrc/ranger.hip) instead of the reference's per-tensor Python loop of
+~15 small torch ops each (:145-253).
+
+``state_dict()`` / ``load_state_dict()`` are the reference's: per parameter ``step``, ``exp_avg``,
+``exp_avg_sq``, ``slow_buffer`` -- so Engine.resume (learning/engine.py:511-525) restores either way.
+"""
+import math
+
+import numpy as np
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import _lib
+
+_REC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("slow", "<u8"),
+                 ("numel", "<i8"), ("rowlen", "<i4"), ("row_base", "<i4"), ("neg_step", "<f4"), ("wd", "<f4"),
+                 ("flags", "<i4"), ("reserved", "<i4")])  # == brats_ranger_tensor (include/brats_hip.h)
+
+
+def radam_step_size(step, beta1, beta2, n_sma_threshold):
+    """learning/optimizer.py:198-214 -> (N_sma > threshold, step_size)."""
+    beta2_t = beta2 ** step
+    n_max = 2 / (1 - beta2) - 1
+    n_sma = n_max - 2 * step * beta2_t / (1 - beta2_t)
+    if n_sma > n_sma_threshold:
+        return True, math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / (
+            1 - beta1 ** step)
+    return False, 1.0 / (1 - beta1 ** step)
+
+
+class Ranger2020(Optimizer):
+    def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=0,
+                 use_gc=True, use_gcnorm=False, normloss=False, normloss_factor=1e-4, gc_conv_only=False, gc_loc=True):
+        if not 0.0 <= alpha <= 1.0:
+            raise ValueError(f'Invalid slow update rate: {alpha}')
+        if not 1 <= k:
+            raise ValueError(f'Invalid lookahead steps: {k}')
+        if not lr > 0:
+            raise ValueError(f'Invalid Learning Rate: {lr}')
+        if not eps > 0:
+            raise ValueError(f'Invalid eps: {eps}')
+        if use_gcnorm or normloss or not gc_loc:
+            raise NotImplementedError("brats21_amd.optim.Ranger2020 implements the reference's default configuration "
+                                      "(use_gcnorm=False, normloss=False, gc_loc=True)")
+        defaults = dict(lr=lr, alpha=alpha, k=k, betas=betas, N_sma_threshhold=N_sma_threshhold, eps=eps,
+                        weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.N_sma_threshhold, self.alpha, self.k = N_sma_threshhold, alpha, k
+        self.use_gc, self.gc_conv_only, self.eps = use_gc, gc_conv_only, eps
+        self._plans = {}
+
+    # ------------------------------------------------------------------------------------------ static plan
+    def _plan(self, gi, active, dev):
+        """chunk / row tables for the set of parameters that have a gradient (static per model)."""
+        key = (gi, tuple(id(p) for p in active))
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        chunk = _lib.lib().brats_ranger_chunk()
+        chunks, rows, rowlen, rowbase, nrows = [], [], [], [], 0
+        for t, p in enumerate(active):
+            n = p.numel()
+            chunks.append(np.stack([np.full((n + chunk - 1) // chunk, t, np.int32),
+                                    np.arange((n + chunk - 1) // chunk, dtype=np.int32)], 1))
+            gc = self.use_gc and p.dim() > (3 if self.gc_conv_only else 1)
+            if gc:
+                r = p.shape[0]
+                rows.append(np.stack([np.full(r, t, np.int32), np.arange(r, dtype=np.int32)], 1))
+                rowlen.append(n // r)
+                rowbase.append(nrows)
+                nrows += r
+            else:
+                rowlen.append(0)
+                rowbase.append(0)
+        plan = {
+            "chunks": torch.from_numpy(np.concatenate(chunks)).to(dev),
+            "rows": torch.from_numpy(np.concatenate(rows)).to(dev) if rows else None,
+            "means": torch.empty(max(nrows, 1), dtype=torch.float32, device=dev),
+            "nrows": nrows, "rowlen": rowlen, "rowbase": rowbase,
+        }
+        self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------------------------------ step
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = _lib.lib()
+        for gi, group in enumerate(self.param_groups):
+            active = [p for p in group["params"] if p.grad is not None]
+            if not active:
+                continue
+            dev = active[0].device
+            if dev.type != "cuda":
+                raise _lib.BratsHipError("brats21_amd.optim.Ranger2020 steps on the GPU only (no CPU fallback)")
+            beta1, beta2 = group["betas"]
+            lr, wd, k = group["lr"], group["weight_decay"], group["k"]
+            plan = self._plan(gi, active, dev)
+            rec = np.zeros(len(active), _REC)
+            keep = []
+            for t, p in enumerate(active):
+                g = p.grad
+                if g.is_sparse:
+                    raise RuntimeError('Ranger optimizer does not support sparse gradients')
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                    raise _lib.BratsHipError("Ranger2020: parameters must be contiguous f32 tensors on one GPU")
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                    keep.append(g)
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    state['slow_buffer'] = p.detach().clone(memory_format=torch.contiguous_format)
+                else:
+                    for name in ('exp_avg', 'exp_avg_sq', 'slow_buffer'):  # after load_state_dict / .cpu() round trips
+                        s = state[name]
+                        if s.dtype != torch.float32 or s.device != dev or not s.is_contiguous():
+                            state[name] = s.to(device=dev, dtype=torch.float32).contiguous()
+                state['step'] = int(state['step']) + 1
+                adaptive, step_size = radam_step_size(state['step'], beta1, beta2, self.N_sma_threshhold)
+                rec[t] = (p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
+                          state['slow_buffer'].data_ptr(), p.numel(), plan["rowlen"][t], plan["rowbase"][t],
+                          -step_size * lr, wd, (1 if adaptive else 0) | (2 if state['step'] % k == 0 else 0), 0)
+            table = torch.from_numpy(rec.view(np.uint8)).to(dev, non_blocking=False)
+            _lib.check(lib.brats_ranger_step(
+                table.data_ptr(), len(active), plan["chunks"].data_ptr(), plan["chunks"].shape[0],
+                plan["rows"].data_ptr() if plan["rows"] is not None else None, plan["nrows"], plan["means"].data_ptr(),
+                beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha, torch.cuda.current_stream().cuda_stream),
+                "ranger_step")
+            table.record_stream(torch.cuda.current_stream())
+        return None

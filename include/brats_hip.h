@@ -184,6 +184,53 @@ int brats_dice_stats(const float* logits, const float* target, float* sums /*[K]
 int brats_dice_grad(const float* logits, const float* target, const float* coef /*[K][2]*/,
                     float* dlogits, int N, int K, size_t voxels, brats_stream_t s);
 
+/* ---- post-forward chain of Engine.evaluate on the GPU.  NCDHW f32.
+ * pad_crop: dst[p][z][y][x] = src[p][z-oz][y-oy][x-ox] inside the source box, `fill` outside; positive
+ *   offsets = shape_to_divisible (utils/transforms.py:482-512, o = p_b), negative = shape_to_original
+ *   (utils/transforms.py:515-533, o = -p_b).  planes = N*C.
+ * post_threshold: seg = (prob*scale >= thresh) * any_c(img != 0): the mean over models x TTA passes
+ *   (learning/engine.py:249, scale = 1/passes), AsDiscrete (src/definer.py:700-703) and
+ *   remove_background_voxels (utils/transforms.py:536-550) in one pass; img may be NULL (no masking);
+ *   labels (optional uint8 [N][voxels], K must be 3 = TC/WT/ET) = ConvertToBratsClassesBasedOnMultiChannel
+ *   + ChangeLabel3To4 (utils/transforms.py:169-206).
+ * overlap_counts: counts[nk] = {#(pred&target), #pred, #target} (uint64, exact) -- the sums behind the
+ *   hard Dice / confusion metrics of utils/metrics.py:35-67. */
+int brats_pad_crop(const float* src, float* dst, int planes, int sd, int sh, int sw, int dd, int dh,
+                   int dw, int oz, int oy, int ox, float fill, brats_stream_t s);
+int brats_post_threshold(const float* prob, const float* img, float* seg, uint8_t* labels, int N, int K,
+                         int C, size_t voxels, float scale, float thresh, brats_stream_t s);
+int brats_overlap_counts(const float* pred, const float* target, unsigned long long* counts, int NK,
+                         size_t voxels, brats_stream_t s);
+
+/* ---- multi-tensor Ranger2020 step (learning/optimizer.py:136-255: RAdam with the
+ * N_sma threshold, gradient centralisation :11-20, lookahead :233-240).  All tensors f32, contiguous.
+ * The host fills one record per parameter (device array `table`); per-step scalars that the reference
+ * derives from state['step'] in Python (:198-214) are host-computed per tensor:
+ *   neg_step = -step_size * lr ; flags bit0 = N_sma > threshold (adaptive branch), bit1 = lookahead
+ *   step (step % k == 0); rowlen > 0 enables gradient centralisation over rows of `rowlen` elements
+ *   (= numel / shape[0]) with the tensor's rows stored at row_means[row_base ...].
+ * chunks: device int32 [nchunks][2] = (tensor index, chunk index), chunk = brats_ranger_chunk()
+ * elements; rows: device int32 [nrows][2] = (tensor index, row) for every centralised row. */
+typedef struct {
+  void* param;
+  const void* grad;
+  void* exp_avg;
+  void* exp_avg_sq;
+  void* slow;
+  long long numel;
+  int rowlen;
+  int row_base;
+  float neg_step;
+  float wd;
+  int flags;
+  int reserved;
+} brats_ranger_tensor;
+int brats_ranger_chunk(void);
+int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int* chunks, int nchunks,
+                      const int* rows, int nrows, float* row_means, float beta1, float beta2,
+                      float one_minus_beta1, float one_minus_beta2, float eps, float alpha,
+                      brats_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,6 +218,17 @@ def install():
         _mod("monai.utils", BlendMode=_BlendMode, PytorchPadMode=_PytorchPadMode,
              fall_back_tuple=_fall_back_tuple)
         _mod("monai.losses", DiceLoss=_DiceLoss)
+        # utils/transforms.py imports these at module level; the functions the golden generator calls
+        # (shape_to_divisible / shape_to_original / remove_background_voxels / the two label
+        # converters) use none of them beyond `Transform` as an empty base class.
+        sys.modules["monai.transforms"].Transform = type("Transform", (), {})
+        sys.modules["monai.transforms"].MapTransform = type("MapTransform", (), {})
+        sys.modules["monai.transforms"].BorderPad = type("BorderPad", (), {})
+        _mod("monai.config", DtypeLike=object, KeysCollection=object)
+        for absent in ("SimpleITK", "skimage", "skimage.morphology"):
+            if absent not in sys.modules:
+                _mod(absent)
+        sys.modules["skimage"].morphology = sys.modules["skimage.morphology"]
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

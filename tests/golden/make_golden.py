@@ -180,6 +180,80 @@ def inference_fixtures():
     print("inference.npz", {k: getattr(v, "shape", None) for k, v in res.items()})
 
 
+def post_fixtures():
+    """Post-forward chain of Engine.evaluate (learning/engine.py:205-285) from the reference's own
+    utils/transforms.py.  numpy >= 1.24 dropped the `np.int` alias the reference still uses, and
+    remove_background_voxels calls `.to(img.get_device())`, which only resolves for CUDA tensors:
+    both are environment shims applied around the unchanged reference functions."""
+    np.int = int
+    from utils.transforms import (shape_to_divisible, shape_to_original, remove_background_voxels,  # noqa: E402
+                                  ConvertToBratsClassesBasedOnMultiChannel, ChangeLabel3To4)
+    res = {}
+    rng = np.random.RandomState(2021)
+    for tag, size, k, min_shape in (("a", (13, 10, 7), 8, None), ("b", (16, 9, 24), 8, None),
+                                    ("c", (5, 6, 7), 4, 12)):
+        x = synth.closed_form("pad" + tag, (2, 4) + size)
+        y, p_b, p_a = shape_to_divisible(x, k=k, min_shape=min_shape)
+        res[f"div_{tag}_meta"] = np.array(list(size) + [k, -1 if min_shape is None else min_shape])
+        res[f"div_{tag}_out"] = y.numpy()
+        res[f"div_{tag}_pb"], res[f"div_{tag}_pa"] = np.asarray(p_b), np.asarray(p_a)
+        res[f"orig_{tag}_out"] = shape_to_original(y * 2.0 + 1.0, p_b, p_a).numpy()
+    img = synth.closed_form("bgimg", (1, 4, 9, 10, 11))  # the reference broadcast only works at batch 1
+    keep = torch.from_numpy(rng.rand(1, 4, 9, 10, 11) > 0.7)
+    img = img * keep  # ~24 % of the voxels are zero in every modality
+    out = torch.from_numpy((rng.rand(1, 3, 9, 10, 11) > 0.4).astype(np.float32))
+    get_device = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: self.device
+    try:
+        res["bg_out"] = remove_background_voxels(img, out).numpy()
+    finally:
+        torch.Tensor.get_device = get_device
+    res["bg_img"], res["bg_pred"] = img.numpy(), out.numpy()
+    seg = torch.from_numpy((rng.rand(1, 3, 6, 7, 8) > 0.5).astype(np.float32))  # every TC/WT/ET combination
+    lab = ChangeLabel3To4()(ConvertToBratsClassesBasedOnMultiChannel()(seg))
+    res["lab_seg"], res["lab_out"] = seg.numpy(), lab.numpy()
+    np.savez_compressed(os.path.join(OUT, "post.npz"), **res)
+    print("post.npz", {k: getattr(v, "shape", None) for k, v in res.items()})
+
+
+RANGER_SHAPES = {"conv.weight": (6, 4, 3, 3, 3), "conv.bias": (6,), "fc.weight": (5, 7), "gamma": (1, 6, 1, 1, 1),
+                 "unused": (3,)}
+RANGER_CASES = {"gc_wd": dict(use_gc=True, gc_conv_only=False, weight_decay=1e-2),
+                "convonly": dict(use_gc=True, gc_conv_only=True, weight_decay=0.0),
+                "plain": dict(use_gc=False, gc_conv_only=False, weight_decay=1e-5)}
+
+
+def ranger_fixture():
+    """13 steps of the reference's Ranger2020 (learning/optimizer.py) on closed-form parameters / gradients:
+    steps 1-5 take the non-adaptive branch (N_sma <= 5), 6.. the RAdam branch, lookahead fires at 6 and 12;
+    the parameter 'unused' never receives a gradient (like EvoNorm's v)."""
+    import contextlib
+    import io
+    from learning.optimizer import Ranger2020
+    res = {"meta": json.dumps({"shapes": {k: list(v) for k, v in RANGER_SHAPES.items()}, "steps": 13, "lr": 1e-2,
+                               "cases": RANGER_CASES})}
+    for case, kw in RANGER_CASES.items():
+        params = {n: torch.nn.Parameter(synth.closed_form("rp." + n, s)) for n, s in RANGER_SHAPES.items()}
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = Ranger2020(list(params.values()), lr=1e-2, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999),
+                             eps=1e-5, use_gcnorm=False, normloss=False, gc_loc=True, **kw)
+        for step in range(1, 14):
+            for n, p in params.items():
+                p.grad = None if n == "unused" else synth.closed_form(f"rg.{n}.{step}", RANGER_SHAPES[n], 0.1 * step)
+            opt.step()
+            if step in (5, 6, 13):
+                for n, p in params.items():
+                    res[f"{case}.{step}.{n}"] = p.detach().numpy().copy()
+        for n, p in params.items():
+            if n != "unused":
+                st = opt.state[p]
+                res[f"{case}.exp_avg.{n}"] = st["exp_avg"].numpy().copy()
+                res[f"{case}.exp_avg_sq.{n}"] = st["exp_avg_sq"].numpy().copy()
+                res[f"{case}.slow.{n}"] = st["slow_buffer"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ranger.npz"), **res)
+    print("ranger.npz", len(res), "arrays")
+
+
 if __name__ == "__main__":
     # src/definer.py imports half of MONAI at module import; restate only its 6-line TTA list
     # constructor call (src/definer.py:653-657) against the reference's own tta package.
@@ -189,7 +263,7 @@ if __name__ == "__main__":
     m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
                                      t.Rotate90(angles=[0, 90, 180, 270])])
     sys.modules["src_definer_tta"] = m
-    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference"]
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger"]
     if "equiunet" in which:
         equiunet_fixtures()
     if "assp" in which:
@@ -198,3 +272,7 @@ if __name__ == "__main__":
         op_fixtures()
     if "inference" in which:
         inference_fixtures()
+    if "post" in which:
+        post_fixtures()
+    if "ranger" in which:
+        ranger_fixture()

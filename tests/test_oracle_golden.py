@@ -129,3 +129,52 @@ def test_sliding_window_and_tta_vectors(golden_dir):
         np.testing.assert_array_equal(a.contiguous().numpy().ravel(), g["tta_aug"][i])
         np.testing.assert_array_equal(oinf.tta_deaugment(a, *p).contiguous().numpy(), g["tta_roundtrip"][i])
         np.testing.assert_array_equal(g["tta_roundtrip"][i], v.numpy())  # all 16 exactly invertible (F7)
+
+
+def test_post_forward_chain_vectors(golden_dir):
+    """oracle/evaluate.py against the reference's utils/transforms.py outputs (tests/golden/post.npz)."""
+    from oracle import evaluate as oev
+    g = np.load(os.path.join(golden_dir, "post.npz"))
+    for tag in "abc":
+        d, h, w, k, ms = (int(v) for v in g[f"div_{tag}_meta"])
+        x = synth.closed_form("pad" + tag, (2, 4, d, h, w))
+        y, p_b, p_a = oev.shape_to_divisible(x, k=k, min_shape=None if ms < 0 else ms)
+        np.testing.assert_array_equal(p_b, g[f"div_{tag}_pb"])
+        np.testing.assert_array_equal(p_a, g[f"div_{tag}_pa"])
+        np.testing.assert_array_equal(y.numpy(), g[f"div_{tag}_out"])
+        np.testing.assert_array_equal(oev.shape_to_original(y * 2.0 + 1.0, p_b, p_a).numpy(), g[f"orig_{tag}_out"])
+    out = oev.remove_background_voxels(torch.from_numpy(g["bg_img"]), torch.from_numpy(g["bg_pred"]))
+    np.testing.assert_array_equal(out.numpy(), g["bg_out"])
+    assert 0.1 < 1 - float(g["bg_out"].sum() / g["bg_pred"].sum()) < 0.5  # the mask really removes something
+    lab = oev.to_brats_labels(torch.from_numpy(g["lab_seg"]))
+    np.testing.assert_array_equal(lab.numpy()[:, None], g["lab_out"])
+    assert set(np.unique(g["lab_out"]).tolist()) == {0, 1, 2, 4}
+
+
+def test_hard_dice_known_answers():
+    from oracle import evaluate as oev
+    p = torch.zeros(1, 3, 2, 2, 2)
+    t = torch.zeros(1, 3, 2, 2, 2)
+    p[0, 0, 0] = 1            # 4 voxels predicted
+    t[0, 0, :, 0] = 1         # 4 voxels true, 2 shared -> 2*2/8
+    p[0, 1, 0, 0, 0] = 1      # predicted, nothing true -> 0
+    np.testing.assert_allclose(oev.hard_dice_metric(p, t).numpy(), [[0.5, 0.0, 1.0]])
+
+
+def test_ranger_oracle_matches_reference(golden_dir):
+    from _replay import ranger_replay
+    from oracle import ranger as orang
+
+    def step_fn(params, lr, kw):
+        states = {n: None for n in params}
+
+        def step(grads):
+            for n, p in params.items():
+                if grads[n] is None:
+                    continue
+                if states[n] is None:
+                    states[n] = orang.new_state(p)
+                orang.ranger_step(p, grads[n], states[n], lr=lr, **kw)
+        return {"step": step, "state": lambda n: states[n]}
+
+    ranger_replay(golden_dir, lambda t: t.clone(), step_fn, lambda t: t.numpy())
