@@ -21,8 +21,8 @@ struct WgradParams {
   float* ws;
   int N, D, H, W, cin, cout;
   int tz, ty, tx, ntiles, nsplit;
-  int stagger;  // de-phasing delay in units of s_sleep(16) = 1024 cycles (BRATS_WGRAD_STAGGER)
-  int debug;  // ablation bits (BRATS_WGRAD_DEBUG): 1 skip global loads, 2 skip MMA, 8 skip LDS writes+barriers
+  int debug;  // ablation bits (BRATS_WGRAD_DEBUG): 1 loads dropped by the range check, 2 skip MMA, 4 no tiles,
+              // 8 skip LDS writes + barriers, 16 no load instructions
 };
 
 constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // tile = 16 x-rows of 16 voxels
@@ -86,46 +86,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const int ci_lim = (ci0 < p.c1 ? p.c1 : p.c1 + p.c2) - ci0;  // valid channels from this source in the tile
   const int co_lim = p.cout - co0;
 
-  // ---- per-lane staging constants (row-per-wave: row origin and row bounds are scalar) ----
-  int xhx[G::XIPR], xgo[G::XIPR], xlo[G::XIPR];
+  // ---- per-lane staging constants.  A staged piece = 16 bytes of one voxel; wave w owns halo rows w, w+4, ...
+  //      Every piece is fetched by ONE unconditional buffer_load whose 32-bit byte offset is
+  //      (tile origin, scalar) + (piece offset inside the halo box, per lane, computed once per kernel);
+  //      pieces outside the volume / channel range get offset 0xffffffff, which the descriptor's range check
+  //      turns into zeros.  No per-piece branches, no 64-bit address arithmetic (that per-tile scalar + vector
+  //      overhead used to cost more than the MFMAs of the tile).
+  int xhx[G::XIPR], xlo[G::XIPR];
+  int xvo[G::XRPW][G::XIPR];
 #pragma unroll
   for (int j = 0; j < G::XIPR; ++j) {
     const int pc = lane + 64 * j;
     const int hx = pc / G::XPPV, part = pc % G::XPPV;
     const bool ok = pc < G::XPPR && part * G::EPL < ci_lim;
-    xhx[j] = ok ? hx : -100000;
-    xgo[j] = hx * xpitch + part * G::EPL;
+    xhx[j] = ok ? hx : -100000;  // fails every x-range test
     xlo[j] = pc < G::XPPR ? wave * (G::HX * G::SX) + hx * G::SX + part * 16 : -1;
+#pragma unroll
+    for (int k = 0; k < G::XRPW; ++k) {
+      const int row = wave + 4 * k;
+      xvo[k][j] = (((row / G::HY) * p.H + row % G::HY) * p.W + hx) * xpitch * G::ESZ + part * 16;
+    }
   }
-  int yvx[G::YIPR], ygo[G::YIPR], ylo[G::YIPR];
+  int yvx[G::YIPR], ylo[G::YIPR];
+  int yvo[G::YRPW][G::YIPR];
 #pragma unroll
   for (int j = 0; j < G::YIPR; ++j) {
     const int pc = lane + 64 * j;
     const int vx = pc / G::YPPV, part = pc % G::YPPV;
     const bool ok = pc < G::YPPR && part * G::EPL < co_lim;
     yvx[j] = ok ? vx : 100000;
-    ygo[j] = vx * p.dyp + part * G::EPL;
     ylo[j] = pc < G::YPPR ? wave * (WG_TX * G::SY) + vx * G::SY + part * 16 : -1;
+#pragma unroll
+    for (int k = 0; k < G::YRPW; ++k) {
+      const int row = wave + 4 * k;
+      yvo[k][j] = (((row / WG_TY) * p.H + row % WG_TY) * p.W + vx) * p.dyp * G::ESZ + part * 16;
+    }
   }
-  // interior fast path: element offsets of every staged piece from the tile's halo origin.  For a tile whose
-  // halo lies inside the volume the per-tile staging is then just XRPW*XIPR + YRPW*YIPR loads off one scalar
-  // base (no per-row bounds / pointer arithmetic: that per-tile scalar+vector overhead cost as much as the MFMAs)
-  int xvo[G::XRPW][G::XIPR], yvo[G::YRPW][G::YIPR];
-#pragma unroll
-  for (int k = 0; k < G::XRPW; ++k) {
-    const int row = wave + 4 * k;
-#pragma unroll
-    for (int j = 0; j < G::XIPR; ++j)
-      xvo[k][j] = (lane + 64 * j < G::XPPR && row < G::XROWS) ? ((row / G::HY) * p.H + row % G::HY) * p.W * xpitch + xgo[j] : 0;
-  }
-#pragma unroll
-  for (int k = 0; k < G::YRPW; ++k) {
-    const int row = wave + 4 * k;
-#pragma unroll
-    for (int j = 0; j < G::YIPR; ++j)
-      yvo[k][j] = (lane + 64 * j < G::YPPR) ? ((row / WG_TY) * p.H + row % WG_TY) * p.W * p.dyp + ygo[j] : 0;
-  }
-  const bool chan_full = ci_lim >= G::CI_T && co_lim >= G::CO_T;
+  const unsigned xsample_bytes = (unsigned)p.D * p.H * p.W * xpitch * G::ESZ;  // < 2^31, checked by the host
+  const unsigned ysample_bytes = (unsigned)p.D * p.H * p.W * p.dyp * G::ESZ;
 
   // ---- the wave's (tap-in-plane, ci-fragment) pairs ----
   int poff[G::PPW];
@@ -141,63 +139,70 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 #pragma unroll
     for (int m = 0; m < COF; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // De-phase the two workgroups sharing a CU (they run identical per-tile sequences and would otherwise stay in
-  // lockstep: both waiting on loads, then both contending for the matrix pipe).  The SIMD wave slot (HW_ID
-  // bits 3:0) of co-resident workgroups differs; odd slots start half a tile period late.  Speed only.
-  if (p.stagger > 0) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
-    if (hwid & 1u) for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-  }
-  for (int tile = lane8 * tpx + gsub; tile < tile_end; tile += g8) {
+  // Software pipeline across tiles: the global loads of tile i+1 are issued right after tile i has been written to
+  // LDS (the staging registers are free again) and fly during tile i's MFMA phase.  With only 2 workgroups per CU
+  // a workgroup's own load -> LDS -> MFMA chain is otherwise serial and sets the throughput (load latency under a
+  // chip-wide burst is as long as the MFMA phase).
+  u32x4 rx[G::XRPW][G::XIPR], ry[G::YRPW][G::YIPR];
+  const unsigned live = (p.debug & 1) ? 0u : 1u;  // ablation: zero records = every load dropped by the range check
+  auto issue_loads = [&](int tile) {
+    if (p.debug & 16) {  // ablation: no load instructions at all
+#pragma unroll
+      for (int k = 0; k < G::XRPW; ++k)
+#pragma unroll
+        for (int j = 0; j < G::XIPR; ++j) rx[k][j] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < G::YRPW; ++k)
+#pragma unroll
+        for (int j = 0; j < G::YIPR; ++j) ry[k][j] = u32x4{0u, 0u, 0u, 0u};
+      return;
+    }
     int bt = tile;
     const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
     const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
     const int z0 = (bt % p.tz) * WG_TZ;
     const int n = bt / p.tz;
-    const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
-    u32x4 rx[G::XRPW][G::XIPR], ry[G::YRPW][G::YIPR];
     const int gz0 = z0 + (tzg - 1) * DIL;
-    const bool interior = chan_full && gz0 >= 0 && gz0 + WG_TZ <= p.D && y0 >= DIL && y0 + WG_TY + DIL <= p.H &&
-                          x0 >= DIL && x0 + WG_TX + DIL <= p.W && !(p.debug & 1);
-    if (interior) {
-      const T* xb = xsrc + (sample_vox + ((size_t)gz0 * p.H + (y0 - DIL)) * p.W + (x0 - DIL)) * xpitch;
-      const T* yb = (const T*)p.dy + (sample_vox + ((size_t)z0 * p.H + y0) * p.W + x0) * p.dyp + co0;
+    const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0,
+                                                                          (int)(xsample_bytes * live), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0),
+                                                                          (short)0, (int)(ysample_bytes * live), 0x00020000);
+    const int xorg = ((gz0 * p.H + (y0 - DIL)) * p.W + (x0 - DIL)) * xpitch * G::ESZ;  // may be negative at the low faces
+    const int yorg = ((z0 * p.H + y0) * p.W + x0) * p.dyp * G::ESZ;
+    bool xok[G::XIPR], yok[G::YIPR];
 #pragma unroll
-      for (int k = 0; k < G::XRPW; ++k)
+    for (int j = 0; j < G::XIPR; ++j) xok[j] = (unsigned)(x0 - DIL + xhx[j]) < (unsigned)p.W;
 #pragma unroll
-        for (int j = 0; j < G::XIPR; ++j) rx[k][j] = *(const u32x4*)(xb + xvo[k][j]);
+    for (int j = 0; j < G::YIPR; ++j) yok[j] = x0 + yvx[j] < p.W;
 #pragma unroll
-      for (int k = 0; k < G::YRPW; ++k)
+    for (int k = 0; k < G::XRPW; ++k) {
+      const int row = wave + 4 * k;
+      const int gz = gz0 + row / G::HY, gy = y0 - DIL + row % G::HY;
+      const bool row_ok = row < G::XROWS && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H;  // scalar
 #pragma unroll
-        for (int j = 0; j < G::YIPR; ++j) ry[k][j] = *(const u32x4*)(yb + yvo[k][j]);
-    } else {
-    // ---- global -> registers (zero outside the volume / channel range) ----
-  #pragma unroll
-      for (int k = 0; k < G::XRPW; ++k) {
-        const int row = wave + 4 * k;
-        const int gz = z0 + row / G::HY + (tzg - 1) * DIL, gy = y0 - DIL + row % G::HY;
-        const bool row_ok = row < G::XROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
-        const T* rowp = xsrc + ((ptrdiff_t)(sample_vox + (size_t)(gz * p.H + gy) * p.W) + (x0 - DIL)) * xpitch;
-  #pragma unroll
-        for (int j = 0; j < G::XIPR; ++j) {
-          const int gx = x0 - DIL + xhx[j];
-          rx[k][j] = u32x4{0u, 0u, 0u, 0u};
-          if (row_ok && gx >= 0 && gx < p.W && !(p.debug & 1)) rx[k][j] = *(const u32x4*)(rowp + xgo[j]);
-        }
-      }
-  #pragma unroll
-      for (int k = 0; k < G::YRPW; ++k) {
-        const int row = wave + 4 * k;
-        const int gz = z0 + row / WG_TY, gy = y0 + row % WG_TY;
-        const bool row_ok = gz < p.D && gy < p.H;
-        const T* rowp = (const T*)p.dy + (sample_vox + (size_t)(gz * p.H + gy) * p.W + x0) * p.dyp + co0;
-  #pragma unroll
-        for (int j = 0; j < G::YIPR; ++j) {
-          ry[k][j] = u32x4{0u, 0u, 0u, 0u};
-          if (row_ok && x0 + yvx[j] < p.W && !(p.debug & 1)) ry[k][j] = *(const u32x4*)(rowp + ygo[j]);
-        }
+      for (int j = 0; j < G::XIPR; ++j) {
+        const int vo = (row_ok && xok[j]) ? xorg + xvo[k][j] : -1;
+        rx[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
       }
     }
+#pragma unroll
+    for (int k = 0; k < G::YRPW; ++k) {
+      const int row = wave + 4 * k;
+      const bool row_ok = z0 + row / WG_TY < p.D && y0 + row % WG_TY < p.H;
+#pragma unroll
+      for (int j = 0; j < G::YIPR; ++j) {
+        const int vo = (row_ok && yok[j]) ? yorg + yvo[k][j] : -1;
+        ry[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, vo, 0, 0));
+      }
+    }
+  };
+  // (the dilated 48x48 tile has no registers left to keep a second tile in flight: it would spill)
+  constexpr bool PREFETCH = !(G::BF && DIL == 2 && COF * CIF == 9);
+  const int tile_first = (p.debug & 4) ? tile_end : lane8 * tpx + gsub;  // ablation bit 4: no tiles (prologue + epilogue only)
+  if (PREFETCH && tile_first < tile_end) issue_loads(tile_first);
+  for (int tile = tile_first; tile < tile_end; tile += g8) {
+    if (!PREFETCH) issue_loads(tile);
     if (!(p.debug & 8)) {
     __syncthreads();  // previous tile's LDS reads are done
 #pragma unroll
@@ -216,6 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
     __syncthreads();
     } else { asm volatile("" :: "v"(rx[0][0][0]), "v"(ry[0][0][0])); }
+    if (PREFETCH && tile + g8 < tile_end) issue_loads(tile + g8);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMA phase
 
     // ---- MFMA over the 256 voxels of the tile ----
     if (p.debug & 2) continue;
@@ -392,6 +399,11 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   const int epl = dtype == BRATS_BF16 ? 8 : 4;
   if (pitch1 % epl || (c2 && pitch2 % epl) || dypitch % epl || c1 % epl || c2 % epl || cout % epl)
     BRATS_FAIL(BRATS_E_ARG, "wgrad: channel counts / pitches must be multiples of %d", epl);
+  {  // staged pieces are addressed by 32-bit byte offsets inside one sample (buffer_load voffset)
+    const int mp = pitch1 > pitch2 ? (pitch1 > dypitch ? pitch1 : dypitch) : (pitch2 > dypitch ? pitch2 : dypitch);
+    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
+  }
   int cof, cif;
   wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
   WgradParams p;
@@ -404,7 +416,6 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   const int cit = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
   p.nsplit = wgrad_nsplit(p.ntiles, cot, cit);
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("BRATS_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
-  { static int stg = -1; if (stg < 0) { const char* e = getenv("BRATS_WGRAD_STAGGER"); stg = e ? atoi(e) : 5; } p.stagger = stg; }
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
   hipStream_t st = (hipStream_t)s;

@@ -24,4 +24,8 @@ for k, d in agg.items():
         line += f" writeMB={m['WRITE_SIZE']/1024:.0f}"
     if 'SQ_INSTS_MFMA' in m:
         line += f" valu/mfma={m['SQ_INSTS_VALU']/max(m['SQ_INSTS_MFMA'],1):.2f} lds/mfma={m['SQ_INSTS_LDS']/max(m['SQ_INSTS_MFMA'],1):.2f} vmemrd/mfma={m['SQ_INSTS_VMEM_RD']/max(m['SQ_INSTS_MFMA'],1):.3f} wait_lds={m.get('SQ_WAIT_INST_LDS',0)/max(m.get('SQ_ACTIVE_INST_ANY',1),1):.2f}"
+    if 'GRBM_GUI_ACTIVE' in m and 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
+        # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs; MFMA busy cycles are summed over all 1024 SIMDs
+        clk = m['GRBM_GUI_ACTIVE'] / 8 / dur  # GHz (dur in ns)
+        line += f" clk={clk:.2f}GHz mfma_util={m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}"
     print(line)

@@ -7,7 +7,7 @@ dt = torch.bfloat16
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 N, S = 2, 128
 def run(cin, cout, s, dil=1, reps=3):
-    x = torch.randn(N, s, s, s, cin, device=dev).to(dt)
+    x = torch.relu(torch.randn(N, s, s, s, cin, device=dev)).to(dt)  # post-ReLU activations, as in the network
     dy = torch.randn(N, s, s, s, cout, device=dev).to(dt)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
     wpk = ops.pack_weights(w, dt, ops.PACK_FWD, dil=dil)

@@ -28,7 +28,8 @@ def test_ranger_matches_reference_golden(golden_dir):
             opt.step()
         return {"step": step, "state": lambda n: opt.state[params[n]]}
 
-    ranger_replay(golden_dir, lambda t: torch.nn.Parameter(t.to(DEV)), step_fn, lambda t: t.detach().cpu().numpy())
+    ranger_replay(golden_dir, lambda t: torch.nn.Parameter(t.to(DEV)), step_fn, lambda t: t.detach().cpu().numpy(),
+                  rtol=2e-5)  # f32 tolerance: the device's sqrt / divide round differently from the CPU's by <= 1-2 ulp per step
 
 
 def test_ranger_full_model_vs_oracle_and_state_dict_roundtrip():
