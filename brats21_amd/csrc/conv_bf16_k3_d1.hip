@@ -1,3 +1,17 @@
-// explicit instantiation unit: bf16, 3x3x3, dilation 1 (see conv_igemm.hpp)
-#include "conv_igemm.hpp"
-CONV_DEFINE_LAUNCH_BF16(3, 1)
+// explicit instantiation unit: bf16, 3x3x3, dilation 1 (see conv_igemm.hpp); large layers with 48-channel chunks
+// take the ping-pong persistent kernel of conv_igemm_pp.hpp
+#include <stdlib.h>
+#include "conv_igemm_pp.hpp"
+template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream_t st) {
+  if (ck == 48) {
+    const int rc = conv_try_pp<48>(p, st);
+    if (rc >= 0) return rc;
+  }
+  switch (ck) {
+    case 48: return conv_launch_ck<bf16_t, 3, 48, 1>(p, st);
+    case 32: return conv_launch_ck<bf16_t, 3, 32, 1>(p, st);
+    case 16: return conv_launch_ck<bf16_t, 3, 16, 1>(p, st);
+    case 8: return conv_launch_ck<bf16_t, 3, 8, 1>(p, st);
+  }
+  BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv bf16: unsupported channel chunk %d", ck);
+}

@@ -22,6 +22,7 @@ struct ConvParams {
   void* y2; int y2pitch; int ysplit;  // optional second destination for output channels >= ysplit (dgrad of a concat input)
   int N, D, H, W, cout, rows16, nchunks;
   int tz, ty, tx;
+  int debug;  // ablation bits for conv_igemm_pp.hpp (BRATS_CONV_DEBUG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue
 };
 
 constexpr int CONV_TZ = 4, CONV_TY = 4, CONV_TX = 16;  // a voxel fragment = one x-row of 16
@@ -79,7 +80,7 @@ constexpr int conv_lds_bytes() {
 // pressure): the weight fragments of step k+1 are requested from L2 before the MFMAs of step k, and the
 // 8 activation fragments are read from LDS in two halves so that 4 ds_read_b128 are always in flight
 // behind 12 MFMAs.
-template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */>
+template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */, int BAR = 0 /* s_barriers embedded at 1/3 and 2/3 (conv_igemm_pp.hpp) */>
 DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
                          int lane, f32x4 (&acc)[NF][8]) {
   using G = ConvGeom<T, KS, CK, DIL>;
@@ -135,6 +136,10 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       __builtin_amdgcn_sched_barrier(0);
       mma(k_, I1{});
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BAR == 2 && (k == NSTEP / 3 || k == (2 * NSTEP) / 3)) {
+        __builtin_amdgcn_s_barrier();  // the other team's epilogue rounds (no memory of this wave is involved)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     });
   } else {
     static_for<0, NSTEP>([&](auto k_) {

@@ -63,6 +63,11 @@ int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode,
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
 /* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
 int brats_conv3d_split_granule(int cout);
+/* Tuning / test knob: selects the kernel family of the large bf16 3x3x3 layers.  1 = the persistent
+ * "ping-pong" kernel (LDS-DMA double buffering, two wave teams in anti-phase; experimental, not
+ * faster yet), 0 = one tile per workgroup, -1 = default (0, or the BRATS_CONV_PP environment
+ * variable).  Both families compute the same values; returns the previous setting. */
+int brats_conv3d_set_pingpong(int mode);
 /* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
  * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2
  * as two dense tensors in one launch. */

@@ -244,3 +244,44 @@ def test_fused_dice_matches_torch_dice(jaccard):
     assert abs(loss.item() - cpu.item()) < 1e-6
     for a, b in zip(gfused, gref):
         torch.testing.assert_close(a, b, atol=1e-9, rtol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cin2,cout,n,size,split", [
+    (48, 0, 48, 2, (32, 64, 64), None),     # K-split tile (cout 48), one chunk
+    (48, 48, 48, 3, (34, 62, 66), None),    # two sources, ragged in z / y / x
+    (48, 0, 96, 2, (32, 64, 64), 48),       # no-split tile (cout 96), dual destination
+    (96, 0, 192, 2, (32, 32, 64), None),    # two cout tiles per voxel tile, two chunks
+])
+def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, split):
+    """The persistent LDS-DMA kernel of the large bf16 layers against the one-tile-per-workgroup kernel on the same
+    inputs (bit-exact outputs: same MFMA order, commutative K-split sum) and against torch on a sub-volume."""
+    from brats21_amd import _lib, ops
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((n, *size, cin), generator=g).to(dev).to(dt)
+    x2 = torch.randn((n, *size, cin2), generator=g).to(dev).to(dt) if cin2 else None
+    w = torch.randn((cout, cin + cin2, 3, 3, 3), generator=g) * (2.0 / ((cin + cin2) * 27)) ** 0.5
+    bias = torch.randn(cout, generator=g).to(dev)
+    wpk = ops.pack_weights(w.to(dev), dt, ops.PACK_FWD, c1=cin if cin2 else None)
+    lib = _lib.lib()
+    res = {}
+    for mode in (0, 1):
+        old = lib.brats_conv3d_set_pingpong(mode)
+        try:
+            y, st = ops.conv3d(x, wpk, cout, 3, 1, bias=bias, want_stats=True, x2=x2, split=split)
+            torch.cuda.synchronize()
+        finally:
+            lib.brats_conv3d_set_pingpong(old)
+        res[mode] = (y, st)
+    ya, yb = res[0][0], res[1][0]
+    if split is not None:
+        assert torch.equal(ya[0], yb[0]) and torch.equal(ya[1], yb[1])
+        yb = torch.cat([yb[0], yb[1]], -1)
+    else:
+        assert torch.equal(ya, yb)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-3)
+    # torch reference on sample 0 (zero padding at every face included)
+    xin = x[:1].float().cpu() if x2 is None else torch.cat([x[:1], x2[:1]], -1).float().cpu()
+    ref = F.conv3d(xin.permute(0, 4, 1, 2, 3), w.to(dt).float(), bias.cpu(), 1, 1)
+    torch.testing.assert_close(_from_ndhwc(yb[:1]), ref, atol=3e-2, rtol=2e-2)
