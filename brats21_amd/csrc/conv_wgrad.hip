@@ -302,13 +302,199 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   }
 }
 
-// dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order; 16-byte loads)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int cout, int cin) {
+// ---------------------------------------------------------------------------------------------------------
+// All-taps variant for the 48 x 48 channel block of the large bf16 layers (dilation 1).  The tap-plane kernel
+// above stages the dY tile three times and every X plane twice (one workgroup per tap plane): measured at
+// 48->48 @128^3 its global->LDS traffic (3.2 GB per launch) alone takes 0.40 of the 0.78 ms.  Here ONE workgroup
+// of 8 waves per CU owns all 27 taps of a tile: X tile with z halo (6 x 6 x 18 voxels) + dY tile = 87 KB of LDS,
+// staged once per tile = 2.3x less traffic.  The 81 (tap, ci-fragment) pairs are dealt to the 8 waves
+// (11 pairs x 3 co-fragments = 132 accumulator registers per lane, kept across all tiles of the workgroup);
+// the next tile's 87 KB are prefetched into registers (11 x 16 B per lane) during the MFMA phase.
+struct Wg3 {
+  static constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, HVOX = HZ * HY * HX;
+  static constexpr int SX = 96, SY = 96, PPV = 6;
+  static constexpr int XPIECES = HVOX * PPV, YPIECES = WG_VOX * PPV;       // 3888, 1536 sixteen-byte pieces
+  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;     // 8, 3 per thread
+  static constexpr int LDS_X = HVOX * SX, LDS = LDS_X + WG_VOX * SY;       // 62208 + 24576
+  static constexpr int PAIRS = 81, PPW = 11;                                // pair p -> wave p % 8
+};
+
+__global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradParams p) {
+  typedef bf16_t T;
+  using G = Wg3;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldx = lds;
+  char* ldy = lds + G::LDS_X;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, v = lane & 15;
+  const int lane8 = blockIdx.x & 7, gsub = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+  const int split = blockIdx.x;
+  const int tpx = (p.ntiles + 7) / 8;
+  const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
+  const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 48;
+  const T* xsrc;
+  int xpitch;
+  if (ci0 < p.c1) { xsrc = (const T*)p.x1 + ci0; xpitch = p.p1; }
+  else { xsrc = (const T*)p.x2 + (ci0 - p.c1); xpitch = p.p2; }
+
+  // static per-lane piece codes: hz | hy << 3 | hx << 6 | part << 11 | valid << 14  (flat piece P = tid + 512 i)
+  int xcode[G::XI], ycode[G::YI];
+#pragma unroll
+  for (int i = 0; i < G::XI; ++i) {
+    const int P = tid + 512 * i;
+    const int vox = P / G::PPV, part = P % G::PPV;
+    const int hx = vox % G::HX, hy = (vox / G::HX) % G::HY, hz = vox / (G::HX * G::HY);
+    xcode[i] = P < G::XPIECES ? (hz | hy << 3 | hx << 6 | part << 11 | 1 << 14) : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < G::YI; ++i) {
+    const int P = tid + 512 * i;
+    const int vox = P / G::PPV, part = P % G::PPV;
+    ycode[i] = (vox >> 6) | ((vox >> 4) & 3) << 3 | (vox & 15) << 6 | part << 11 | 1 << 14;
+  }
+  const unsigned xsample_bytes = (unsigned)p.D * p.H * p.W * xpitch * 2;
+  const unsigned ysample_bytes = (unsigned)p.D * p.H * p.W * p.dyp * 2;
+
+  int poff[G::PPW];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 8 * jj;
+    const int t = pid / 3, nn = pid % 3;
+    poff[jj] = pid < G::PAIRS ? (((t / 9) * G::HY + (t / 3) % 3) * G::HX + t % 3) * G::SX + nn * 32 : 0;
+  }
+  f32x4 acc[G::PPW][3];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rx[G::XI], ry[G::YI];
+  const unsigned live = (p.debug & 1) ? 0u : 1u;
+  auto issue_loads = [&](int tile) {
+    int bt = tile;
+    const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
+    const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
+    const int z0 = (bt % p.tz) * WG_TZ;
+    const int n = bt / p.tz;
+    const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0,
+                                                                          (int)(xsample_bytes * live), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0),
+                                                                          (short)0, (int)(ysample_bytes * live), 0x00020000);
+    unsigned zm = 0, ym = 0, xm = 0, zy = 0, yy = 0, xy = 0;
+#pragma unroll
+    for (int h = 0; h < G::HZ; ++h) zm |= ((unsigned)(z0 - 1 + h) < (unsigned)p.D ? 1u : 0u) << h;
+#pragma unroll
+    for (int h = 0; h < G::HY; ++h) ym |= ((unsigned)(y0 - 1 + h) < (unsigned)p.H ? 1u : 0u) << h;
+#pragma unroll
+    for (int h = 0; h < G::HX; ++h) xm |= ((unsigned)(x0 - 1 + h) < (unsigned)p.W ? 1u : 0u) << h;
+    zy = zm >> 1; yy = ym >> 1; xy = xm >> 1;  // the dY tile is the halo box without its rim
+    const int xorg = ((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1);  // voxel index of the halo corner (may be negative)
+    const int yorg = (z0 * p.H + y0) * p.W + x0;
+    const int xpb = xpitch * 2, ypb = p.dyp * 2;
+#pragma unroll
+    for (int i = 0; i < G::XI; ++i) {
+      int c = xcode[i];
+      asm volatile("" : "+v"(c));  // opaque: the derived terms must not be hoisted out of the tile loop (registers)
+      const unsigned ok = (unsigned)(c >> 14) & (zm >> (c & 7)) & (ym >> ((c >> 3) & 7)) & (xm >> ((c >> 6) & 31)) & 1u;
+      const int pv = ((c & 7) * p.H + ((c >> 3) & 7)) * p.W + ((c >> 6) & 31);
+      const int vo = ok ? (xorg + pv) * xpb + ((c >> 11) & 7) * 16 : -1;
+      rx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < G::YI; ++i) {
+      int c = ycode[i];
+      asm volatile("" : "+v"(c));
+      const unsigned ok = (zy >> (c & 7)) & (yy >> ((c >> 3) & 7)) & (xy >> ((c >> 6) & 31)) & 1u;
+      const int pv = ((c & 7) * p.H + ((c >> 3) & 7)) * p.W + ((c >> 6) & 31);
+      const int vo = ok ? (yorg + pv) * ypb + ((c >> 11) & 7) * 16 : -1;
+      ry[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, vo, 0, 0));
+    }
+  };
+
+  const int tile_first = (p.debug & 4) ? tile_end : lane8 * tpx + gsub;
+  if (tile_first < tile_end) issue_loads(tile_first);
+  for (int tile = tile_first; tile < tile_end; tile += g8) {
+    __syncthreads();  // previous tile's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < G::XI; ++i)
+      if (tid + 512 * i < G::XPIECES) *(u32x4*)(ldx + (tid + 512 * i) * 16) = rx[i];
+#pragma unroll
+    for (int i = 0; i < G::YI; ++i) *(u32x4*)(ldy + (tid + 512 * i) * 16) = ry[i];
+    __syncthreads();
+    if (tile + g8 < tile_end) issue_loads(tile + g8);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMA phase
+    if (p.debug & 2) continue;
+    // k-step s = x-rows 2s, 2s+1 of the tile (row = z*4 + y); see the tap-plane kernel for the fragment layout
+    const int qq = v >> 2, pp = v & 3;
+    const int ybase = (4 * q + qq) * G::SY + pp * 8;
+    const int xbase = (4 * q + qq) * G::SX + pp * 8;
+    constexpr int PD = 2;  // (3 in the tap-plane kernel; here the 256-register budget is full)
+    bf16x8 a[2][3], b[PD + 1];
+    auto read_a = [&](auto s_) {
+      constexpr int s = s_;
+      const int yoff = ybase + (32 * s) * G::SY;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
+    };
+    auto read_b = [&](auto u_) {
+      constexpr int u = u_;
+      constexpr int s = u / G::PPW, jj = u % G::PPW;
+      const int xoff = xbase + (((s >> 1) * G::HY + 2 * (s & 1)) * G::HX) * G::SX + poff[jj];
+      b[u % (PD + 1)] = tr_pair(ldx + xoff, ldx + xoff + G::HX * G::SX);
+    };
+    constexpr int NU = 8 * G::PPW;
+    read_a(std::integral_constant<int, 0>{});
+    static_for<0, PD>([&](auto u_) { read_b(u_); });
+    static_for<0, NU>([&](auto u_) {
+      constexpr int u = u_;
+      constexpr int s = u / G::PPW, jj = u % G::PPW;
+      if constexpr (u + PD < NU) read_b(std::integral_constant<int, u + PD>{});
+      if constexpr (jj == 0 && s + 1 < 8) read_a(std::integral_constant<int, s + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+        acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+
+  // ---- slab: ws[split][tap][co][ci] ----
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 8 * jj;
+    if (pid < G::PAIRS) {
+      const int t = pid / 3, nn = pid % 3;
+      float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
+      const int ci = ci0 + nn * 16 + v;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order -> bitwise reproducible; 16-byte loads)
+// A block = 32 consecutive f32x4 elements x 8 split groups: thread (e, g) adds splits g, g+8, ... and the 8 partial
+// sums are combined in group order through LDS (one thread per element deep the kernel had 61 workgroups, each
+// lane walking all ~256 slabs serially).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                           int cout, int cin) {
   const size_t per = (size_t)27 * cout * cin;
   const size_t per4 = per / 4;  // cin % 4 == 0
-  for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < per4; i4 += (size_t)gridDim.x * blockDim.x) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nsplit; ++k) s += *(const f32x4*)(ws + (size_t)k * per + i4 * 4);
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const size_t i4 = (size_t)blockIdx.x * 32 + e;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < per4)
+    for (int k = g; k < nsplit; k += 8) s += *(const f32x4*)(ws + (size_t)k * per + i4 * 4);
+  __shared__ f32x4 part[8][32];
+  part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i4 < per4) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += part[k][e];
     const size_t i = i4 * 4;
     const int ci = i % cin;
     const int co = (i / cin) % cout;
@@ -353,13 +539,41 @@ static void wgrad_tiles(int dtype, int c1, int c2, int cout, int* cof, int* cif)
   *cif = ok(3) ? 3 : (ok(2) ? 2 : 1);
 }
 
+// all-taps kernel: 48 x 48 channel blocks only, one persistent workgroup per CU in total (8 XCD ranges x g8)
+int g_wgrad_alltaps_mode = -1;  // brats_conv3d_set_wgrad_alltaps(): -1 = environment / default (on), 0 = off, 1 = on
+static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int ntiles, int* g8_out) {
+  static int env_mode = -1, ncu = 0;
+  if (env_mode < 0) {
+    const char* e = getenv("BRATS_WGRAD_ALLTAPS");
+    env_mode = e ? atoi(e) : 1;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  const int mode = g_wgrad_alltaps_mode >= 0 ? g_wgrad_alltaps_mode : env_mode;
+  if (!mode || dtype != BRATS_BF16 || dil != 1 || cout % 48 || c1 % 48 || (c2 > 0 && c2 % 48)) return false;
+  const int blocks = (cout / 48) * ((c1 + (c2 > 0 ? c2 : 0)) / 48);
+  int g8 = ceil_div(ncu, 8 * blocks);
+  if (g8 < 1) g8 = 1;
+  if (ntiles < 4 * 8 * g8) return false;  // too few tiles per workgroup to amortise 132 accumulators x 27 taps of slab
+  *g8_out = g8;
+  return true;
+}
+extern "C" int brats_conv3d_set_wgrad_alltaps(int mode) {
+  const int old = g_wgrad_alltaps_mode;
+  g_wgrad_alltaps_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  return old;
+}
+
 extern "C" size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout) {
   if (ksize != 3) return 0;
   int cof, cif;
   wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
   const int ntiles = N * ceil_div(D, WG_TZ) * ceil_div(H, WG_TY) * ceil_div(W, WG_TX);
   const int cin_tiles = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
-  const int ns = wgrad_nsplit(ntiles, ceil_div(cout, 16 * cof), cin_tiles);
+  int ns = wgrad_nsplit(ntiles, ceil_div(cout, 16 * cof), cin_tiles);
+  int g8 = 0;
+  if (wgrad_alltaps_ok(dtype, 1, c1, c2, cout, ntiles, &g8) && 8 * g8 > ns) ns = 8 * g8;  // the dilation is not known here
   return (size_t)ns * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
 }
 
@@ -424,15 +638,26 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * 27 * cout * p.cin * sizeof(float), st);
     if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: memset: %s", hipGetErrorString(e));
   }
+  int g8a = 0;
+  const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a);
   dim3 grid(3 * p.nsplit, cot, cit);  // x = lane8 + 8*(3*gsub + tzg)
   int rc;
-  if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
+  if (alltaps) {
+    p.nsplit = 8 * g8a;
+    static bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3::LDS);
+      if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3::LDS, hipGetErrorString(e));
+      done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_alltaps_kernel, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3::LDS, st, p);
+    rc = 0;
+  } else if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
   else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);
   if (rc) return rc;
   const size_t per = (size_t)27 * cout * p.cin;
-  size_t blocks = (per / 4 + 255) / 256;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, (const float*)ws, dw,
-                     p.nsplit, cout, p.cin);
+  const size_t blocks = (per / 4 + 31) / 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, p.cin);
   if (dbias) {
     const size_t vox = (size_t)N * D * H * W;
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);

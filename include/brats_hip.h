@@ -80,6 +80,11 @@ int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2,
  * `ws` = f32 workspace of brats_conv3d_wgrad_ws_bytes(); dw = [cout][c1+c2][k^3] f32, overwritten.
  * dbias (may be NULL): [cout] f32 = sum_v dy. */
 size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout);
+/* Tuning / test knob: 1 = the all-taps kernel for 48x48 channel blocks of large bf16 dilation-1
+ * layers (one 8-wave workgroup per CU owns all 27 taps of a tile), 0 = the tap-plane kernel
+ * everywhere, -1 = default (1, or the BRATS_WGRAD_ALLTAPS environment variable).  Same values up
+ * to f32 summation order; returns the previous setting. */
+int brats_conv3d_set_wgrad_alltaps(int mode);
 int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
                        const void* dy, int dypitch, float* ws, float* dw, float* dbias,
                        int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,

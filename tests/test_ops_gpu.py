@@ -285,3 +285,67 @@ def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, sp
     xin = x[:1].float().cpu() if x2 is None else torch.cat([x[:1], x2[:1]], -1).float().cpu()
     ref = F.conv3d(xin.permute(0, 4, 1, 2, 3), w.to(dt).float(), bias.cpu(), 1, 1)
     torch.testing.assert_close(_from_ndhwc(yb[:1]), ref, atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("cin,cin2,cout,n,size", [
+    (48, 0, 48, 2, (32, 64, 64)),
+    (48, 48, 48, 3, (34, 62, 66)),     # two sources, ragged in z / y / x
+    (96, 0, 96, 2, (32, 32, 64)),      # 2 x 2 channel blocks
+])
+def test_conv3d_wgrad_alltaps_kernel_matches_tapplane_kernel(cin, cin2, cout, n, size):
+    """The all-taps wgrad kernel (one 8-wave workgroup per CU, X tile with z halo staged once) against the tap-plane
+    kernel on the same inputs (f32 split-K sums in a different order: 1e-5 relative) and against torch autograd."""
+    from brats21_amd import _lib, ops
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn((n, *size, cin), generator=g).to(dev).to(dt)
+    x2 = torch.randn((n, *size, cin2), generator=g).to(dev).to(dt) if cin2 else None
+    dy = (torch.randn((n, *size, cout), generator=g) * 0.1).to(dev).to(dt)
+    lib = _lib.lib()
+    res = {}
+    for mode in (0, 1):
+        old = lib.brats_conv3d_set_wgrad_alltaps(mode)
+        try:
+            dw, db = ops.conv3d_wgrad(x, dy, 3, 1, want_dbias=True, x2=x2)
+            torch.cuda.synchronize()
+        finally:
+            lib.brats_conv3d_set_wgrad_alltaps(old)
+        res[mode] = (dw, db)
+    scale = float(res[0][0].abs().max())
+    assert scale > 0
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * scale
+    assert torch.equal(res[0][1], res[1][1])
+    # torch autograd on sample 0 only would not see the other samples' contribution: use a small sub-problem instead
+    xs = x[:1, :12, :12, :16] if x2 is None else torch.cat([x[:1, :12, :12, :16], x2[:1, :12, :12, :16]], -1)
+    dys = dy[:1, :12, :12, :16]
+    old = lib.brats_conv3d_set_wgrad_alltaps(1)
+    try:
+        dws, _ = ops.conv3d_wgrad(xs.contiguous(), dys.contiguous(), 3, 1)  # too few tiles: falls back to the tap-plane kernel
+    finally:
+        lib.brats_conv3d_set_wgrad_alltaps(old)
+    w = torch.zeros((cout, cin + cin2, 3, 3, 3), requires_grad=True)
+    F.conv3d(xs.float().cpu().permute(0, 4, 1, 2, 3), w, None, 1, 1).backward(dys.float().cpu().permute(0, 4, 1, 2, 3))
+    torch.testing.assert_close(dws.cpu(), w.grad, atol=4e-3 * float(w.grad.abs().max()), rtol=1e-2)
+
+
+def test_conv3d_wgrad_alltaps_vs_torch_full_volume():
+    """All-taps kernel against torch autograd on a volume large enough to select it (boundary tiles included)."""
+    from brats21_amd import _lib, ops
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(17)
+    n, size = 2, (32, 60, 66)
+    x = torch.randn((n, *size, 48), generator=g).to(dt)
+    dy = (torch.randn((n, *size, 48), generator=g) * 0.1).to(dt)
+    lib = _lib.lib()
+    old = lib.brats_conv3d_set_wgrad_alltaps(1)
+    try:
+        dw, _ = ops.conv3d_wgrad(x.to(dev), dy.to(dev), 3, 1)
+        torch.cuda.synchronize()
+    finally:
+        lib.brats_conv3d_set_wgrad_alltaps(old)
+    w = torch.zeros((48, 48, 3, 3, 3), requires_grad=True)
+    torch.set_num_threads(16)
+    F.conv3d(x.float().permute(0, 4, 1, 2, 3), w, None, 1, 1).backward(dy.float().permute(0, 4, 1, 2, 3))
+    torch.testing.assert_close(dw.cpu(), w.grad, atol=4e-3 * float(w.grad.abs().max()), rtol=1e-2)
