@@ -152,21 +152,18 @@ extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scal
 
 // ---- backward of z = act(GN(y)) ----------------------------------------------------------------
 // pass 1: red[n][c] = { sum_v u, sum_v u*xhat },  u = dz * act'(y*scale+shift), xhat = (y-mean_g)*rstd_g
+// A thread owns one 16-byte channel vector (fixed for the whole kernel) and walks voxels: its per-channel constants
+// live in registers (read from LDS per element they made both passes LDS-bound at ~3.5 TB/s), two voxels are in
+// flight per iteration.
 template <typename T>
-__global__ void gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y, int ypitch,
-                                     const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
-                                     float* __restrict__ red, int act, float slope, int voxels, int C, int groups) {
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
+                                                            int ypitch, const float* __restrict__ scale_shift,
+                                                            const float* __restrict__ mean_rstd, float* __restrict__ red, int act,
+                                                            float slope, int voxels, int C, int groups) {
   constexpr int VW = 16 / sizeof(T);
-  extern __shared__ float sm[];  // ss[C*2], mr[C*2] (per channel mean,rstd), then reduction scratch
-  float* ss = sm;
-  float* mr = sm + 2 * C;
+  extern __shared__ float sm[];  // reduction scratch [vl_n][C][2]
   const int n = blockIdx.y;
   const int cpg = C / groups;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    ss[i] = scale_shift[(size_t)n * C * 2 + i];
-    mr[i] = mean_rstd[(n * groups + (i >> 1) / cpg) * 2 + (i & 1)];
-  }
-  __syncthreads();
   const int cv = C / VW;
   const int vl_n = blockDim.x / cv;  // voxel lanes per block
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv;
@@ -175,25 +172,52 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, cons
 #pragma unroll
   for (int j = 0; j < VW; ++j) a1[j] = a2[j] = 0.f;
   if (myvl < vl_n) {
-    const T* dzb = dz + (size_t)n * voxels * dzpitch;
-    const T* yb = y + (size_t)n * voxels * ypitch;
-    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
-      float g[VW], yy[VW];
-      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
-      Vec<T, VW>::load(yb + vox * ypitch + c0, yy);
+    float sc[VW], sh[VW], rs[VW], mo[VW];  // pre = y*sc + sh ; xhat = y*rs + mo
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int c = c0 + j;
+      sc[j] = scale_shift[((size_t)n * C + c) * 2];
+      sh[j] = scale_shift[((size_t)n * C + c) * 2 + 1];
+      const float mean = mean_rstd[(n * groups + c / cpg) * 2], rstd = mean_rstd[(n * groups + c / cpg) * 2 + 1];
+      rs[j] = rstd;
+      mo[j] = -mean * rstd;
+    }
+    const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
+    const T* yb = y + (size_t)n * voxels * ypitch + c0;
+    const size_t stride = (size_t)gridDim.x * vl_n;
+    size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+    auto body = [&](const float* g, const float* yy) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
-        const float pre = yy[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1];
-        const float u = g[j] * act_grad(pre, act, slope);
-        const float xh = (yy[j] - mr[(c0 + j) * 2]) * mr[(c0 + j) * 2 + 1];
+        const float u = g[j] * act_grad(yy[j] * sc[j] + sh[j], act, slope);
         a1[j] += u;
-        a2[j] += u * xh;
+        a2[j] += u * (yy[j] * rs[j] + mo[j]);
       }
+    };
+    for (; vox + 3 * stride < (size_t)voxels; vox += 4 * stride) {  // 4 voxels (8 loads) in flight per thread
+      float g0[VW], y0[VW], g1[VW], y1[VW], g2[VW], y2[VW], g3[VW], y3[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch, g0);
+      Vec<T, VW>::load(yb + vox * ypitch, y0);
+      Vec<T, VW>::load(dzb + (vox + stride) * dzpitch, g1);
+      Vec<T, VW>::load(yb + (vox + stride) * ypitch, y1);
+      Vec<T, VW>::load(dzb + (vox + 2 * stride) * dzpitch, g2);
+      Vec<T, VW>::load(yb + (vox + 2 * stride) * ypitch, y2);
+      Vec<T, VW>::load(dzb + (vox + 3 * stride) * dzpitch, g3);
+      Vec<T, VW>::load(yb + (vox + 3 * stride) * ypitch, y3);
+      body(g0, y0);
+      body(g1, y1);
+      body(g2, y2);
+      body(g3, y3);
+    }
+    for (; vox < (size_t)voxels; vox += stride) {
+      float g0[VW], y0[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch, g0);
+      Vec<T, VW>::load(yb + vox * ypitch, y0);
+      body(g0, y0);
     }
   }
   // block reduction over voxel lanes through LDS, then one atomic per channel per block
-  float* scr = sm + 4 * C;  // [vl_n][C][2]
-  __syncthreads();
+  float* scr = sm;  // [vl_n][C][2]
   if (myvl < vl_n) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
@@ -209,37 +233,30 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, cons
   }
 }
 
-// pass 2: dy = rstd*(u*gamma - m1 - xhat*m2);  block (0,0) also finishes dgamma/dbeta
+// pass 2: dy = rstd*(u*gamma - m1 - xhat*m2) = u*A + y*B + K with per-channel A = rstd*gamma, B = -rstd^2*m2,
+// K = rstd*(mean*rstd*m2 - m1);  block (0,0) also finishes dgamma/dbeta
 template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y, int ypitch,
-                                    const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ red, T* __restrict__ dy,
-                                    int dypitch, float* __restrict__ dgamma, float* __restrict__ dbeta, int act, float slope,
-                                    int N, int voxels, int C, int groups) {
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
+                                                           int ypitch, const float* __restrict__ scale_shift,
+                                                           const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ red, T* __restrict__ dy, int dypitch,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int act,
+                                                           float slope, int N, int voxels, int C, int groups) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
-  float* ss = sm;            // [C][2]
-  float* mr = sm + 2 * C;    // [C][2] mean, rstd per channel
-  float* gm = sm + 4 * C;    // [C] gamma
-  float* m12 = sm + 5 * C;   // [C][2] m1, m2 per channel (group values replicated)
+  float* m12 = sm;  // [groups][2]: m1, m2 per group
   const int n = blockIdx.y;
   const int cpg = C / groups;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    ss[i] = scale_shift[(size_t)n * C * 2 + i];
-    mr[i] = mean_rstd[(n * groups + (i >> 1) / cpg) * 2 + (i & 1)];
-  }
-  for (int i = threadIdx.x; i < C; i += blockDim.x) gm[i] = gamma[i];
-  __syncthreads();
   const float invM = 1.f / ((float)cpg * (float)voxels);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g0 = (c / cpg) * cpg;
+  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
     float t1 = 0.f, t2 = 0.f;
     for (int j = 0; j < cpg; ++j) {
-      t1 += gm[g0 + j] * red[((size_t)n * C + g0 + j) * 2];
-      t2 += gm[g0 + j] * red[((size_t)n * C + g0 + j) * 2 + 1];
+      const int c = g * cpg + j;
+      t1 += gamma[c] * red[((size_t)n * C + c) * 2];
+      t2 += gamma[c] * red[((size_t)n * C + c) * 2 + 1];
     }
-    m12[c * 2] = t1 * invM;
-    m12[c * 2 + 1] = t2 * invM;
+    m12[g * 2] = t1 * invM;
+    m12[g * 2 + 1] = t2 * invM;
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -251,26 +268,51 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const
   }
   __syncthreads();
   const int cv = C / VW;
-  const size_t total = (size_t)voxels * cv;
-  const T* dzb = dz + (size_t)n * voxels * dzpitch;
-  const T* yb = y + (size_t)n * voxels * ypitch;
-  T* dyb = dy + (size_t)n * voxels * dypitch;
-  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-    const size_t vox = it / cv;
-    const int c0 = (int)(it % cv) * VW;
-    float g[VW], yy[VW], o[VW];
-    Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
-    Vec<T, VW>::load(yb + vox * ypitch + c0, yy);
+  const int vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv;
+  if (myvl >= vl_n) return;
+  const int c0 = mycv * VW;
+  float sc[VW], sh[VW], ca[VW], cb[VW], ck[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) {
+    const int c = c0 + j, g = c / cpg;
+    sc[j] = scale_shift[((size_t)n * C + c) * 2];
+    sh[j] = scale_shift[((size_t)n * C + c) * 2 + 1];
+    const float mean = mean_rstd[(n * groups + g) * 2], rstd = mean_rstd[(n * groups + g) * 2 + 1];
+    const float m1 = m12[g * 2], m2 = m12[g * 2 + 1];
+    ca[j] = rstd * gamma[c];
+    cb[j] = -rstd * rstd * m2;
+    ck[j] = rstd * (mean * rstd * m2 - m1);
+  }
+  const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
+  const T* yb = y + (size_t)n * voxels * ypitch + c0;
+  T* dyb = dy + (size_t)n * voxels * dypitch + c0;
+  const size_t stride = (size_t)gridDim.x * vl_n;
+  size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+  auto body = [&](const float* g, const float* yy, float* o) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      const int c = c0 + j;
-      const float pre = yy[j] * ss[c * 2] + ss[c * 2 + 1];
-      const float u = g[j] * act_grad(pre, act, slope);
-      const float rstd = mr[c * 2 + 1];
-      const float xh = (yy[j] - mr[c * 2]) * rstd;
-      o[j] = rstd * (u * gm[c] - m12[c * 2] - xh * m12[c * 2 + 1]);
+      const float u = g[j] * act_grad(yy[j] * sc[j] + sh[j], act, slope);
+      o[j] = u * ca[j] + (yy[j] * cb[j] + ck[j]);
     }
-    Vec<T, VW>::store(dyb + vox * dypitch + c0, o);
+  };
+  for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+    float g0[VW], y0[VW], g1[VW], y1[VW], o0[VW], o1[VW];
+    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
+    Vec<T, VW>::load(yb + vox * ypitch, y0);
+    Vec<T, VW>::load(dzb + (vox + stride) * dzpitch, g1);
+    Vec<T, VW>::load(yb + (vox + stride) * ypitch, y1);
+    body(g0, y0, o0);
+    body(g1, y1, o1);
+    Vec<T, VW>::store(dyb + vox * dypitch, o0);
+    Vec<T, VW>::store(dyb + (vox + stride) * dypitch, o1);
+  }
+  if (vox < (size_t)voxels) {
+    float g0[VW], y0[VW], o0[VW];
+    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
+    Vec<T, VW>::load(yb + vox * ypitch, y0);
+    body(g0, y0, o0);
+    Vec<T, VW>::store(dyb + vox * dypitch, o0);
   }
 }
 
@@ -287,10 +329,12 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "gn_act_bwd: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
-  dim3 g1(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
-  const size_t lds1 = (size_t)(4 * C + vl * C * 2) * sizeof(float);
-  dim3 g2(stream_grid((size_t)voxels * cv, 256), N);
-  const size_t lds2 = (size_t)7 * C * sizeof(float);
+  // pass 1 ends with 2C atomics per block onto N*2C addresses: few, fat blocks (the atomics of 2048 blocks per sample
+  // serialised on 96 addresses took longer than the streaming itself)
+  dim3 g1(gx < 1 ? 1 : (gx > 512 ? 512 : gx), N);
+  const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
+  dim3 g2(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
+  const size_t lds2 = (size_t)2 * groups * sizeof(float);
   if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                        ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
