@@ -83,6 +83,43 @@ class Ranger2020(Optimizer):
         return plan
 
     # ------------------------------------------------------------------------------------------ step
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plans = {}  # the state tensors were replaced: cached pointer tables are stale
+
+    def _table(self, plan, active, dev):
+        """Host copy of the per-tensor records.  Parameter / state pointers and shapes never change between steps
+        (cached); per step only the gradient pointers and the step-dependent scalars are rewritten -- the reference's
+        Python loop over parameters (learning/optimizer.py:145-253) must not come back as host time here."""
+        rec = plan.get("rec")
+        if rec is None:
+            rec = np.zeros(len(active), _REC)
+            for t, p in enumerate(active):
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
+                    raise _lib.BratsHipError("Ranger2020: parameters must be contiguous f32 tensors on one GPU")
+                state = self.state[p]
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    state['slow_buffer'] = p.detach().clone(memory_format=torch.contiguous_format)
+                else:
+                    for name in ('exp_avg', 'exp_avg_sq', 'slow_buffer'):  # after load_state_dict / .cpu() round trips
+                        s = state[name]
+                        if s.dtype != torch.float32 or s.device != dev or not s.is_contiguous():
+                            state[name] = s.to(device=dev, dtype=torch.float32).contiguous()
+                    state['step'] = int(state['step'])
+                rec[t] = (p.data_ptr(), 0, state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
+                          state['slow_buffer'].data_ptr(), p.numel(), plan["rowlen"][t], plan["rowbase"][t], 0.0, 0.0, 0, 0)
+            plan["rec"] = rec
+            plan["states"] = [self.state[p] for p in active]
+            # pinned staging ring: the H2D copy of the table is asynchronous, a slot is reused only after its copy ran
+            plan["pinned"] = [torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
+            plan["events"] = [None] * 4
+            plan["dev_table"] = torch.empty(rec.nbytes, dtype=torch.uint8, device=dev)
+            plan["slot"] = 0
+        return rec
+
     @torch.no_grad()
     def step(self, closure=None):
         lib = _lib.lib()
@@ -96,38 +133,44 @@ class Ranger2020(Optimizer):
             beta1, beta2 = group["betas"]
             lr, wd, k = group["lr"], group["weight_decay"], group["k"]
             plan = self._plan(gi, active, dev)
-            rec = np.zeros(len(active), _REC)
+            rec = self._table(plan, active, dev)
             keep = []
+            grads = rec["grad"]
             for t, p in enumerate(active):
                 g = p.grad
-                if g.is_sparse:
-                    raise RuntimeError('Ranger optimizer does not support sparse gradients')
-                if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
-                    raise _lib.BratsHipError("Ranger2020: parameters must be contiguous f32 tensors on one GPU")
-                if g.dtype != torch.float32 or not g.is_contiguous():
+                if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
+                    if g.is_sparse:
+                        raise RuntimeError('Ranger optimizer does not support sparse gradients')
                     g = g.float().contiguous()
                     keep.append(g)
-                state = self.state[p]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    state['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    state['slow_buffer'] = p.detach().clone(memory_format=torch.contiguous_format)
-                else:
-                    for name in ('exp_avg', 'exp_avg_sq', 'slow_buffer'):  # after load_state_dict / .cpu() round trips
-                        s = state[name]
-                        if s.dtype != torch.float32 or s.device != dev or not s.is_contiguous():
-                            state[name] = s.to(device=dev, dtype=torch.float32).contiguous()
-                state['step'] = int(state['step']) + 1
-                adaptive, step_size = radam_step_size(state['step'], beta1, beta2, self.N_sma_threshhold)
-                rec[t] = (p.data_ptr(), g.data_ptr(), state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
-                          state['slow_buffer'].data_ptr(), p.numel(), plan["rowlen"][t], plan["rowbase"][t],
-                          -step_size * lr, wd, (1 if adaptive else 0) | (2 if state['step'] % k == 0 else 0), 0)
-            table = torch.from_numpy(rec.view(np.uint8)).to(dev, non_blocking=False)
+                grads[t] = g.data_ptr()
+            states = plan["states"]
+            steps = [st['step'] + 1 for st in states]
+            for st, v in zip(states, steps):
+                st['step'] = v
+            cache = {}
+            neg, flags = rec["neg_step"], rec["flags"]
+            for t, v in enumerate(steps):
+                c = cache.get(v)
+                if c is None:
+                    adaptive, step_size = radam_step_size(v, beta1, beta2, self.N_sma_threshhold)
+                    c = cache[v] = (-step_size * lr, (1 if adaptive else 0) | (2 if v % k == 0 else 0))
+                neg[t], flags[t] = c
+            rec["wd"] = wd
+            slot = plan["slot"]
+            plan["slot"] = (slot + 1) % 4
+            if plan["events"][slot] is not None:
+                plan["events"][slot].synchronize()
+            pinned = plan["pinned"][slot]
+            pinned.numpy()[:] = rec.view(np.uint8)
+            table = plan["dev_table"]
+            table.copy_(pinned, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            plan["events"][slot] = ev
             _lib.check(lib.brats_ranger_step(
                 table.data_ptr(), len(active), plan["chunks"].data_ptr(), plan["chunks"].shape[0],
                 plan["rows"].data_ptr() if plan["rows"] is not None else None, plan["nrows"], plan["means"].data_ptr(),
                 beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha, torch.cuda.current_stream().cuda_stream),
                 "ranger_step")
-            table.record_stream(torch.cuda.current_stream())
         return None
