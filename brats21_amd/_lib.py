@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbrats_hip.so")
+LIB_PATH = os.environ.get("BRATS_HIP_LIB") or os.path.join(_HERE, "libbrats_hip.so")  # override: A/B builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "brats_hip.h")
 
 F32, BF16 = 0, 1
