@@ -462,10 +462,7 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
   if (myvl < vl_n) {
     const T* dzb = dz + (size_t)n * voxels * dzpitch;
     const T* xb = x + (size_t)n * voxels * xpitch;
-    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
-      float g[VW], xx[VW];
-      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
-      Vec<T, VW>::load(xb + vox * xpitch + c0, xx);
+    auto body = [&](const float* g, const float* xx) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
         const float sg = sigmoidf_(xx[j]);
@@ -473,6 +470,23 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
         a2[j] += g[j] * xx[j] * sg;
         a3[j] += g[j] * sg * (1.f + xx[j] * (1.f - sg));
       }
+    };
+    const size_t stride = (size_t)gridDim.x * vl_n;
+    size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+    for (; vox + stride < (size_t)voxels; vox += 2 * stride) {  // two voxels (4 loads) in flight per thread
+      float g0[VW], x0[VW], g1[VW], x1[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g0);
+      Vec<T, VW>::load(xb + vox * xpitch + c0, x0);
+      Vec<T, VW>::load(dzb + (vox + stride) * dzpitch + c0, g1);
+      Vec<T, VW>::load(xb + (vox + stride) * xpitch + c0, x1);
+      body(g0, x0);
+      body(g1, x1);
+    }
+    if (vox < (size_t)voxels) {
+      float g0[VW], x0[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g0);
+      Vec<T, VW>::load(xb + vox * xpitch + c0, x0);
+      body(g0, x0);
     }
   }
   float* scr = sm;  // [vl_n][C][3]
@@ -535,25 +549,42 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
     }
   }
   __syncthreads();
-  const int cv = C / VW;
-  const size_t total = (size_t)voxels * cv;
-  const T* dzb = dz + (size_t)n * voxels * dzpitch;
-  const T* xb = x + (size_t)n * voxels * xpitch;
-  T* dxb = dx + (size_t)n * voxels * dxpitch;
-  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-    const size_t vox = it / cv;
-    const int c0 = (int)(it % cv) * VW;
-    float g[VW], xx[VW], o[VW];
-    Vec<T, VW>::load(dzb + vox * dzpitch + c0, g);
-    Vec<T, VW>::load(xb + vox * xpitch + c0, xx);
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  if (myvl >= vl_n) return;
+  float cg[VW], cm[VW], ck[VW];  // per-channel constants in registers (not re-read from LDS per element)
+#pragma unroll
+  for (int j = 0; j < VW; ++j) { cg[j] = gr[c0 + j]; cm[j] = mu[c0 + j]; ck[j] = kk[c0 + j]; }
+  const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
+  const T* xb = x + (size_t)n * voxels * xpitch + c0;
+  T* dxb = dx + (size_t)n * voxels * dxpitch + c0;
+  auto body = [&](const float* g, const float* xx, float* o) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      const int c = c0 + j;
       const float sg = sigmoidf_(xx[j]);
       const float dnum = sg * (1.f + xx[j] * (1.f - sg));
-      o[j] = g[j] * gr[c] * dnum - kk[c] * (xx[j] - mu[c]);
+      o[j] = g[j] * cg[j] * dnum - ck[j] * (xx[j] - cm[j]);
     }
-    Vec<T, VW>::store(dxb + vox * dxpitch + c0, o);
+  };
+  const size_t stride = (size_t)gridDim.x * vl_n;
+  size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+  for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+    float g0[VW], x0[VW], g1[VW], x1[VW], o0[VW], o1[VW];
+    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
+    Vec<T, VW>::load(xb + vox * xpitch, x0);
+    Vec<T, VW>::load(dzb + (vox + stride) * dzpitch, g1);
+    Vec<T, VW>::load(xb + (vox + stride) * xpitch, x1);
+    body(g0, x0, o0);
+    body(g1, x1, o1);
+    Vec<T, VW>::store(dxb + vox * dxpitch, o0);
+    Vec<T, VW>::store(dxb + (vox + stride) * dxpitch, o1);
+  }
+  if (vox < (size_t)voxels) {
+    float g0[VW], x0[VW], o0[VW];
+    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
+    Vec<T, VW>::load(xb + vox * xpitch, x0);
+    body(g0, x0, o0);
+    Vec<T, VW>::store(dxb + vox * dxpitch, o0);
   }
 }
 
@@ -571,9 +602,9 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
   if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "evonorm_bwd: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
-  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > 512 ? 512 : gx)), N);  // few fat blocks: 3C atomics per block onto N*3C addresses
   const size_t lds1 = (size_t)(vl * C * 3) * sizeof(float);
-  dim3 g2(stream_grid((size_t)voxels * cv, 256), N);
+  dim3 g2((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
   const size_t lds2 = (size_t)3 * C * sizeof(float);
   if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
@@ -606,16 +637,42 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T*
   if (myvl < vl_n) {
     const T* ab = a + (size_t)n * voxels * apitch;
     const T* bb = b ? b + (size_t)n * voxels * bpitch : nullptr;
-    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
-      float x[VW], y[VW];
-      Vec<T, VW>::load(ab + vox * apitch + c0, x);
-      if (bb) {
-        Vec<T, VW>::load(bb + vox * bpitch + c0, y);
+    const size_t stride = (size_t)gridDim.x * vl_n;
+    size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+    if (bb) {
+      for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+        float x0[VW], y0[VW], x1[VW], y1[VW];
+        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
+        Vec<T, VW>::load(bb + vox * bpitch + c0, y0);
+        Vec<T, VW>::load(ab + (vox + stride) * apitch + c0, x1);
+        Vec<T, VW>::load(bb + (vox + stride) * bpitch + c0, y1);
 #pragma unroll
-        for (int j = 0; j < VW; ++j) acc[j] += x[j] * y[j];
-      } else {
+        for (int j = 0; j < VW; ++j) acc[j] += x0[j] * y0[j];
 #pragma unroll
-        for (int j = 0; j < VW; ++j) acc[j] += x[j];
+        for (int j = 0; j < VW; ++j) acc[j] += x1[j] * y1[j];
+      }
+      if (vox < (size_t)voxels) {
+        float x0[VW], y0[VW];
+        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
+        Vec<T, VW>::load(bb + vox * bpitch + c0, y0);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += x0[j] * y0[j];
+      }
+    } else {
+      for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+        float x0[VW], x1[VW];
+        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
+        Vec<T, VW>::load(ab + (vox + stride) * apitch + c0, x1);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += x0[j];
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += x1[j];
+      }
+      if (vox < (size_t)voxels) {
+        float x0[VW];
+        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) acc[j] += x0[j];
       }
     }
   }
@@ -640,7 +697,7 @@ extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int b
   if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "channel_dot: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
-  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 512 ? 512 : gx)), N);
   const size_t lds = (size_t)vl * C * sizeof(float);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(channel_dot_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)a, apitch, (const bf16_t*)b, bpitch, out, voxels, C);
@@ -662,18 +719,31 @@ __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const 
     sm[C + c] = add ? add[(size_t)n * C + c] : 0.f;
   }
   __syncthreads();
-  const int cv = C / VW;
-  const size_t total = (size_t)voxels * cv;
-  const T* ab = a + (size_t)n * voxels * apitch;
-  T* db = dst + (size_t)n * voxels * dpitch;
-  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-    const size_t vox = it / cv;
-    const int c0 = (int)(it % cv) * VW;
-    float x[VW];
-    Vec<T, VW>::load(ab + vox * apitch + c0, x);
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  if (myvl >= vl_n) return;
+  float cs[VW], ca[VW];
 #pragma unroll
-    for (int j = 0; j < VW; ++j) x[j] = x[j] * sm[c0 + j] + sm[C + c0 + j];
-    Vec<T, VW>::store(db + vox * dpitch + c0, x);
+  for (int j = 0; j < VW; ++j) { cs[j] = sm[c0 + j]; ca[j] = sm[C + c0 + j]; }
+  const T* ab = a + (size_t)n * voxels * apitch + c0;
+  T* db = dst + (size_t)n * voxels * dpitch + c0;
+  const size_t stride = (size_t)gridDim.x * vl_n;
+  size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+  for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+    float x0[VW], x1[VW];
+    Vec<T, VW>::load(ab + vox * apitch, x0);
+    Vec<T, VW>::load(ab + (vox + stride) * apitch, x1);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { x0[j] = x0[j] * cs[j] + ca[j]; x1[j] = x1[j] * cs[j] + ca[j]; }
+    Vec<T, VW>::store(db + vox * dpitch, x0);
+    Vec<T, VW>::store(db + (vox + stride) * dpitch, x1);
+  }
+  if (vox < (size_t)voxels) {
+    float x0[VW];
+    Vec<T, VW>::load(ab + vox * apitch, x0);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) x0[j] = x0[j] * cs[j] + ca[j];
+    Vec<T, VW>::store(db + vox * dpitch, x0);
   }
 }
 
