@@ -1,0 +1,12 @@
+#!/bin/bash
+# Collects the round's committed evidence on the GPU box: bench line, rocprofv3 kernel stats of the same command,
+# per-layer conv table, and separate --pmc passes over the dominant conv shapes.  Outputs under gpurun_out/final/.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/final; mkdir -p $out
+python3 bench.py --steps 10 --warmup 3 --kernel-table > $out/bench.json 2> $out/conv_table.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline > $out/bench_profiled.log 2>&1
+cp $out/stats/*/*kernel_stats.csv $out/bench_kernel_stats.csv
+bash scripts/pmc.sh final/pmc scripts/prof_conv.py all > /dev/null 2>&1
+python3 scripts/pmc_report.py final/pmc > $out/pmc_conv.txt
+python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_assp.json
+tail -c 600 $out/bench.json; echo; cat $out/pmc_conv.txt | cut -c1-250
