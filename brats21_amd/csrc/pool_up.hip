@@ -154,35 +154,44 @@ DEVI Lerp lerp_coef(int o, int in_len, float scale) {
 }
 static inline float ac_scale(int in_len, int out_len) { return out_len > 1 ? (float)(in_len - 1) / (float)(out_len - 1) : 0.f; }
 
+// One block = one output row (n, zo, yo): the z / y interpolation coefficients and the four source-row pointers are
+// scalar; a thread handles (xo, channel vector) items of the row (no per-element div / mod chains).
 template <typename T>
-__global__ void upsample_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch, int N, int C, int D,
-                                    int H, int W, int sc, float sd, float sh, float sw) {
+__global__ void __launch_bounds__(256) upsample_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch,
+                                                           int N, int C, int D, int H, int W, int sc, float sd, float sh,
+                                                           float sw) {
   constexpr int VW = 16 / sizeof(T);
   const int cv = C / VW, Do = D * sc, Ho = H * sc, Wo = W * sc;
-  const size_t total = (size_t)N * Do * Ho * Wo * cv;
-  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(it % cv) * VW;
-    size_t v = it / cv;
-    const int xo = v % Wo; v /= Wo;
-    const int yo = v % Ho; v /= Ho;
-    const int zo = v % Do;
-    const int n = (int)(v / Do);
-    const Lerp lz = lerp_coef(zo, D, sd), ly = lerp_coef(yo, H, sh), lx = lerp_coef(xo, W, sw);
-    float o[VW];
+  for (size_t row = blockIdx.x; row < (size_t)N * Do * Ho; row += gridDim.x) {
+    const int yo = (int)(row % Ho);
+    const int zo = (int)((row / Ho) % Do);
+    const int n = (int)(row / ((size_t)Ho * Do));
+    const Lerp lz = lerp_coef(zo, D, sd), ly = lerp_coef(yo, H, sh);
+    const T* xb = x + (size_t)n * D * H * W * xpitch;
+    const T* r00 = xb + (size_t)(lz.i0 * H + ly.i0) * W * xpitch;
+    const T* r01 = xb + (size_t)(lz.i0 * H + ly.i1) * W * xpitch;
+    const T* r10 = xb + (size_t)(lz.i1 * H + ly.i0) * W * xpitch;
+    const T* r11 = xb + (size_t)(lz.i1 * H + ly.i1) * W * xpitch;
+    T* yb = y + row * Wo * ypitch;
+    for (int it = threadIdx.x; it < Wo * cv; it += blockDim.x) {
+      const int xo = it / cv, c0 = (it % cv) * VW;
+      const Lerp lx = lerp_coef(xo, W, sw);
+      float o[VW];
 #pragma unroll
-    for (int j = 0; j < VW; ++j) o[j] = 0.f;
-    const T* xb = x + (size_t)n * D * H * W * xpitch + c0;
+      for (int j = 0; j < VW; ++j) o[j] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int z = (k & 4) ? lz.i1 : lz.i0, yy = (k & 2) ? ly.i1 : ly.i0, xx = (k & 1) ? lx.i1 : lx.i0;
-      // same association as ATen's upsample_trilinear3d: w_z * (w_y * (w_x * v ...)) -> use product of weights
-      const float w = ((k & 4) ? lz.w1 : lz.w0) * ((k & 2) ? ly.w1 : ly.w0) * ((k & 1) ? lx.w1 : lx.w0);
-      float a[VW];
-      Vec<T, VW>::load(xb + ((size_t)(z * H + yy) * W + xx) * xpitch, a);
+      for (int k = 0; k < 8; ++k) {
+        const T* r = (k & 4) ? ((k & 2) ? r11 : r10) : ((k & 2) ? r01 : r00);
+        const int xx = (k & 1) ? lx.i1 : lx.i0;
+        // same association as ATen's upsample_trilinear3d: w_z * (w_y * (w_x * v ...)) -> use product of weights
+        const float w = ((k & 4) ? lz.w1 : lz.w0) * ((k & 2) ? ly.w1 : ly.w0) * ((k & 1) ? lx.w1 : lx.w0);
+        float a[VW];
+        Vec<T, VW>::load(r + (size_t)xx * xpitch + c0, a);
 #pragma unroll
-      for (int j = 0; j < VW; ++j) o[j] += w * a[j];
+        for (int j = 0; j < VW; ++j) o[j] += w * a[j];
+      }
+      Vec<T, VW>::store(yb + (size_t)xo * ypitch + c0, o);
     }
-    Vec<T, VW>::store(y + ((((size_t)n * Do + zo) * Ho + yo) * Wo + xo) * ypitch + c0, o);
   }
 }
 
@@ -191,14 +200,15 @@ extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !y || C % vw || xpitch % vw || ypitch % vw || scale < 1)
     BRATS_FAIL(BRATS_E_ARG, "upsample_fwd: C/pitch must be multiples of %d", vw);
-  const size_t total = (size_t)N * D * H * W * scale * scale * scale * (C / vw);
+  const size_t rows = (size_t)N * D * scale * H * scale;
+  const unsigned grid = (unsigned)(rows > 65536 ? 65536 : rows);
   const float sd = ac_scale(D, D * scale), sh = ac_scale(H, H * scale), sw = ac_scale(W, W * scale);
   if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
-                       (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);
+    hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, xpitch,
+                       (bf16_t*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);
   else
-    hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)x, xpitch, (float*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);
+    hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const float*)x, xpitch,
+                       (float*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
