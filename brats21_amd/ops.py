@@ -126,10 +126,32 @@ def conv_chunk(dtype, ksize, dil, c1, c2=0):
     return ck
 
 
+_PACK_CACHE = {}  # inference only: packed weights keyed by (storage pointer, version counter, layout arguments)
+
+
 def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c1=None):
     """w: torch-layout [Cout, Cin, k, k, k] f32 parameter -> packed MFMA-fragment buffer.
     mode PACK_FWD: GEMM rows = Cout, K = Cin (zero-padded to cin_pad); PACK_DGRAD: rows = Cin slice,
-    K = Cout, taps flipped."""
+    K = Cout, taps flipped.
+
+    Under ``torch.no_grad()`` (sliding-window / TTA inference: 144 forwards of the same weights per volume) the
+    packed buffer is cached; the key carries the tensor's version counter, which every in-place update bumps
+    (optimizer steps incl. brats21_amd.optim.Ranger2020, load_state_dict, SWA averaging)."""
+    key = None
+    if not torch.is_grad_enabled():
+        key = (w.data_ptr(), w._version, tuple(w.shape), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit
+    packed = _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1)
+    if key is not None:
+        if len(_PACK_CACHE) >= 1024:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = packed
+    return packed
+
+
+def _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1):
     cout_w, cin_w, k = w.shape[0], w.shape[1], w.shape[2]
     w = w.detach()
     if cin_pad is not None and cin_pad != cin_w:

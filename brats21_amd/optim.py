@@ -173,4 +173,6 @@ class Ranger2020(Optimizer):
                 plan["rows"].data_ptr() if plan["rows"] is not None else None, plan["nrows"], plan["means"].data_ptr(),
                 beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha, torch.cuda.current_stream().cuda_stream),
                 "ranger_step")
+            for p in active:  # the kernel wrote through raw pointers: tell autograd / the packed-weight cache
+                torch.autograd.graph.increment_version(p)
         return None

@@ -82,3 +82,37 @@ def test_network_sliding_window_tta_graph_vs_oracle():
         p = tta_predict(xp.to(dev), graphed, comp)
         p_ref = oinf.tta_predict(xp, ref_pred)
         assert float((p.cpu() - p_ref).abs().max()) < 5e-4
+
+
+def test_packed_weight_cache_tracks_weight_updates():
+    """Inference caches packed weights under no_grad; an optimizer step / in-place update must invalidate them."""
+    from brats21_amd import get_model, ops
+    from brats21_amd.optim import Ranger2020
+    dev = torch.device("cuda:0")
+    m = get_model(argparse.Namespace(model="equiunet", width=8, norm="group", act="relu", num_classes=3, dropout=0)).to(dev)
+    m.precision = "fp32"
+    x = synth.closed_form_image(1, 4, (16, 16, 16), "cachex").to(dev)
+    opt = Ranger2020(m.parameters(), lr=1e-2, use_gc=False)
+    m.eval()
+    with torch.no_grad():
+        y0 = m(x)[0].clone() if isinstance(m(x), (tuple, list)) else m(x).clone()
+        n_cached = len(ops._PACK_CACHE)
+        y0b = m(x)[0] if isinstance(m(x), (tuple, list)) else m(x)
+        assert n_cached > 0 and len(ops._PACK_CACHE) == n_cached and torch.equal(y0, y0b)
+    m.train()
+    out = m(x)
+    loss = out[0].float().mean() + sum(o.float().mean() for o in out[1])
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    m.eval()
+    with torch.no_grad():
+        r = m(x)
+        y1 = r[0] if isinstance(r, (tuple, list)) else r
+        assert not torch.equal(y0, y1), "stale packed weights after an optimizer step"
+        with torch.no_grad():
+            p = next(m.parameters())
+            p.mul_(1.5)
+        r = m(x)
+        y2 = r[0] if isinstance(r, (tuple, list)) else r
+        assert not torch.equal(y1, y2), "stale packed weights after an in-place update"
