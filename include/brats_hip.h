@@ -241,6 +241,28 @@ int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int*
                       float one_minus_beta1, float one_minus_beta2, float eps, float alpha,
                       brats_stream_t s);
 
+/* ---- input pipeline on the GPU (the reference's CPU transform chain,
+ * src/definer.py:449-467).  NCDHW f32.
+ * crop_perm: dst axis a runs along source axis p_a over the crop box [c, c+e) of the source, reversed
+ *   when f_a, then v*scale[plane] + shift[plane] (either may be NULL): RandSpatialCropd + RandRotate90d +
+ *   RandFlipd + RandShiftIntensityd (/ scale) in one gather.  dst dims = (e[p0], e[p1], e[p2]).
+ * label_to_channels: BraTS labels {0,1,2,4} -> 3 binary channels; order 0 = (TC, WT, ET) (MONAI
+ *   ConvertToMultiChannelBasedOnBratsClassesd, src/definer.py:451), 1 = (WT, TC, ET)
+ *   (utils/transforms.py:155-166).
+ * zscore_normalize: NormalizeIntensity(nonzero, channel_wise=True[, remove_outliers -> clip])
+ *   (utils/transforms.py:328-406): per plane, over the non-zero voxels, (x - mean) / population std
+ *   (1 when 0), clip > 0 clamps to +-clip; zeros stay zero.  stats = f64 workspace [planes][3].
+ * gamma_noise: MONAI AdjustContrast ((x - min)/(range + 1e-7))^gamma * range + min (gamma <= 0: skipped)
+ *   followed by + noise (may be NULL): RandAdjustContrastd + RandGaussianNoised (:463-464). */
+int brats_crop_perm(const float* src, float* dst, int planes, int s0, int s1, int s2, int c0, int c1, int c2,
+                    int e0, int e1, int e2, int p0, int p1, int p2, int f0, int f1, int f2,
+                    const float* scale, const float* shift, brats_stream_t s);
+int brats_label_to_channels(const float* label, float* out, int N, size_t voxels, int order, brats_stream_t s);
+int brats_zscore_normalize(const float* x, float* y, double* stats, int planes, size_t voxels, int nonzero,
+                           float clip, brats_stream_t s);
+int brats_gamma_noise(const float* x, float* y, size_t total, float vmin, float vrange, float gamma,
+                      const float* noise, brats_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

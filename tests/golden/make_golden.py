@@ -254,6 +254,28 @@ def ranger_fixture():
     print("ranger.npz", len(res), "arrays")
 
 
+def prep_fixture():
+    """Input pipeline: the reference's own NormalizeIntensity (utils/transforms.py:328-406) and its
+    ConvertToMultiChannelBasedOnBratsClassesd (:145-166) on seeded inputs."""
+    from utils.transforms import NormalizeIntensity, ConvertToMultiChannelBasedOnBratsClassesd
+    rng = np.random.RandomState(7)
+    img = (rng.rand(4, 9, 10, 11).astype(np.float32) * 300.0 + 20.0) * (rng.rand(4, 9, 10, 11) > 0.35)
+    img[3] = 0.0                      # a channel without any non-zero voxel is returned unchanged
+    img[2][img[2] != 0] = 57.0        # zero variance -> divisor 1
+    res = {"img": img.astype(np.float32)}
+    for tag, kw in (("nz", dict(nonzero=True, channel_wise=True)),
+                    ("nz_clip", dict(nonzero=True, channel_wise=True, remove_outliers=True, outliers_value=1.5)),
+                    ("all", dict(nonzero=False, channel_wise=True))):
+        res["norm_" + tag] = NormalizeIntensity(**kw)(img.astype(np.float32).copy())
+    label = rng.choice(np.array([0, 1, 2, 4], dtype=np.float32), size=(6, 7, 8))
+    conv = ConvertToMultiChannelBasedOnBratsClassesd.__new__(ConvertToMultiChannelBasedOnBratsClassesd)
+    conv.keys = ["seg"]  # the stub MapTransform base has no __init__
+    res["label"] = label
+    res["label_utils"] = conv({"seg": label})["seg"]
+    np.savez_compressed(os.path.join(OUT, "prep.npz"), **res)
+    print("prep.npz", {k: getattr(v, "shape", None) for k, v in res.items()})
+
+
 if __name__ == "__main__":
     # src/definer.py imports half of MONAI at module import; restate only its 6-line TTA list
     # constructor call (src/definer.py:653-657) against the reference's own tta package.
@@ -263,7 +285,7 @@ if __name__ == "__main__":
     m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
                                      t.Rotate90(angles=[0, 90, 180, 270])])
     sys.modules["src_definer_tta"] = m
-    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger"]
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep"]
     if "equiunet" in which:
         equiunet_fixtures()
     if "assp" in which:
@@ -276,3 +298,5 @@ if __name__ == "__main__":
         post_fixtures()
     if "ranger" in which:
         ranger_fixture()
+    if "prep" in which:
+        prep_fixture()

@@ -178,3 +178,27 @@ def test_ranger_oracle_matches_reference(golden_dir):
         return {"step": step, "state": lambda n: states[n]}
 
     ranger_replay(golden_dir, lambda t: t.clone(), step_fn, lambda t: t.numpy())
+
+
+def test_input_pipeline_vectors(golden_dir):
+    """oracle/prep.py against the reference's NormalizeIntensity / label conversion (tests/golden/prep.npz) and
+    known answers for the MONAI-side augmentations."""
+    from oracle import prep
+    g = np.load(os.path.join(golden_dir, "prep.npz"))
+    img = g["img"]
+    np.testing.assert_allclose(prep.normalize_intensity(img), g["norm_nz"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prep.normalize_intensity(img, remove_outliers=True, outliers_value=1.5), g["norm_nz_clip"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prep.normalize_intensity(img, nonzero=False), g["norm_all"], rtol=0, atol=1e-6)
+    assert np.array_equal(g["norm_nz"][3], img[3]) and float(np.abs(g["norm_nz"][2]).max()) == 0.0
+    np.testing.assert_array_equal(prep.convert_to_multichannel(g["label"], "utils"), g["label_utils"])
+    m = prep.convert_to_multichannel(g["label"], "monai")
+    np.testing.assert_array_equal(m[0], g["label_utils"][1])
+    np.testing.assert_array_equal(m[1], g["label_utils"][0])
+    # known answers: rot90 over spatial axes (0, 2), flip of all axes, AdjustContrast end points
+    a = np.arange(2 * 2 * 1 * 3, dtype=np.float32).reshape(2, 2, 1, 3)
+    r = prep.rotate90(a, 1)
+    assert r.shape == (2, 3, 1, 2) and r[0, 0, 0, 0] == a[0, 0, 0, 2] and r[0, 2, 0, 1] == a[0, 1, 0, 0]
+    f = prep.flip(a)
+    assert f[1, 0, 0, 0] == a[1, 1, 0, 2]
+    c = prep.adjust_contrast(np.array([[[[1.0, 3.0, 5.0]]]], dtype=np.float32), 2.0)
+    np.testing.assert_allclose(c.ravel(), [1.0, 2.0, 5.0], atol=1e-5)
