@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--optimizer", default="ranger", choices=["ranger", "adam"],
                     help="ranger = the reference's default (--optimizer ranger, src/arguments_train.py:120), fused HIP step")
     ap.add_argument("--use-gc", action="store_true", help="Ranger gradient centralisation (reference default: off)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one hipGraph (single GPU; no per-kernel timers, so roofline is null)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
     args = ap.parse_args()
 
@@ -135,7 +137,7 @@ def main():
     if args.optimizer == "ranger":  # src/definer.py:316-331 + the CLI defaults lr 1e-4, weight_decay 1e-5
         with contextlib.redirect_stdout(io.StringIO()):
             opt = Ranger2020(model.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5,
-                             weight_decay=1e-5, use_gc=args.use_gc)
+                             weight_decay=1e-5, use_gc=args.use_gc, capturable=args.graph)
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
     buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None
@@ -145,12 +147,17 @@ def main():
     use_amp = args.precision == "bf16"
     train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets)
 
+    if args.graph:
+        assert world == 1 and args.optimizer == "ranger", "--graph: single GPU, ranger optimizer"
+        from brats21_amd.engine import GraphedTrainStep
+        train_step = GraphedTrainStep(train_step, warmup=2)
+
     def step():
         return train_step(x, t)
 
     for _ in range(args.warmup):
         step()
-    timer = ops.KernelTimer() if rank == 0 else None
+    timer = ops.KernelTimer() if rank == 0 and not args.graph else None
     ops.TIMER = timer
     if world > 1:
         dist.barrier()
@@ -173,24 +180,29 @@ def main():
         return
 
     # ---- roofline of the dominant kernel, from HIP events recorded inside the timed steps ----
-    table = timer.summary()
+    if timer is None:  # --graph: one graph launch per step, no per-kernel HIP events
+        roofline = None
+        table = {}
+    else:
+        table = timer.summary()
     fam = {}
     for key, (cnt, avg, tot) in table.items():
         fam.setdefault(key[0], [0.0, 0.0])
         kind, cin, cout, k, dil, n, d, h, w, dt = key
         fam[kind][0] += tot
         fam[kind][1] += conv_flops(cin, cout, k, n, d, h, w) * cnt
-    dom_key = max(table, key=lambda k: table[k][2])
-    cnt, avg_ms, tot_ms = table[dom_key]
-    kind, cin, cout, k, dil, n, d, h, w, dt = dom_key
-    fl = conv_flops(cin, cout, k, n, d, h, w)
-    peak = PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS
-    achieved = fl / (avg_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": f"{kind} cin={cin} cout={cout} k={k} dil={dil} @{n}x{d}x{h}x{w}",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "launches": cnt, "avg_ms": round(avg_ms, 4),
-                "families": {f: {"ms_per_step": round(v[0] / args.steps, 3), "TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
-                             for f, v in fam.items()}}
+    if table:
+      dom_key = max(table, key=lambda k: table[k][2])
+      cnt, avg_ms, tot_ms = table[dom_key]
+      kind, cin, cout, k, dil, n, d, h, w, dt = dom_key
+      fl = conv_flops(cin, cout, k, n, d, h, w)
+      peak = PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS
+      achieved = fl / (avg_ms * 1e-3) / 1e12
+      roofline = {"bound": "mfma", "kernel": f"{kind} cin={cin} cout={cout} k={k} dil={dil} @{n}x{d}x{h}x{w}",
+                  "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                  "traffic": None, "launches": cnt, "avg_ms": round(avg_ms, 4),
+                  "families": {f: {"ms_per_step": round(v[0] / args.steps, 3), "TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
+                               for f, v in fam.items()}}
     if args.kernel_table:
         for key in sorted(table, key=lambda k: -table[k][2]):
             c, a, tt = table[key]

@@ -29,8 +29,8 @@ __global__ void __launch_bounds__(256) ranger_row_means_kernel(const brats_range
 
 __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_tensor* __restrict__ tab,
                                                             const int* __restrict__ chunks, const float* __restrict__ means,
-                                                            float beta1, float beta2, float omb1, float omb2, float eps,
-                                                            float alpha) {
+                                                            const brats_ranger_dyn* __restrict__ dyn, float beta1, float beta2,
+                                                            float omb1, float omb2, float eps, float alpha) {
   const int t = chunks[blockIdx.x * 2];
   const long base = (long)chunks[blockIdx.x * 2 + 1] * RANGER_CHUNK;
   const brats_ranger_tensor T = tab[t];
@@ -39,7 +39,10 @@ __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_t
   float* __restrict__ m = (float*)T.exp_avg;
   float* __restrict__ v = (float*)T.exp_avg_sq;
   float* __restrict__ slow = (float*)T.slow;
-  const bool adaptive = T.flags & 1, look = T.flags & 2, gc = T.rowlen > 0;
+  // graph-captured steps read the step-dependent scalars from device memory (written by ranger_advance_kernel)
+  const int flags = dyn ? dyn->flags : T.flags;
+  const float neg_step = dyn ? dyn->neg_step : T.neg_step;
+  const bool adaptive = flags & 1, look = flags & 2, gc = T.rowlen > 0;
   const long end = base + RANGER_CHUNK < T.numel ? base + RANGER_CHUNK : T.numel;
   for (long i = base + threadIdx.x; i < end; i += 256) {
     float gi = g[i];
@@ -52,7 +55,7 @@ __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_t
       G = G + T.wd * pi;
       if (!adaptive) mi = G;  // the reference's G_grad aliases exp_avg here (learning/optimizer.py:220-223)
     }
-    pi = pi + T.neg_step * G;
+    pi = pi + neg_step * G;
     if (look) {
       const float si = slow[i] + alpha * (pi - slow[i]);
       slow[i] = si;
@@ -64,11 +67,41 @@ __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_t
   }
 }
 
+// step += 1; neg_step / flags of learning/optimizer.py:198-214 in f64 on the device (one thread), so that a captured
+// hipGraph can be replayed without any host-side change between steps
+__global__ void ranger_advance_kernel(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k, double nsma_thr) {
+  const int step = dyn->step + 1;
+  const double b2t = pow(beta2, (double)step);
+  const double nmax = 2.0 / (1.0 - beta2) - 1.0;
+  const double nsma = nmax - 2.0 * step * b2t / (1.0 - b2t);
+  const double b1c = 1.0 - pow(beta1, (double)step);
+  double ss;
+  int flags = 0;
+  if (nsma > nsma_thr) {
+    ss = sqrt((1.0 - b2t) * (nsma - 4.0) / (nmax - 4.0) * (nsma - 2.0) / nsma * nmax / (nmax - 2.0)) / b1c;
+    flags |= 1;
+  } else {
+    ss = 1.0 / b1c;
+  }
+  if (step % k == 0) flags |= 2;
+  dyn->step = step;
+  dyn->flags = flags;
+  dyn->neg_step = (float)(-ss * lr);
+}
+
 extern "C" int brats_ranger_chunk(void) { return RANGER_CHUNK; }
 
+extern "C" int brats_ranger_advance(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k, double nsma_threshold,
+                                    brats_stream_t s) {
+  if (!dyn || k < 1) BRATS_FAIL(BRATS_E_ARG, "ranger_advance: bad argument");
+  hipLaunchKernelGGL(ranger_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, dyn, lr, beta1, beta2, k, nsma_threshold);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int* chunks, int nchunks, const int* rows,
-                                 int nrows, float* row_means, float beta1, float beta2, float one_minus_beta1,
-                                 float one_minus_beta2, float eps, float alpha, brats_stream_t s) {
+                                 int nrows, float* row_means, const brats_ranger_dyn* dyn, float beta1, float beta2,
+                                 float one_minus_beta1, float one_minus_beta2, float eps, float alpha, brats_stream_t s) {
   if (!table || ntensors <= 0 || !chunks || nchunks <= 0) BRATS_FAIL(BRATS_E_ARG, "ranger_step: empty tensor / chunk table");
   if (nrows > 0 && (!rows || !row_means)) BRATS_FAIL(BRATS_E_ARG, "ranger_step: gradient centralisation needs rows + row_means");
   hipStream_t st = (hipStream_t)s;
@@ -76,7 +109,7 @@ extern "C" int brats_ranger_step(const brats_ranger_tensor* table, int ntensors,
     hipLaunchKernelGGL(ranger_row_means_kernel, dim3(nrows), dim3(256), 0, st, table, rows, row_means);
     BRATS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(ranger_update_kernel, dim3(nchunks), dim3(256), 0, st, table, chunks, row_means, beta1, beta2,
+  hipLaunchKernelGGL(ranger_update_kernel, dim3(nchunks), dim3(256), 0, st, table, chunks, row_means, dyn, beta1, beta2,
                      one_minus_beta1, one_minus_beta2, eps, alpha);
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -40,3 +40,47 @@ class TrainStep:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
         self.optimizer.step()
         return loss
+
+
+class GraphedTrainStep:
+    """A TrainStep captured once into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: forward, fused Dice,
+    the backward program, and the optimizer step become ONE graph launch instead of 350-600 kernel launches, which
+    takes the Python / launch path off the critical path (EquiUnetASSPEvo is launch-bound on slow hosts: 23 vs 28 ms).
+
+    Requirements: fixed input shapes, an optimizer whose step is capturable (brats21_amd.optim.Ranger2020(capturable=
+    True), or a torch optimizer constructed with capturable=True), no gradient buckets (single GPU).  ``warmup`` eager
+    steps run on the first batch before the capture (lazy initialisation, allocator warm-up): they are real steps.
+    The learning rate is baked into the graph: re-create the object after changing it."""
+
+    def __init__(self, step, warmup=2):
+        if step.buckets is not None:
+            raise NotImplementedError("GraphedTrainStep: capture with gradient buckets (multi-GPU) is not supported yet")
+        if not getattr(step.optimizer, "capturable", False) and not all(
+                g.get("capturable", False) for g in step.optimizer.param_groups):
+            raise ValueError("GraphedTrainStep needs a capturable optimizer (e.g. brats21_amd.optim.Ranger2020(capturable=True))")
+        self.step, self.warmup = step, warmup
+        self.graph = self.static_image = self.static_target = self.static_loss = None
+
+    def _capture(self, image, target):
+        self.static_image, self.static_target = image.clone(), target.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.step(self.static_image, self.static_target)
+        torch.cuda.current_stream().wait_stream(side)
+        self.step.model.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self.step(self.static_image, self.static_target)
+
+    def __call__(self, image, target):
+        if self.graph is None:
+            self._capture(image, target)
+        else:
+            if image.data_ptr() != self.static_image.data_ptr():
+                self.static_image.copy_(image, non_blocking=True)
+            if target.data_ptr() != self.static_target.data_ptr():
+                self.static_target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.static_loss

@@ -31,7 +31,8 @@ def radam_step_size(step, beta1, beta2, n_sma_threshold):
 
 class Ranger2020(Optimizer):
     def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=0,
-                 use_gc=True, use_gcnorm=False, normloss=False, normloss_factor=1e-4, gc_conv_only=False, gc_loc=True):
+                 use_gc=True, use_gcnorm=False, normloss=False, normloss_factor=1e-4, gc_conv_only=False, gc_loc=True,
+                 capturable=False):
         if not 0.0 <= alpha <= 1.0:
             raise ValueError(f'Invalid slow update rate: {alpha}')
         if not 1 <= k:
@@ -48,6 +49,10 @@ class Ranger2020(Optimizer):
         super().__init__(params, defaults)
         self.N_sma_threshhold, self.alpha, self.k = N_sma_threshhold, alpha, k
         self.use_gc, self.gc_conv_only, self.eps = use_gc, gc_conv_only, eps
+        # capturable (extension, like torch.optim.Adam's): the step counter and the RAdam scalars live on the device,
+        # so a step captured into a hipGraph (engine.GraphedTrainStep) replays without host-side changes.  All
+        # parameters of a group then share one step count, and lr is baked into the captured graph.
+        self.capturable = capturable
         self._plans = {}
 
     # ------------------------------------------------------------------------------------------ static plan
@@ -87,6 +92,18 @@ class Ranger2020(Optimizer):
         super().load_state_dict(state_dict)
         self._plans = {}  # the state tensors were replaced: cached pointer tables are stale
 
+    def sync_steps(self):
+        """capturable mode: graph replays advance only the device-side step counters; copy them into state['step']."""
+        for plan in self._plans.values():
+            if plan.get("dyn") is not None:
+                step = int(plan["dyn"][0].item())
+                for st in plan["states"]:
+                    st['step'] = step
+
+    def state_dict(self):
+        self.sync_steps()
+        return super().state_dict()
+
     def _table(self, plan, active, dev):
         """Host copy of the per-tensor records.  Parameter / state pointers and shapes never change between steps
         (cached); per step only the gradient pointers and the step-dependent scalars are rewritten -- the reference's
@@ -115,6 +132,7 @@ class Ranger2020(Optimizer):
             plan["states"] = [self.state[p] for p in active]
             # pinned staging ring: the H2D copy of the table is asynchronous, a slot is reused only after its copy ran
             plan["pinned"] = [torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
+            plan["pinned_capture"] = torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory()  # see step(): capture mode
             plan["events"] = [None] * 4
             plan["dev_table"] = torch.empty(rec.nbytes, dtype=torch.uint8, device=dev)
             plan["slot"] = 0
@@ -157,22 +175,42 @@ class Ranger2020(Optimizer):
                     c = cache[v] = (-step_size * lr, (1 if adaptive else 0) | (2 if v % k == 0 else 0))
                 neg[t], flags[t] = c
             rec["wd"] = wd
-            slot = plan["slot"]
-            plan["slot"] = (slot + 1) % 4
-            if plan["events"][slot] is not None:
-                plan["events"][slot].synchronize()
-            pinned = plan["pinned"][slot]
-            pinned.numpy()[:] = rec.view(np.uint8)
+            capturing = torch.cuda.is_current_stream_capturing()
+            stream = torch.cuda.current_stream().cuda_stream
+            dyn = None
+            if self.capturable:
+                if len(cache) != 1:
+                    raise _lib.BratsHipError("Ranger2020(capturable=True): all parameters of a group must share one step count")
+                dyn = plan.get("dyn")
+                if dyn is None:  # {step, flags, neg_step, reserved}; starts at the step count BEFORE this step
+                    dyn = plan["dyn"] = torch.tensor([steps[0] - 1, 0, 0, 0], dtype=torch.int32, device=dev)
+                _lib.check(lib.brats_ranger_advance(dyn.data_ptr(), float(lr), float(beta1), float(beta2), int(k),
+                                                    float(self.N_sma_threshhold), stream), "ranger_advance")
+            elif capturing:
+                raise _lib.BratsHipError("Ranger2020.step() inside a hipGraph capture needs capturable=True")
             table = plan["dev_table"]
-            table.copy_(pinned, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            plan["events"][slot] = ev
+            if capturing:
+                # the memcpy node re-reads this buffer at every replay: a buffer nobody rewrites afterwards (allocated with
+                # the plan -- pinning memory is not allowed while a stream is capturing)
+                pinned = plan["pinned_capture"]
+                pinned.numpy()[:] = rec.view(np.uint8)
+                table.copy_(pinned, non_blocking=True)
+            else:
+                slot = plan["slot"]
+                plan["slot"] = (slot + 1) % 4
+                if plan["events"][slot] is not None:
+                    plan["events"][slot].synchronize()
+                pinned = plan["pinned"][slot]
+                pinned.numpy()[:] = rec.view(np.uint8)
+                table.copy_(pinned, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                plan["events"][slot] = ev
             _lib.check(lib.brats_ranger_step(
                 table.data_ptr(), len(active), plan["chunks"].data_ptr(), plan["chunks"].shape[0],
                 plan["rows"].data_ptr() if plan["rows"] is not None else None, plan["nrows"], plan["means"].data_ptr(),
-                beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha, torch.cuda.current_stream().cuda_stream),
-                "ranger_step")
+                dyn.data_ptr() if dyn is not None else None, beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha,
+                stream), "ranger_step")
             for p in active:  # the kernel wrote through raw pointers: tell autograd / the packed-weight cache
                 torch.autograd.graph.increment_version(p)
         return None

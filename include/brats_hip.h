@@ -235,11 +235,23 @@ typedef struct {
   int flags;
   int reserved;
 } brats_ranger_tensor;
+/* Graph-capturable stepping: `dyn` (device) holds the step counter and the two step-dependent scalars;
+ * brats_ranger_advance increments the counter and recomputes them on the device (f64), and
+ * brats_ranger_step with dyn != NULL reads them instead of the table's neg_step / flags -- a captured
+ * hipGraph of (advance, step) replays without host-side changes.  dyn == NULL: host-computed scalars. */
+typedef struct {
+  int step;
+  int flags;
+  float neg_step;
+  int reserved;
+} brats_ranger_dyn;
 int brats_ranger_chunk(void);
+int brats_ranger_advance(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k,
+                         double nsma_threshold, brats_stream_t s);
 int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int* chunks, int nchunks,
-                      const int* rows, int nrows, float* row_means, float beta1, float beta2,
-                      float one_minus_beta1, float one_minus_beta2, float eps, float alpha,
-                      brats_stream_t s);
+                      const int* rows, int nrows, float* row_means, const brats_ranger_dyn* dyn,
+                      float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
+                      float alpha, brats_stream_t s);
 
 /* ---- input pipeline on the GPU (the reference's CPU transform chain,
  * src/definer.py:449-467).  NCDHW f32.

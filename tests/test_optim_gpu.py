@@ -71,3 +71,45 @@ def test_ranger_full_model_vs_oracle_and_state_dict_roundtrip():
         Ranger2020(params, normloss=True)
     with pytest.raises(ValueError):
         Ranger2020(params, alpha=1.5)
+
+
+def test_graphed_train_step_matches_eager():
+    """The whole step (fwd + fused Dice + bwd + capturable Ranger) captured into one hipGraph replays to the same
+    parameters as the eager TrainStep (bf16 kernels are deterministic), across the step-5 -> 6 RAdam switch and the
+    lookahead sync at step 6."""
+    from brats21_amd import get_model
+    from brats21_amd.engine import GraphedTrainStep, TrainStep
+    from brats21_amd.optim import Ranger2020
+    from oracle import synth
+    ns = argparse.Namespace(model="equiunet", width=8, norm="group", act="relu", num_classes=3, dropout=0)
+    xs = [synth.random_image(1, 4, (16, 16, 16), seed=20 + i).to(DEV) for i in range(8)]
+    t = synth.nested_spheres(1, (16, 16, 16)).to(DEV)
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = get_model(ns).to(DEV).train()
+        opt = Ranger2020(m.parameters(), lr=1e-2, weight_decay=1e-5, use_gc=True, capturable=graphed)
+        step = TrainStep(m, opt, amp=True)
+        if graphed:
+            step = GraphedTrainStep(step, warmup=2)
+            # the two warm-up steps run on the first batch: replay the same schedule eagerly below
+        losses = []
+        seq = [xs[0], xs[0], xs[0]] + xs[1:] if graphed else [xs[0], xs[0], xs[0]] + xs[1:]
+        if graphed:
+            losses.append(float(step(xs[0], t).detach()))       # 2 eager warm-ups + capture + 1 replay = steps 1..3 on xs[0]
+            for x in xs[1:]:
+                losses.append(float(step(x, t).detach()))
+        else:
+            for i, x in enumerate(seq):
+                l = float(step(x, t).detach())
+                if i >= 2:
+                    losses.append(l)
+        torch.cuda.synchronize()
+        results.append((losses, [p.detach().clone() for p in m.parameters()], opt))
+    (l0, p0, o0), (l1, p1, o1) = results
+    assert len(l0) == len(l1) == 8
+    np.testing.assert_allclose(l0, l1, rtol=1e-5, atol=1e-6)
+    worst = max(float((a - b).abs().max()) for a, b in zip(p0, p1))
+    assert worst < 1e-5, worst
+    assert o1.state_dict()["state"][0]["step"] == 10 == o0.state_dict()["state"][0]["step"]
