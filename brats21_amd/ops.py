@@ -5,6 +5,8 @@ torch.float32; a tensor may be a channel-slice *view* of a wider buffer (pitch =
 is how torch.cat (networks/equiunet2020.py:478-486 of the reference) is removed.  PyTorch is only
 the allocator / stream provider here; every arithmetic op is a HIP kernel of the library.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -126,7 +128,7 @@ def conv_chunk(dtype, ksize, dil, c1, c2=0):
     return ck
 
 
-_PACK_CACHE = {}  # inference only: packed weights keyed by (storage pointer, version counter, layout arguments)
+_PACK_CACHE = {}  # inference only: packed weights keyed by (tensor object, layout arguments), validated by version counter
 
 
 def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c1=None):
@@ -139,15 +141,17 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c
     (optimizer steps incl. brats21_amd.optim.Ranger2020, load_state_dict, SWA averaging)."""
     key = None
     if not torch.is_grad_enabled():
-        key = (w.data_ptr(), w._version, tuple(w.shape), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
+        # keyed by the tensor OBJECT (weak reference: a new tensor that reuses a freed address must not hit) and its
+        # version counter
+        key = (id(w), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
         hit = _PACK_CACHE.get(key)
-        if hit is not None:
-            return hit
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+            return hit[3]
     packed = _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1)
     if key is not None:
         if len(_PACK_CACHE) >= 1024:
             _PACK_CACHE.clear()
-        _PACK_CACHE[key] = packed
+        _PACK_CACHE[key] = (weakref.ref(w), w._version, w.data_ptr(), packed)
     return packed
 
 
