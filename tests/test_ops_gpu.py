@@ -349,3 +349,34 @@ def test_conv3d_wgrad_alltaps_vs_torch_full_volume():
     torch.set_num_threads(16)
     F.conv3d(x.float().permute(0, 4, 1, 2, 3), w, None, 1, 1).backward(dy.float().permute(0, 4, 1, 2, 3))
     torch.testing.assert_close(dw.cpu(), w.grad, atol=4e-3 * float(w.grad.abs().max()), rtol=1e-2)
+
+
+def test_conv3d_full_size_layer_vs_torch():
+    """One 48->48 layer at the bench's full spatial size (1 x 128^3): forward, dgrad and weight gradient of the bf16
+    kernels (tile igemm + all-taps wgrad, boundary tiles on every face) against torch's CPU f32 convolution."""
+    from brats21_amd import ops
+    dev = _dev()
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(23)
+    s = 128
+    x = torch.relu(torch.randn((1, 48, s, s, s), generator=g)).to(dt).float()
+    w = (torch.randn((48, 48, 3, 3, 3), generator=g) * (2.0 / (48 * 27)) ** 0.5).to(dt).float()
+    dy = (torch.randn((1, 48, s, s, s), generator=g) * 0.1).to(dt).float()
+    torch.set_num_threads(16)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, None, 1, 1)
+    y_ref.backward(dy)
+    xd, dyd = _to_ndhwc(x, dt, dev), _to_ndhwc(dy, dt, dev)
+    y, stats = ops.conv3d(xd, ops.pack_weights(w.to(dev), dt, ops.PACK_FWD), 48, 3, 1, want_stats=True)
+    dx, _ = ops.conv3d(dyd, ops.pack_weights(w.to(dev), dt, ops.PACK_DGRAD), 48, 3, 1)
+    dw, _ = ops.conv3d_wgrad(xd, dyd, 3, 1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(_from_ndhwc(y), y_ref.detach(), atol=3e-2, rtol=2e-2)     # bf16 output rounding
+    torch.testing.assert_close(_from_ndhwc(dx), xr.grad, atol=2e-2, rtol=2e-2)
+    scale = float(wr.grad.abs().max())
+    torch.testing.assert_close(dw.cpu(), wr.grad, atol=2e-3 * scale, rtol=1e-2)           # f32 accumulation of 2M products
+    # epilogue statistics = per-channel sum / sum of squares of the f32 result
+    st = stats.double().sum(1).cpu()[0]
+    ref1, ref2 = y_ref.detach().double().sum((0, 2, 3, 4)), (y_ref.detach().double() ** 2).sum((0, 2, 3, 4))
+    torch.testing.assert_close(st[:, 0], ref1, atol=2e-2 * s ** 1.5, rtol=1e-3)
+    torch.testing.assert_close(st[:, 1], ref2, atol=1e-2, rtol=1e-3)
