@@ -70,7 +70,7 @@ def inference_bench(model, dev, args):
     flips = [Transformer(SignedPerm((0, 1, 2), f), SignedPerm((0, 1, 2), f)) for f in itertools.product([False, True], repeat=3)]
     vol = synth.random_image(1, 4, (240, 240, 155), seed=99, device=dev)
     vol = vol * (synth.nested_spheres(1, (240, 240, 155), device=dev)[:, 0:1] > 0)  # zero background outside the "brain"
-    ev = Evaluator(model, tta_transforms=flips, sliding_window_size=(128, 128, 128), sw_batch_size=1, overlap=0.5,
+    ev = Evaluator(model, tta_transforms=flips, sliding_window_size=(128, 128, 128), sw_batch_size=args.sw_batch, overlap=0.5,
                    k_divisible=8, amp=args.precision == "bf16")
     with torch.no_grad():
         Evaluator(model, tta_transforms=flips[:1], sliding_window_size=(128, 128, 128), overlap=0.5,
@@ -88,7 +88,7 @@ def inference_bench(model, dev, args):
     fwd_tf = 144 * (1995.7e9 if args.model == "equiunet" else 1689.8e9) / sec / 1e12
     return {"metric": "inference volumes/sec", "value": round(1.0 / sec, 4), "unit": "volumes/s",
             "config": "4x240x240x155 padded to 160 (learning/engine.py:217), window 128^3, overlap 0.5, 18 windows x 8-flip TTA "
-                      f"= 144 patch forwards, {args.precision}, hipGraph patch step, on-GPU mean + threshold + background "
+                      f"= 144 patch forwards ({args.sw_batch} windows per launch), {args.precision}, hipGraph patch step, on-GPU mean + threshold + background "
                       "removal + BraTS labels + crop", "s_per_volume": round(sec, 3),
             "ms_per_patch_forward": round(sec / 144 * 1e3, 2), "TFLOPs": round(fwd_tf, 1),
             "foreground_fraction": round(float((out["labels"] != 0).float().mean()), 5)}
@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--optimizer", default="ranger", choices=["ranger", "adam"],
                     help="ranger = the reference's default (--optimizer ranger, src/arguments_train.py:120), fused HIP step")
     ap.add_argument("--use-gc", action="store_true", help="Ranger gradient centralisation (reference default: off)")
+    ap.add_argument("--sw-batch", type=int, default=3, help="sliding-window windows per forward in the inference leg")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one hipGraph (single GPU; no per-kernel timers, so roofline is null)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")

@@ -14,6 +14,7 @@
 // Per Cin chunk (CK channels) the halo tile is staged once and all taps read it (27x reuse from
 // LDS; HBM/L2 sees only the ~2x halo amplification).  2 workgroups/CU overlap staging with MFMA.
 #pragma once
+#include <stdlib.h>
 #include "common.hpp"
 
 struct ConvParams {
@@ -61,16 +62,23 @@ struct ConvGeom {
   static constexpr int unitoff(int g) { return g < UNITS ? tapoff(g / UPT) + (g % UPT) * UB : 0; }
 };
 
-template <int NF, bool KSPLIT> struct ConvTile {
-  static constexpr int NFW = KSPLIT ? NF : 2 * NF;  // cout16-fragments per workgroup
+// wave roles inside a workgroup: wm always picks the z half of the tile; wn picks
+//   !KSPLIT && !VS : the cout half (tile = 2*NF*16 couts, 8 voxel fragments per wave)
+//   KSPLIT         : the parity of the K macro-steps (same couts and voxels, reduced through LDS)
+//   VS             : the y half (same couts, 4 voxel fragments per wave, all K: no reduction, all four waves share
+//                    the epilogue; the weight fragments are fetched twice as often)
+template <int NF, bool KSPLIT, bool VS = false> struct ConvTile {
+  static_assert(!(KSPLIT && VS), "one split mode at a time");
+  static constexpr int NFW = (KSPLIT || VS) ? NF : 2 * NF;  // cout16-fragments per workgroup
+  static constexpr int NB = VS ? 4 : 8;                     // voxel fragments (x-rows of 16) per wave
   static constexpr int RED_BYTES = KSPLIT ? 2 * NF * 8 * 64 * 16 : 0;
-  static constexpr int SRED_BYTES = 2 * NFW * 16 * 2 * 4;
+  static constexpr int SRED_BYTES = (VS ? 4 : 2) * NFW * 16 * 2 * 4;
 };
 
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false>
 constexpr int conv_lds_bytes() {
   using G = ConvGeom<T, KS, CK, DIL>;
-  using TL = ConvTile<NF, KSPLIT>;
+  using TL = ConvTile<NF, KSPLIT, VS>;
   int a = G::LDS_TILE > TL::RED_BYTES ? G::LDS_TILE : TL::RED_BYTES;
   a = (a + 15) / 16 * 16;
   return a + TL::SRED_BYTES;
@@ -80,9 +88,11 @@ constexpr int conv_lds_bytes() {
 // pressure): the weight fragments of step k+1 are requested from L2 before the MFMAs of step k, and the
 // 8 activation fragments are read from LDS in two halves so that 4 ds_read_b128 are always in flight
 // behind 12 MFMAs.
-template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */, int BAR = 0 /* s_barriers embedded at 1/3 and 2/3 (conv_igemm_pp.hpp) */>
+template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */, int BAR = 0 /* s_barriers embedded at 1/3 and 2/3 (conv_igemm_pp.hpp) */,
+          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */>
 DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
-                         int lane, f32x4 (&acc)[NF][8]) {
+                         int lane, f32x4 (&acc)[NF][NB]) {
+  constexpr int YB = NB / 2;
   using G = ConvGeom<T, KS, CK, DIL>;
   constexpr int FOZ = G::HY * G::HX * G::S;  // one z-slice
   constexpr int NSTEP = PARITY < 0 ? G::MS : (G::MS - PARITY + 1) / 2;
@@ -90,7 +100,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
     const bf16x8* wp0 = (const bf16x8*)wpk_chunk + (size_t)f0 * 64 + lane;
     constexpr int WD = 2;  // weight prefetch distance in macro-steps (L2 latency under load > one step of 24 MFMAs)
     bf16x8 a[WD + 1][NF];
-    bf16x8 b[8];
+    bf16x8 b[NB];
     auto load_a = [&](auto k_) {
       constexpr int k = k_;
       constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
@@ -109,13 +119,13 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
         lb = lane_b + (q == 0 ? o0 : q == 1 ? o1 - G::UB : q == 2 ? o2 - 2 * G::UB : o3 - 3 * G::UB);
       }
 #pragma unroll
-      for (int i = 4 * half; i < 4 * half + 4; ++i)
-        b[i] = *(const bf16x8*)(ldsb + lb + ((i >> 2) * FOZ + (i & 3) * G::HX * G::S));
+      for (int i = YB * half; i < YB * half + YB; ++i)
+        b[i] = *(const bf16x8*)(ldsb + lb + ((i / YB) * FOZ + (i % YB) * G::HX * G::S));
     };
     auto mma = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
 #pragma unroll
-      for (int i = 4 * half; i < 4 * half + 4; ++i)
+      for (int i = YB * half; i < YB * half + YB; ++i)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
     };
@@ -154,8 +164,8 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
         constexpr int o = G::unitoff(4 * (4 * ms + j));  // CK%4==0: the 4 quarters share the tap
         if constexpr (4 * (4 * ms + j) < G::UNITS) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float bb = *(const float*)(ldsb + lane_b + o + ((i >> 2) * FOZ + (i & 3) * G::HX * G::S));
+          for (int i = 0; i < NB; ++i) {
+            const float bb = *(const float*)(ldsb + lane_b + o + ((i / YB) * FOZ + (i % YB) * G::HX * G::S));
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f][j], bb, acc[f][i], 0, 0, 0);
           }
@@ -174,10 +184,11 @@ DEVI float row16_sum(float x) {
   return x;
 }
 
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   using G = ConvGeom<T, KS, CK, DIL>;
-  using TL = ConvTile<NF, KSPLIT>;
+  using TL = ConvTile<NF, KSPLIT, VS>;
+  constexpr int NB = TL::NB, YB = NB / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar row math
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   const int n = bt / p.tz;
   const int z0 = tzi * CONV_TZ, y0 = tyi * CONV_TY, x0 = txi * CONV_TX;
   const int ct = blockIdx.y;
-  const int f0 = ct * TL::NFW + (KSPLIT ? 0 : wn * NF);
+  const int f0 = ct * TL::NFW + ((KSPLIT || VS) ? 0 : wn * NF);
   const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
 
   // --- staging: wave w owns halo rows (hz,hy) = w, w+4, ...; a row is HX voxels x PPV 16-byte pieces,
@@ -214,14 +225,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     lds_off[j] = pc < PPR ? wave * (G::HX * G::S) + hx * G::S + part * 16 : -1;
   }
 
-  f32x4 acc[NF][8];
+  f32x4 acc[NF][NB];
 #pragma unroll
   for (int f = 0; f < NF; ++f)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NB; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // lane's voxel inside the halo tile (tap (0,0,0) corner) + quarter offset
-  const int lane_b = ((wm * 2) * G::HY * G::HX + v) * G::S + q * G::UB;
+  const int lane_b = ((wm * 2) * G::HY * G::HX + (VS ? wn * 2 * G::HX : 0) + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;  // bytes of packed weights per chunk
 
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       if (wn == 0) conv_mma_chunk<T, KS, CK, DIL, NF, 0>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
       else conv_mma_chunk<T, KS, CK, DIL, NF, 1>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     } else {
-      conv_mma_chunk<T, KS, CK, DIL, NF, -1>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+      conv_mma_chunk<T, KS, CK, DIL, NF, -1, 0, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     }
   }
 
@@ -317,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
                       (ct + 1) * TL::NFW * 16 <= p.cout;  // scalar
     if (full) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int z = z0 + 2 * wm + (i >> 2), y = y0 + (i & 3);
+      for (int i = 0; i < NB; ++i) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
         T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -334,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int z = z0 + 2 * wm + (i >> 2), y = y0 + (i & 3);
+      for (int i = 0; i < NB; ++i) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
         const bool ok = z < p.D && y < p.H && x_ok;
         const float mk = ok ? 1.f : 0.f;
         T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
@@ -367,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           const int cl = (f0 + f - ct * TL::NFW) * 16 + 4 * q;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 0] = s1[f][r];
-            sred[((wm * TL::NFW * 16) + cl + r) * 2 + 1] = s2[f][r];
+            sred[(((VS ? wm + 2 * wn : wm) * TL::NFW * 16) + cl + r) * 2 + 0] = s1[f][r];
+            sred[(((VS ? wm + 2 * wn : wm) * TL::NFW * 16) + cl + r) * 2 + 1] = s2[f][r];
           }
         }
       }
@@ -381,30 +392,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       if (c < p.cout) {
         const size_t tps = (size_t)p.tz * p.ty * p.tx;
         float* dst = p.stats + (((size_t)n * tps + tile_in_sample) * p.cout + c) * 2;
-        dst[0] = sred[tid * 2] + sred[(TL::NFW * 16 + tid) * 2];
-        dst[1] = sred[tid * 2 + 1] + sred[(TL::NFW * 16 + tid) * 2 + 1];
+        float t1 = sred[tid * 2] + sred[(TL::NFW * 16 + tid) * 2];
+        float t2 = sred[tid * 2 + 1] + sred[(TL::NFW * 16 + tid) * 2 + 1];
+        if constexpr (VS) {
+          t1 += sred[(2 * TL::NFW * 16 + tid) * 2] + sred[(3 * TL::NFW * 16 + tid) * 2];
+          t2 += sred[(2 * TL::NFW * 16 + tid) * 2 + 1] + sred[(3 * TL::NFW * 16 + tid) * 2 + 1];
+        }
+        dst[0] = t1;
+        dst[1] = t2;
       }
     }
   }
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------------
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false>
 int conv_launch_one(const ConvParams& p, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT>();
-  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT>;
+  constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT, VS>();
+  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     attr_done = true;
   }
-  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT>::NFW));
+  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT, VS>::NFW));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
 
+static inline bool conv_vsplit_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BRATS_CONV_VSPLIT"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 struct ConvTileChoice { int nf; bool ksplit; int nfw; };
 static inline ConvTileChoice conv_choose_tile(int rows16) {
   if (rows16 % 6 == 0) return {3, false, 6};
@@ -418,7 +440,11 @@ template <typename T, int KS, int CK, int DIL>
 int conv_launch_ck(const ConvParams& p, hipStream_t st) {
   const ConvTileChoice t = conv_choose_tile(p.rows16);
   if (t.nf == 3 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 3, false>(p, st);
-  if (t.nf == 3 && t.ksplit) return conv_launch_one<T, KS, CK, DIL, 3, true>(p, st);
+  if (t.nf == 3 && t.ksplit) {
+    // Cout = 48 (mod 96): the y-split roles (no K reduction, shared epilogue) for bf16; K-split stays for f32 / opt-out
+    if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled()) return conv_launch_one<T, KS, CK, DIL, 3, false, true>(p, st);
+    return conv_launch_one<T, KS, CK, DIL, 3, true>(p, st);
+  }
   if (t.nf == 2 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, false>(p, st);
   if (t.nf == 2 && t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, true>(p, st);
   return conv_launch_one<T, KS, CK, DIL, 1, true>(p, st);

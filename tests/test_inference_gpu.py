@@ -116,3 +116,21 @@ def test_packed_weight_cache_tracks_weight_updates():
         r = m(x)
         y2 = r[0] if isinstance(r, (tuple, list)) else r
         assert not torch.equal(y1, y2), "stale packed weights after an in-place update"
+
+
+def test_sliding_window_batch_size_does_not_change_results():
+    """Windows are independent samples (per-sample norms): batching 3 of them per launch must give the same stitched
+    logits as one at a time (the bench's inference leg uses 3 windows per launch)."""
+    from brats21_amd import get_model
+    from brats21_amd.inferers import sliding_window_inference
+    dev = torch.device("cuda:0")
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(8))
+    m = get_model(argparse.Namespace(model="equiunet", width=8, norm="group", act="relu", num_classes=3, dropout=0))
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    m.skip_deep_heads_in_eval = True
+    x = synth.closed_form_image(1, 4, (24, 32, 24), "swbatch").to(dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = sliding_window_inference(x, (16, 16, 16), 1, m, overlap=0.5)
+        y3 = sliding_window_inference(x, (16, 16, 16), 3, m, overlap=0.5)
+    assert torch.equal(y1, y3)

@@ -254,7 +254,7 @@ def test_fused_dice_matches_torch_dice(jaccard):
 ])
 def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, split):
     """The persistent LDS-DMA kernel of the large bf16 layers against the one-tile-per-workgroup kernel on the same
-    inputs (bit-exact outputs: same MFMA order, commutative K-split sum) and against torch on a sub-volume."""
+    inputs and against torch on sample 0."""
     from brats21_amd import _lib, ops
     dev = _dev()
     dt = torch.bfloat16
@@ -275,11 +275,15 @@ def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, sp
             lib.brats_conv3d_set_pingpong(old)
         res[mode] = (y, st)
     ya, yb = res[0][0], res[1][0]
+    # cout 96 / 192: both kernels run the same MFMA order -> bit-identical.  cout 48: the tile kernel accumulates all of
+    # K in one chain (y-split roles), the ping-pong kernel adds two K-parity partial sums -> equal up to one bf16 ulp.
+    same = (lambda a, b: torch.equal(a, b)) if cout % 96 == 0 else (
+        lambda a, b: bool(((a.float() - b.float()).abs() <= 2e-2 * b.float().abs() + 2e-2).all()))
     if split is not None:
-        assert torch.equal(ya[0], yb[0]) and torch.equal(ya[1], yb[1])
+        assert same(ya[0], yb[0]) and same(ya[1], yb[1])
         yb = torch.cat([yb[0], yb[1]], -1)
     else:
-        assert torch.equal(ya, yb)
+        assert same(ya, yb)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-3)
     # torch reference on sample 0 (zero padding at every face included)
     xin = x[:1].float().cpu() if x2 is None else torch.cat([x[:1], x2[:1]], -1).float().cpu()
