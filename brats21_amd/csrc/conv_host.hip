@@ -126,6 +126,11 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
   const int align = dtype == BRATS_BF16 ? 8 : 4;
   if (pitch1 % align || (c2 && pitch2 % align) || ypitch % 4)
     BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: channel pitches must keep 16-byte loads / 4-channel stores aligned");
+  {  // staged pieces are addressed by 32-bit byte offsets inside one sample (buffer_load voffset)
+    const int mp = pitch1 > pitch2 ? pitch1 : pitch2;
+    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
+  }
   const int ck = brats_conv3d_chunk(dtype, ksize, dil, c1, c2);
   if (!ck) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: no channel chunk divides c1=%d c2=%d", c1, c2);
   ConvParams p;

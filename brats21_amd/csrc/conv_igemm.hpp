@@ -241,9 +241,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     int pitch;
     if (c0 < p.c1) { src = (const T*)p.x1 + c0; pitch = p.p1; }
     else { src = (const T*)p.x2 + (c0 - p.c1); pitch = p.p2; }
-    int goff[IPR];  // element offset of the lane's piece from the row origin (gx = x0 - R)
+    // one unconditional buffer_load per piece: pieces outside the volume get an out-of-range offset, for which the
+    // descriptor's range check returns zeros (no per-piece branch, no zero-initialisation of the staging registers)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(src + sample_vox * pitch), (short)0, (int)((size_t)p.D * p.H * p.W * pitch * G::ESZ), 0x00020000);
+    const int pb = pitch * G::ESZ;
+    int goff[IPR];  // byte offset of the lane's piece from the row origin (gx = x0 - R)
 #pragma unroll
-    for (int j = 0; j < IPR; ++j) goff[j] = (hx_part[j] >> 16) * pitch + (hx_part[j] & 0xffff) * G::EPL;
+    for (int j = 0; j < IPR; ++j) goff[j] = (hx_part[j] >> 16) * pb + (hx_part[j] & 0xffff) * 16;
     u32x4 r[RPW][IPR];
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
@@ -251,11 +256,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       const int hz = row / G::HY, hy = row % G::HY;
       const int gz = z0 - G::R + hz, gy = y0 - G::R + hy;
       const bool row_ok = row < NROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;  // scalar
-      const T* rowp = src + ((ptrdiff_t)(sample_vox + (size_t)(gz * p.H + gy) * p.W) + (x0 - G::R)) * pitch;
+      const int rb = ((gz * p.H + gy) * p.W + (x0 - G::R)) * pb;  // may be negative at the low faces; valid pieces are not
 #pragma unroll
       for (int j = 0; j < IPR; ++j) {
-        r[k][j] = u32x4{0u, 0u, 0u, 0u};
-        if (row_ok && hx_part[j] >= 0) r[k][j] = *(const u32x4*)(rowp + goff[j]);
+        const int vo = (row_ok && hx_part[j] >= 0) ? rb + goff[j] : -1;
+        r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
       }
     }
     if (chunk > 0) __syncthreads();  // all waves finished reading the previous chunk's tile
