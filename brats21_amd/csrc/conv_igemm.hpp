@@ -432,6 +432,11 @@ static inline bool conv_vsplit_enabled() {
   if (v < 0) { const char* e = getenv("BRATS_CONV_VSPLIT"); v = e ? atoi(e) : 1; }
   return v != 0;
 }
+static inline long conv_small_grid_threshold() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("BRATS_CONV_SMALLGRID"); v = e ? atol(e) : 200; }
+  return v;
+}
 struct ConvTileChoice { int nf; bool ksplit; int nfw; };
 static inline ConvTileChoice conv_choose_tile(int rows16) {
   if (rows16 % 6 == 0) return {3, false, 6};
@@ -444,7 +449,14 @@ static inline ConvTileChoice conv_choose_tile(int rows16) {
 template <typename T, int KS, int CK, int DIL>
 int conv_launch_ck(const ConvParams& p, hipStream_t st) {
   const ConvTileChoice t = conv_choose_tile(p.rows16);
-  if (t.nf == 3 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 3, false>(p, st);
+  if (t.nf == 3 && !t.ksplit) {
+    // small volumes (16^3 levels): 96-cout tiles give fewer workgroups than CUs; the y-split roles (48 couts per
+    // workgroup) double the grid at the price of staging each halo tile twice
+    if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled() &&
+        (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 6) < conv_small_grid_threshold())
+      return conv_launch_one<T, KS, CK, DIL, 3, false, true>(p, st);
+    return conv_launch_one<T, KS, CK, DIL, 3, false>(p, st);
+  }
   if (t.nf == 3 && t.ksplit) {
     // Cout = 48 (mod 96): the y-split roles (no K reduction, shared epilogue) for bf16; K-split stays for f32 / opt-out
     if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled()) return conv_launch_one<T, KS, CK, DIL, 3, false, true>(p, st);
