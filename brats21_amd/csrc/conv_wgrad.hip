@@ -21,6 +21,7 @@ struct WgradParams {
   float* ws;
   int N, D, H, W, cin, cout;
   int tz, ty, tx, ntiles, nsplit;
+  int nlane;  // tile ranges (8 = one per XCD; fewer for small volumes so that fewer split-K slabs are written)
   int debug;  // ablation bits (BRATS_WGRAD_DEBUG): 1 loads dropped by the range check, 2 skip MMA, 4 no tiles,
               // 8 skip LDS writes + barriers, 16 no load instructions
 };
@@ -72,10 +73,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, v = lane & 15;
   // ---- schedule: blockIdx.x = lane8 + 8*r, r = 3*gsub + tzg ----
-  const int lane8 = blockIdx.x & 7, rr = blockIdx.x >> 3;
-  const int tzg = rr % 3, gsub = rr / 3, g8 = gridDim.x / 24;
-  const int split = lane8 + 8 * gsub;
-  const int tpx = (p.ntiles + 7) / 8;
+  const int lane8 = blockIdx.x % p.nlane, rr = blockIdx.x / p.nlane;
+  const int tzg = rr % 3, gsub = rr / 3, g8 = gridDim.x / (3 * p.nlane);
+  const int split = lane8 + p.nlane * gsub;
+  const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
   const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
   const int cot = blockIdx.y, cit = blockIdx.z;
   const int co0 = cot * G::CO_T, ci0 = cit * G::CI_T;
@@ -328,9 +329,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, v = lane & 15;
-  const int lane8 = blockIdx.x & 7, gsub = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+  const int lane8 = blockIdx.x % p.nlane, gsub = blockIdx.x / p.nlane, g8 = gridDim.x / p.nlane;
   const int split = blockIdx.x;
-  const int tpx = (p.ntiles + 7) / 8;
+  const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
   const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
   const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 48;
   const T* xsrc;
@@ -520,15 +521,24 @@ __global__ void dbias_kernel(const T* __restrict__ dy, int pitch, float* __restr
   if (threadIdx.x == 0) db[c] = red[0];
 }
 
-// spatial groups: 8 XCD ranges x g8 sub-groups; total workgroups = 3 (tap planes) * 8 * g8 * cot * cit ~ 2 per CU
+// spatial groups: nlane tile ranges (8 = one per XCD) x g8 interleaved sub-groups; total workgroups of the tap-plane
+// kernel = 3 (tap planes) * nlane * g8 * cot * cit ~ 2 per CU.  Every (range, sub-group) pair writes its own f32 slab of
+// the whole dW, so small volumes (16^3 levels: 32 tiles, 27 x 384 x 384 weights) use fewer ranges: with 8 the slab
+// traffic (127 MB written + read) cost as much as the MFMAs.
+static int wgrad_nlane(int ntiles) {
+  int nl = 8;
+  while (nl > 1 && ntiles / nl < 16) nl >>= 1;
+  return nl;
+}
 static int wgrad_g8(int ntiles, int cotiles, int citiles) {
-  int g8 = ceil_div(512, 24 * cotiles * citiles);
-  const int cap = ceil_div(ntiles, 8);
+  const int nl = wgrad_nlane(ntiles);
+  int g8 = ceil_div(512, 3 * nl * cotiles * citiles);
+  const int cap = ceil_div(ntiles, nl);
   if (g8 > cap) g8 = cap;
   if (g8 < 1) g8 = 1;
   return g8;
 }
-static int wgrad_nsplit(int ntiles, int cotiles, int citiles) { return 8 * wgrad_g8(ntiles, cotiles, citiles); }
+static int wgrad_nsplit(int ntiles, int cotiles, int citiles) { return wgrad_nlane(ntiles) * wgrad_g8(ntiles, cotiles, citiles); }
 static void wgrad_tiles(int dtype, int c1, int c2, int cout, int* cof, int* cif) {
   const int co16 = ceil_div(cout, 16);
   *cof = co16 % 3 == 0 ? 3 : (co16 % 2 == 0 ? 2 : 1);
@@ -553,9 +563,10 @@ static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int n
   const int mode = g_wgrad_alltaps_mode >= 0 ? g_wgrad_alltaps_mode : env_mode;
   if (!mode || dtype != BRATS_BF16 || dil != 1 || cout % 48 || c1 % 48 || (c2 > 0 && c2 % 48)) return false;
   const int blocks = (cout / 48) * ((c1 + (c2 > 0 ? c2 : 0)) / 48);
-  int g8 = ceil_div(ncu, 8 * blocks);
+  const int nl = wgrad_nlane(ntiles);
+  int g8 = ceil_div(ncu, nl * blocks);
   if (g8 < 1) g8 = 1;
-  if (ntiles < 4 * 8 * g8) return false;  // too few tiles per workgroup to amortise 132 accumulators x 27 taps of slab
+  if (ntiles < 4 * nl * g8) return false;  // too few tiles per workgroup to amortise 132 accumulators x 27 taps of slab
   *g8_out = g8;
   return true;
 }
@@ -573,7 +584,7 @@ extern "C" size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D
   const int cin_tiles = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
   int ns = wgrad_nsplit(ntiles, ceil_div(cout, 16 * cof), cin_tiles);
   int g8 = 0;
-  if (wgrad_alltaps_ok(dtype, 1, c1, c2, cout, ntiles, &g8) && 8 * g8 > ns) ns = 8 * g8;  // the dilation is not known here
+  if (wgrad_alltaps_ok(dtype, 1, c1, c2, cout, ntiles, &g8) && wgrad_nlane(ntiles) * g8 > ns) ns = wgrad_nlane(ntiles) * g8;  // the dilation is not known here
   return (size_t)ns * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
 }
 
@@ -629,6 +640,7 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   const int cot = ceil_div(cout, 16 * cof);
   const int cit = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
   p.nsplit = wgrad_nsplit(p.ntiles, cot, cit);
+  p.nlane = wgrad_nlane(p.ntiles);
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("BRATS_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
@@ -640,10 +652,10 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   }
   int g8a = 0;
   const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a);
-  dim3 grid(3 * p.nsplit, cot, cit);  // x = lane8 + 8*(3*gsub + tzg)
+  dim3 grid(3 * p.nsplit, cot, cit);  // x = lane + nlane*(3*gsub + tzg)
   int rc;
   if (alltaps) {
-    p.nsplit = 8 * g8a;
+    p.nsplit = p.nlane * g8a;
     static bool done = false;
     if (!done) {
       hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3::LDS);
