@@ -311,18 +311,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // staged once per tile = 2.3x less traffic.  The 81 (tap, ci-fragment) pairs are dealt to the 8 waves
 // (11 pairs x 3 co-fragments = 132 accumulator registers per lane, kept across all tiles of the workgroup);
 // the next tile's 87 KB are prefetched into registers (11 x 16 B per lane) during the MFMA phase.
-struct Wg3 {
+// CIF = ci fragments of the channel block: 3 (48 input channels) or 1 (the first layer: <= 16 input channels, 16-channel
+// LDS rows of which only the real ones are fetched)
+template <int CIF> struct Wg3 {
   static constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, HVOX = HZ * HY * HX;
-  static constexpr int SX = 96, SY = 96, PPV = 6;
-  static constexpr int XPIECES = HVOX * PPV, YPIECES = WG_VOX * PPV;       // 3888, 1536 sixteen-byte pieces
-  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;     // 8, 3 per thread
-  static constexpr int LDS_X = HVOX * SX, LDS = LDS_X + WG_VOX * SY;       // 62208 + 24576
-  static constexpr int PAIRS = 81, PPW = 11;                                // pair p -> wave p % 8
+  static constexpr int SX = CIF == 3 ? 96 : 32, SY = 96, XPPV = 2 * CIF, YPPV = 6;
+  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;     // 3888 (1296), 1536 sixteen-byte pieces
+  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;     // 8 (3), 3 per thread
+  static constexpr int LDS_X = HVOX * SX, LDS = LDS_X + WG_VOX * SY;       // 62208 (20736) + 24576
+  static constexpr int PAIRS = 27 * CIF, PPW = (PAIRS + 7) / 8;             // pair p -> wave p % 8
 };
 
+template <int CIF>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradParams p) {
   typedef bf16_t T;
-  using G = Wg3;
+  using G = Wg3<CIF>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldx = lds;
   char* ldy = lds + G::LDS_X;
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
   const int split = blockIdx.x;
   const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
   const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
-  const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 48;
+  const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 16 * CIF;
+  const int ci_lim = (ci0 < p.c1 ? p.c1 : p.c1 + p.c2) - ci0;  // valid channels of this source in the block
   const T* xsrc;
   int xpitch;
   if (ci0 < p.c1) { xsrc = (const T*)p.x1 + ci0; xpitch = p.p1; }
@@ -344,14 +348,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
 #pragma unroll
   for (int i = 0; i < G::XI; ++i) {
     const int P = tid + 512 * i;
-    const int vox = P / G::PPV, part = P % G::PPV;
+    const int vox = P / G::XPPV, part = P % G::XPPV;
     const int hx = vox % G::HX, hy = (vox / G::HX) % G::HY, hz = vox / (G::HX * G::HY);
-    xcode[i] = P < G::XPIECES ? (hz | hy << 3 | hx << 6 | part << 11 | 1 << 14) : 0;
+    xcode[i] = (P < G::XPIECES && part * 8 < ci_lim) ? (hz | hy << 3 | hx << 6 | part << 11 | 1 << 14) : 0;
   }
 #pragma unroll
   for (int i = 0; i < G::YI; ++i) {
     const int P = tid + 512 * i;
-    const int vox = P / G::PPV, part = P % G::PPV;
+    const int vox = P / G::YPPV, part = P % G::YPPV;
     ycode[i] = (vox >> 6) | ((vox >> 4) & 3) << 3 | (vox & 15) << 6 | part << 11 | 1 << 14;
   }
   const unsigned xsample_bytes = (unsigned)p.D * p.H * p.W * xpitch * 2;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
 #pragma unroll
   for (int jj = 0; jj < G::PPW; ++jj) {
     const int pid = wave + 8 * jj;
-    const int t = pid / 3, nn = pid % 3;
+    const int t = pid / CIF, nn = pid % CIF;
     poff[jj] = pid < G::PAIRS ? (((t / 9) * G::HY + (t / 3) % 3) * G::HX + t % 3) * G::SX + nn * 32 : 0;
   }
   f32x4 acc[G::PPW][3];
@@ -466,13 +470,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
   for (int jj = 0; jj < G::PPW; ++jj) {
     const int pid = wave + 8 * jj;
     if (pid < G::PAIRS) {
-      const int t = pid / 3, nn = pid % 3;
+      const int t = pid / CIF, nn = pid % CIF;
       float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
       const int ci = ci0 + nn * 16 + v;
+      if (nn * 16 + v < ci_lim) {
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
+          for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
+      }
     }
   }
 }
@@ -561,8 +567,10 @@ static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int n
     ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
   const int mode = g_wgrad_alltaps_mode >= 0 ? g_wgrad_alltaps_mode : env_mode;
-  if (!mode || dtype != BRATS_BF16 || dil != 1 || cout % 48 || c1 % 48 || (c2 > 0 && c2 % 48)) return false;
-  const int blocks = (cout / 48) * ((c1 + (c2 > 0 ? c2 : 0)) / 48);
+  const int cin = c1 + (c2 > 0 ? c2 : 0);
+  const bool narrow = c2 <= 0 && c1 <= 16;  // the first layer: one 16-channel ci block
+  if (!mode || dtype != BRATS_BF16 || dil != 1 || cout % 48 || (!narrow && (c1 % 48 || (c2 > 0 && c2 % 48)))) return false;
+  const int blocks = (cout / 48) * (narrow ? 1 : cin / 48);
   const int nl = wgrad_nlane(ntiles);
   int g8 = ceil_div(ncu, nl * blocks);
   if (g8 < 1) g8 = 1;
@@ -645,24 +653,30 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
   hipStream_t st = (hipStream_t)s;
-  // slab entries of padded ci columns (c1 not a multiple of 16) are never written: clear the slab
-  if ((c1 + c2) % 16 || cout % 16) {
+  int g8a = 0;
+  const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a);
+  // tap-plane kernel: slab entries of padded ci / co lanes are never written: clear the slab
+  if (!alltaps && ((c1 + c2) % 16 || cout % 16)) {
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * 27 * cout * p.cin * sizeof(float), st);
     if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: memset: %s", hipGetErrorString(e));
   }
-  int g8a = 0;
-  const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a);
   dim3 grid(3 * p.nsplit, cot, cit);  // x = lane + nlane*(3*gsub + tzg)
   int rc;
   if (alltaps) {
     p.nsplit = p.nlane * g8a;
     static bool done = false;
     if (!done) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3::LDS);
-      if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3::LDS, hipGetErrorString(e));
+      hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3<3>::LDS);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3<1>::LDS);
+      if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3<3>::LDS, hipGetErrorString(e));
       done = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_alltaps_kernel, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3::LDS, st, p);
+    if (c2 <= 0 && c1 <= 16) {
+      // the slab columns of the padded ci lanes (c1 < 16) are never written and never read (cin = c1)
+      hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<1>, dim3(p.nsplit, cout / 48, 1), dim3(512), Wg3<1>::LDS, st, p);
+    } else {
+      hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<3>, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3<3>::LDS, st, p);
+    }
     rc = 0;
   } else if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
   else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);

@@ -295,6 +295,7 @@ def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, sp
     (48, 0, 48, 2, (32, 64, 64)),
     (48, 48, 48, 3, (34, 62, 66)),     # two sources, ragged in z / y / x
     (96, 0, 96, 2, (32, 32, 64)),      # 2 x 2 channel blocks
+    (8, 0, 48, 2, (64, 64, 64)),       # the first layer: one 16-channel ci block, 8 real channels
 ])
 def test_conv3d_wgrad_alltaps_kernel_matches_tapplane_kernel(cin, cin2, cout, n, size):
     """The all-taps wgrad kernel (one 8-wave workgroup per CU, X tile with z halo staged once) against the tap-plane
