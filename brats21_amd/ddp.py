@@ -80,6 +80,25 @@ class GradientBuckets:
             size += n
         if cur:
             plan.append(cur)
+        # the last bucket's all-reduce cannot overlap any backward kernel: keep only the final ~1 MiB of gradients (the
+        # shallow layers, produced last) in it and let the rest go out one bucket earlier
+        if plan:
+            tail, size = [], 0
+            while len(plan[-1]) > 1 and (size + plan[-1][-1][2]) * 4 <= (1 << 20):
+                idx, _, n = plan[-1].pop()
+                tail.insert(0, (idx, n))
+                size += n
+            if tail and plan[-1]:
+                off, bucket = 0, []
+                for idx, n in tail:
+                    bucket.append((idx, off, n))
+                    off += n
+                plan.append(bucket)
+            elif tail:  # everything was small: put it back
+                off = 0
+                for idx, n in tail:
+                    plan[-1].append((idx, off, n))
+                    off += n
         self._plan = plan
         self._where = {idx: (b, off) for b, bucket in enumerate(plan) for idx, off, _ in bucket}
         dev = self.params[0].device
