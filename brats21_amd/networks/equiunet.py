@@ -43,22 +43,25 @@ class _NormParams(nn.Module):
 
 
 class ConvBnRelu(nn.Module):
-    """conv3x3x3 (no bias) -> GroupNorm(8) -> act -> Dropout(p)   (networks/equiunet2020.py:51-75)"""
+    """conv3x3x3 (no bias) -> norm -> act -> Dropout(p)   (networks/equiunet2020.py:51-75).  The norm is GroupNorm(8)
+    (``--norm group``) or InstanceNorm3d(affine=True) (``--norm instance``, the CLI default; networks/factory.py:
+    179-188): the same kernels with 8 or ``planes`` statistics groups."""
 
-    def __init__(self, inplanes, planes, dilation=1):
+    def __init__(self, inplanes, planes, dilation=1, norm="group"):
         super().__init__()
         self.conv = _ConvParams(inplanes, planes, 3, bias=False)
         self.bn = _NormParams(planes)
         self.dilation = dilation
+        self.groups = 8 if norm == "group" else planes
 
 
 class UBlock(nn.Module):
     """networks/equiunet2020.py:105-123"""
 
-    def __init__(self, inplanes, midplanes, outplanes, dilation=(1, 1)):
+    def __init__(self, inplanes, midplanes, outplanes, dilation=(1, 1), norm="group"):
         super().__init__()
-        self.ConvBnRelu1 = ConvBnRelu(inplanes, midplanes, dilation[0])
-        self.ConvBnRelu2 = ConvBnRelu(midplanes, outplanes, dilation[1])
+        self.ConvBnRelu1 = ConvBnRelu(inplanes, midplanes, dilation[0], norm)
+        self.ConvBnRelu2 = ConvBnRelu(midplanes, outplanes, dilation[1], norm)
 
 
 def _head(cin, k):
@@ -75,7 +78,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None):
     wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=x.shape[-1] if x2 is not None else None)
     y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
     n, d, h, wd, _ = y.shape
-    mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, 8, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
+    mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
     z = ops.affine_act(y, scale_shift, act, out=out)
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
@@ -83,7 +86,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None):
 def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit."""
     unit, x, x2, y, mean_rstd, scale_shift = rec
-    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), 8, act)
+    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, act)
     if x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
         dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
     else:
@@ -211,8 +214,8 @@ class EquiUnet(nn.Module):
     def __init__(self, inplanes, num_classes, features, norm_layer=None, act="relu", deep_supervision=False, dropout=0,
                  refinement=False):
         super().__init__()
-        if norm_layer != "group":
-            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group only (got {norm_layer!r})")
+        if norm_layer not in ("group", "instance"):
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance (got {norm_layer!r})")
         if act not in ("relu", "leakyrelu"):
             raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu only (got {act!r})")
         if dropout:
@@ -229,15 +232,16 @@ class EquiUnet(nn.Module):
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
         f = self.features
-        self.encoder1 = UBlock(inplanes, f[0], f[0])
-        self.encoder2 = UBlock(f[0], f[1], f[1])
-        self.encoder3 = UBlock(f[1], f[2], f[2])
-        self.encoder4 = UBlock(f[2], f[3], f[3])
-        self.bottom = UBlock(f[3], f[3], f[3], (2, 2))
-        self.bottom_2 = ConvBnRelu(f[3] * 2, f[2])
-        self.decoder3 = UBlock(f[2] * 2, f[2], f[1])
-        self.decoder2 = UBlock(f[1] * 2, f[1], f[0])
-        self.decoder1 = UBlock(f[0] * 2, f[0], f[0])
+        nl = norm_layer
+        self.encoder1 = UBlock(inplanes, f[0], f[0], norm=nl)
+        self.encoder2 = UBlock(f[0], f[1], f[1], norm=nl)
+        self.encoder3 = UBlock(f[1], f[2], f[2], norm=nl)
+        self.encoder4 = UBlock(f[2], f[3], f[3], norm=nl)
+        self.bottom = UBlock(f[3], f[3], f[3], (2, 2), norm=nl)
+        self.bottom_2 = ConvBnRelu(f[3] * 2, f[2], norm=nl)
+        self.decoder3 = UBlock(f[2] * 2, f[2], f[1], norm=nl)
+        self.decoder2 = UBlock(f[1] * 2, f[1], f[0], norm=nl)
+        self.decoder1 = UBlock(f[0] * 2, f[0], f[0], norm=nl)
         self.outconv = _ConvParams(f[0], num_classes, 1, bias=True)
         if deep_supervision:
             self.deep_bottom = _head(f[3], num_classes)

@@ -30,18 +30,25 @@ def _act(x, act):
     raise ValueError(act)
 
 
-def conv_gn_act(sd, pre, x, dilation=1, act="relu"):
-    """ConvBnRelu, networks/equiunet2020.py:51-75: conv3x3x3 (no bias, pad=dil) -> GroupNorm(8) -> act
-    -> Dropout(p=0) (identity).  GroupNorm(8, C, affine) from networks/factory.py:179-182."""
+def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group"):
+    """ConvBnRelu, networks/equiunet2020.py:51-75: conv3x3x3 (no bias, pad=dil) -> norm -> act -> Dropout(p=0)
+    (identity).  norm "group" = GroupNorm(8, C, affine), "instance" = InstanceNorm3d(C, affine=True) (the CLI
+    default, src/arguments_train.py:48) = per-(sample, channel) statistics, biased variance, eps 1e-5
+    (networks/factory.py:179-188)."""
     y = F.conv3d(x, sd[pre + ".conv.weight"], None, 1, dilation, dilation)
-    y = F.group_norm(y, 8, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], 1e-5)
+    if norm == "group":
+        y = F.group_norm(y, 8, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], 1e-5)
+    elif norm == "instance":
+        y = F.instance_norm(y, None, None, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], True, 0.1, 1e-5)
+    else:
+        raise ValueError(norm)
     return _act(y, act)
 
 
-def ublock(sd, pre, x, dilation=(1, 1), act="relu"):
+def ublock(sd, pre, x, dilation=(1, 1), act="relu", norm="group"):
     """UBlock, networks/equiunet2020.py:105-123."""
-    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act)
-    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act)
+    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act, norm)
+    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act, norm)
 
 
 def _up(x, s):
@@ -54,17 +61,17 @@ def _c1(sd, pre, x):
     return F.conv3d(x, sd[pre + ".weight"], sd[pre + ".bias"])
 
 
-def equiunet_forward(sd, x, act="relu", deep_supervision=True):
+def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group"):
     """EquiUnet.forward, networks/equiunet2020.py:467-500. Returns (logits, [4 deep heads])."""
-    down1 = ublock(sd, "encoder1", x, act=act)
-    down2 = ublock(sd, "encoder2", F.max_pool3d(down1, 2, 2), act=act)
-    down3 = ublock(sd, "encoder3", F.max_pool3d(down2, 2, 2), act=act)
-    down4 = ublock(sd, "encoder4", F.max_pool3d(down3, 2, 2), act=act)
-    bottom = ublock(sd, "bottom", down4, (2, 2), act)
-    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act)
-    up3 = ublock(sd, "decoder3", torch.cat([down3, _up(bottom_2, 2)], 1), act=act)
-    up2 = ublock(sd, "decoder2", torch.cat([down2, _up(up3, 2)], 1), act=act)
-    up1 = ublock(sd, "decoder1", torch.cat([down1, _up(up2, 2)], 1), act=act)
+    down1 = ublock(sd, "encoder1", x, act=act, norm=norm)
+    down2 = ublock(sd, "encoder2", F.max_pool3d(down1, 2, 2), act=act, norm=norm)
+    down3 = ublock(sd, "encoder3", F.max_pool3d(down2, 2, 2), act=act, norm=norm)
+    down4 = ublock(sd, "encoder4", F.max_pool3d(down3, 2, 2), act=act, norm=norm)
+    bottom = ublock(sd, "bottom", down4, (2, 2), act, norm)
+    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act, norm)
+    up3 = ublock(sd, "decoder3", torch.cat([down3, _up(bottom_2, 2)], 1), act=act, norm=norm)
+    up2 = ublock(sd, "decoder2", torch.cat([down2, _up(up3, 2)], 1), act=act, norm=norm)
+    up1 = ublock(sd, "decoder1", torch.cat([down1, _up(up2, 2)], 1), act=act, norm=norm)
     out = _c1(sd, "outconv", up1)
     if not deep_supervision:
         return out

@@ -83,6 +83,12 @@ def equiunet_fixtures():
         _model_fixture(m, unet.equiunet_state_shapes, 8, size, fname, sub)
 
 
+def equiunet_instance_fixture():
+    """--norm instance is the CLI default (src/arguments_train.py:48): InstanceNorm3d(affine=True)."""
+    m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="instance", act="relu", deep_supervision=True, dropout=0)
+    _model_fixture(m, unet.equiunet_state_shapes, 8, (32, 32, 32), "equiunet_w8_32_instance.npz", 2)
+
+
 def assp_fixture():
     m = EquiUnetASSPEvo(4, 3, [16, 32, 64, 128], norm_layer="group", act="relu", deep_supervision=True, dropout=0)
     _model_fixture(m, unet.assp_evo_state_shapes, 16, (32, 32, 32), "assp_w16_32.npz", 1)
@@ -285,9 +291,11 @@ if __name__ == "__main__":
     m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
                                      t.Rotate90(angles=[0, 90, 180, 270])])
     sys.modules["src_definer_tta"] = m
-    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep"]
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance"]
     if "equiunet" in which:
         equiunet_fixtures()
+    if "equiunet_instance" in which:
+        equiunet_instance_fixture()
     if "assp" in which:
         assp_fixture()
     if "ops" in which:

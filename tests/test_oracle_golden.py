@@ -202,3 +202,17 @@ def test_input_pipeline_vectors(golden_dir):
     assert f[1, 0, 0, 0] == a[1, 1, 0, 2]
     c = prep.adjust_contrast(np.array([[[[1.0, 3.0, 5.0]]]], dtype=np.float32), 2.0)
     np.testing.assert_allclose(c.ravel(), [1.0, 2.0, 5.0], atol=1e-5)
+
+
+def test_equiunet_instance_norm_oracle_matches_reference(golden_dir):
+    """--norm instance (the reference CLI's default) through the same oracle with per-channel statistics."""
+    g = _load(golden_dir, "equiunet_w8_32_instance.npz")
+    meta, sd, out, loss = _run(lambda sd, x: unet.equiunet_forward(sd, x, norm="instance"), unet.equiunet_state_shapes, g)
+    s = meta["sub"]
+    np.testing.assert_allclose(out[0].detach().numpy()[:, :, ::s, ::s, ::s], g["logits"], atol=TOL, rtol=0)
+    for i, d in enumerate(out[1]):
+        np.testing.assert_allclose(d.detach().numpy()[:, :, ::2 * s, ::2 * s, ::2 * s], g[f"deep{i}"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
