@@ -52,7 +52,7 @@ def test_state_dict_contract_and_factory_errors():
     with pytest.raises(NameError):
         get_model(argparse.Namespace(model="nnunet", **ns))
     with pytest.raises(NotImplementedError):
-        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "instance"}))
+        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "batch"}))
     # no CPU fallback: a CPU forward must fail loudly
     from brats21_amd import BratsHipError
     with pytest.raises(BratsHipError):
