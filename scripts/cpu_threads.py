@@ -1,3 +1,4 @@
+"""Fastest CPU thread count for the oracle baseline on this host (bench.py cpu_baseline uses min(16, cores))."""
 import sys, time, torch
 sys.path.insert(0, '.')
 from oracle import synth, unet

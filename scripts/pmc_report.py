@@ -1,3 +1,4 @@
+"""Summarises the per-kernel PMC counters collected by scripts/pmc.sh (clock, MFMA-busy fraction, LDS conflicts, L2 hit, traffic)."""
 import csv, glob, sys, collections
 tag = sys.argv[1]
 agg = collections.OrderedDict()
