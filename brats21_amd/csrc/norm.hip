@@ -6,10 +6,12 @@
 #include "common.hpp"
 
 // ---- statistics finalize ---------------------------------------------------------------------------
-// stage 1: chan[n][c] = sum over tiles of the conv epilogue's per-tile partials (f64), one block per
-// (n, 16-channel slab): 16 x 16 threads, coalesced 128-byte rows.  stage 2: one block per (n, group).
-__global__ void gn_chan_reduce_kernel(const float* __restrict__ stats, int tps, int C, double* __restrict__ chan) {
-  // grid (C/16, N, splits): each block reduces a slice of the tiles and adds it to chan (zeroed by the caller)
+// stage 1: part[z][n][c] = sum over a slice of the tiles of the conv epilogue's per-tile partials (f64), one block per
+// (n, 16-channel slab, slice): 16 x 16 threads, coalesced 128-byte rows; plain stores, no atomics, no zeroing.
+// stage 2: one block per (n, group) adds the <= 64 slices in order (bitwise reproducible) and finishes.
+// Workspace: chan_ws = [N][C][2] totals (kept: EvoNorm's backward reads them) followed by [splits][N][C][2] partials.
+constexpr int GN_MAX_SPLITS = 64;
+__global__ void gn_chan_reduce_kernel(const float* __restrict__ stats, int tps, int C, double* __restrict__ part) {
   const int n = blockIdx.y, c0 = blockIdx.x * 16;
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int c = c0 + cl;
@@ -32,21 +34,24 @@ __global__ void gn_chan_reduce_kernel(const float* __restrict__ stats, int tps, 
     __syncthreads();
   }
   if (threadIdx.x < 16 && c < C) {
-    atomicAdd(chan + ((size_t)n * C + c) * 2, r1[threadIdx.x]);
-    atomicAdd(chan + ((size_t)n * C + c) * 2 + 1, r2[threadIdx.x]);
+    double* dst = part + (((size_t)blockIdx.z * gridDim.y + n) * C + c) * 2;
+    dst[0] = r1[threadIdx.x];
+    dst[1] = r2[threadIdx.x];
   }
 }
 
-static int chan_reduce_launch(const float* stats, int tps, int N, int C, double* chan_ws, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(chan_ws, 0, (size_t)N * C * 2 * sizeof(double), st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "chan_reduce: memset: %s", hipGetErrorString(e));
+static int gn_splits(int tps) {
   int splits = tps / 64;
-  splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
-  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, splits), dim3(256), 0, st, stats, tps, C, chan_ws);
+  return splits < 1 ? 1 : (splits > GN_MAX_SPLITS ? GN_MAX_SPLITS : splits);
+}
+
+static int chan_reduce_launch(const float* stats, int tps, int N, int C, double* chan_ws, hipStream_t st) {
+  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, gn_splits(tps)), dim3(256), 0, st, stats, tps, C,
+                     chan_ws + (size_t)N * C * 2);
   return 0;
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ chan, int C, int groups, double count_per_channel,
+__global__ void gn_finalize_kernel(double* __restrict__ chan, int splits, int N, int C, int groups, double count_per_channel,
                                    float eps, int unbiased, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ mean_rstd, float* __restrict__ scale_shift) {
   const int n = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -54,8 +59,14 @@ __global__ void gn_finalize_kernel(const double* __restrict__ chan, int C, int g
   __shared__ double r1[256], r2[256];
   double s1 = 0.0, s2 = 0.0;
   if ((int)threadIdx.x < cpg) {
-    s1 = chan[((size_t)n * C + g * cpg + threadIdx.x) * 2];
-    s2 = chan[((size_t)n * C + g * cpg + threadIdx.x) * 2 + 1];
+    const int c = g * cpg + threadIdx.x;
+    const double* part = chan + (size_t)N * C * 2;
+    for (int z = 0; z < splits; ++z) {
+      s1 += part[(((size_t)z * N + n) * C + c) * 2];
+      s2 += part[(((size_t)z * N + n) * C + c) * 2 + 1];
+    }
+    chan[((size_t)n * C + c) * 2] = s1;  // per-channel totals (EvoNorm's backward reads them)
+    chan[((size_t)n * C + c) * 2 + 1] = s2;
   }
   r1[threadIdx.x] = s1;
   r2[threadIdx.x] = s2;
@@ -82,14 +93,16 @@ __global__ void gn_finalize_kernel(const double* __restrict__ chan, int C, int g
   }
 }
 
+extern "C" size_t brats_gn_ws_doubles(int N, int C) { return (size_t)(1 + GN_MAX_SPLITS) * N * C * 2; }
+
 extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
                                  double count_per_channel, float eps, const float* gamma, const float* beta,
                                  float* mean_rstd, float* scale_shift, double* chan_ws, brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
   if (scale_shift && (!gamma || !beta)) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: scale_shift needs gamma/beta");
   if (int rc = chan_reduce_launch(stats, tiles_per_sample, N, C, chan_ws, (hipStream_t)s)) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, (const double*)chan_ws, C, groups,
-                     count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, chan_ws, gn_splits(tiles_per_sample), N, C,
+                     groups, count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
@@ -364,8 +377,8 @@ extern "C" int brats_evonorm_finalize(const float* stats, int tiles_per_sample, 
                                       brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "evonorm_finalize: bad argument");
   if (int rc = chan_reduce_launch(stats, tiles_per_sample, N, C, chan_ws, (hipStream_t)s)) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, (const double*)chan_ws, C, groups,
-                     count_per_channel, eps, 1, (const float*)nullptr, (const float*)nullptr, mean_rstd, (float*)nullptr);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, chan_ws, gn_splits(tiles_per_sample), N, C,
+                     groups, count_per_channel, eps, 1, (const float*)nullptr, (const float*)nullptr, mean_rstd, (float*)nullptr);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

@@ -241,7 +241,7 @@ def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
 def gn_finalize(stats, n, c, groups, voxels, gamma, beta, eps=1e-5):
     mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)
     scale_shift = torch.empty((n, c, 2), dtype=torch.float32, device=stats.device)
-    chan = torch.empty((n, c, 2), dtype=torch.float64, device=stats.device)
+    chan = torch.empty(_lib.lib().brats_gn_ws_doubles(n, c), dtype=torch.float64, device=stats.device)
     _lib.check(_lib.lib().brats_gn_finalize(stats.data_ptr(), stats.shape[1], n, c, groups, float(voxels), eps,
                                             _f32(gamma), _f32(beta), mean_rstd.data_ptr(), scale_shift.data_ptr(),
                                             chan.data_ptr(), _stream()), "gn_finalize")
@@ -361,7 +361,7 @@ def head_bwd(x, weight, dout, scale=1, want_dx=True):
 def evonorm_finalize(stats, n, c, groups, voxels, eps=1e-5):
     """Returns (mean_rstd [N, groups, 2], chan [N, C, 2] f64 per-channel sums kept for the backward)."""
     mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)
-    chan = torch.empty((n, c, 2), dtype=torch.float64, device=stats.device)
+    chan = torch.empty(_lib.lib().brats_gn_ws_doubles(n, c), dtype=torch.float64, device=stats.device)  # totals first
     _lib.check(_lib.lib().brats_evonorm_finalize(stats.data_ptr(), stats.shape[1], n, c, groups, float(voxels), eps,
                                                  mean_rstd.data_ptr(), chan.data_ptr(), _stream()), "evonorm_finalize")
     return mean_rstd, chan

@@ -93,10 +93,13 @@ int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c
 /* ---- GroupNorm(8) + activation (nn.GroupNorm networks/factory.py:179-182, get_act :195-200) ---
  * finalize: per-(n,channel) tile partials -> per-(n,group) mean / rstd (biased var, eps) and the
  * fused per-(n,channel) affine  z = act(y*scale + shift). */
+/* f64 elements of the `chan_ws` workspace of brats_gn_finalize / brats_evonorm_finalize: [N][C][2] per-channel
+ * totals (valid after the call) followed by the per-slice partial sums; no zeroing required. */
+size_t brats_gn_ws_doubles(int N, int C);
 int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
                       double count_per_channel, float eps, const float* gamma, const float* beta,
                       float* mean_rstd /*[N][groups][2]*/, float* scale_shift /*[N][C][2]*/,
-                      double* chan_ws /*[N][C][2] f64 workspace: per-channel sums*/, brats_stream_t s);
+                      double* chan_ws /* f64 workspace of brats_gn_ws_doubles() elements */, brats_stream_t s);
 int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
                          int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
