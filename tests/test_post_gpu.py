@@ -102,3 +102,38 @@ def test_evaluator_case_vs_oracle_chain():
     assert not bool(lab_m.any())
     assert float((res["dice"].cpu() - dice_ref).abs().max()) < 1e-3   # Dice within 1e-3
     assert 0.0 < float(seg_ref.mean()) < 1.0  # the case is not degenerate
+
+
+def test_evaluator_two_model_ensemble_vs_oracle():
+    """Engine.evaluate with a list of models (learning/engine.py:196-199, :239-249): mean over models of the sigmoid
+    outputs on the padded volume (no TTA, no sliding window), threshold, background removal."""
+    from brats21_amd import get_model
+    from brats21_amd.evaluate import Evaluator
+    ns = argparse.Namespace(model="equiunet", width=8, norm="instance", act="relu", num_classes=3, dropout=0)
+    sds, models = [], []
+    for tag in ("a", "b"):
+        shapes = unet.equiunet_state_shapes(8)
+        sd = {k: synth.closed_form(f"ens{tag}.{k}", s, 0.6 if k.endswith("conv.weight") or ".0.weight" in k or k == "outconv.weight" else 1.0)
+              for k, s in shapes.items()}
+        for k in sd:
+            if k.endswith("bn.weight"):
+                sd[k] = sd[k].abs() + 0.5
+        m = get_model(ns)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        m.skip_deep_heads_in_eval = True
+        sds.append(sd)
+        models.append(m)
+    x = synth.closed_form_image(1, 4, (19, 22, 17), "ensx")
+    x = x * (synth.closed_form("ensmask", (1, 1, 19, 22, 17)) > -0.5)
+    res = Evaluator(models, amp=False, use_graph=False)(x.to(DEV))
+    with torch.no_grad():
+        xp, p_b, p_a = oev.shape_to_divisible(x, k=8)
+        probs = [torch.sigmoid(unet.equiunet_forward(sd, xp, norm="instance")[0]) for sd in sds]
+        mean = torch.stack(probs).mean(0)
+        seg_ref = oev.shape_to_original(oev.remove_background_voxels(xp, oev.as_discrete(mean)), p_b, p_a)
+        unsure = oev.shape_to_original(((mean - 0.5).abs() < 1e-3).float(), p_b, p_a).bool()
+    mism = res["seg"].cpu() != seg_ref
+    assert tuple(res["seg"].shape) == (1, 3, 19, 22, 17)
+    assert not bool((mism & ~unsure).any())
+    assert 0.0 < float(seg_ref.mean()) < 1.0
