@@ -127,6 +127,7 @@ def main():
     assert os.path.exists(LIB_PATH), "HIP extension missing"
     rank, world, local = init_process_group_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % max(torch.cuda.device_count(), 1)  # (two ranks may share one GPU under BRATS_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)  # identical random-init weights on every rank

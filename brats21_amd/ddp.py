@@ -29,7 +29,8 @@ def init_process_group_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # BRATS_DIST_BACKEND=gloo: debugging aid (e.g. two ranks sharing one GPU, where RCCL refuses duplicate devices)
+        backend = backend or os.environ.get("BRATS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
