@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("BRATS_HIP_LIB") or os.path.join(_HERE, "libbrats_hip.
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "brats_hip.h")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SWISH, ACT_MISH = 0, 1, 2, 3, 4, 5
 PACK_FWD, PACK_DGRAD = 0, 1
 
 

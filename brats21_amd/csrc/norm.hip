@@ -108,18 +108,41 @@ extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N
 }
 
 // ---- z = act(y*scale + shift) ------------------------------------------------------------------
+// HEAVY = false instantiations contain only relu / leakyrelu (the transcendental activations cost the streaming kernels
+// ~10-20 % through code size and registers even when not selected)
+template <bool HEAVY>
 DEVI float act_fwd(float x, int act, float slope) {
   if (act == BRATS_ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == BRATS_ACT_LEAKY) return x > 0.f ? x : x * slope;
+  if constexpr (!HEAVY) return x;
+  if (act == BRATS_ACT_ELU) return x > 0.f ? x : expm1f(x);
+  if (act == BRATS_ACT_SWISH) return x / (1.f + __expf(-x));
+  if (act == BRATS_ACT_MISH) {
+    const float sp = x > 20.f ? x : log1pf(__expf(x));  // softplus with torch's threshold
+    return x * tanhf(sp);
+  }
   return x;
 }
+template <bool HEAVY>
 DEVI float act_grad(float x, int act, float slope) {  // derivative at pre-activation x
   if (act == BRATS_ACT_RELU) return x > 0.f ? 1.f : 0.f;
   if (act == BRATS_ACT_LEAKY) return x > 0.f ? 1.f : slope;
+  if constexpr (!HEAVY) return 1.f;
+  if (act == BRATS_ACT_ELU) return x > 0.f ? 1.f : __expf(x);
+  if (act == BRATS_ACT_SWISH) {
+    const float sg = 1.f / (1.f + __expf(-x));
+    return sg * (1.f + x * (1.f - sg));
+  }
+  if (act == BRATS_ACT_MISH) {
+    const float sp = x > 20.f ? x : log1pf(__expf(x));
+    const float th = tanhf(sp);
+    const float sg = 1.f / (1.f + __expf(-x));
+    return th + x * (1.f - th * th) * sg;
+  }
   return 1.f;
 }
 
-template <typename T>
+template <typename T, bool HEAVY>
 __global__ void affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
                                   T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C) {
   constexpr int VW = 16 / sizeof(T);
@@ -137,7 +160,7 @@ __global__ void affine_act_kernel(const T* __restrict__ y, int ypitch, const flo
     float a[VW];
     Vec<T, VW>::load(yb + vox * ypitch + c0, a);
 #pragma unroll
-    for (int j = 0; j < VW; ++j) a[j] = act_fwd(a[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1], act, slope);
+    for (int j = 0; j < VW; ++j) a[j] = act_fwd<HEAVY>(a[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1], act, slope);
     Vec<T, VW>::store(zb + vox * zpitch + c0, a);
   }
 }
@@ -153,12 +176,21 @@ extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scal
   if (!y || !z || !scale_shift || C % vw || ypitch % vw || zpitch % vw)
     BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d", vw);
   dim3 grid(stream_grid((size_t)voxels * (C / vw), 256), N);
+  if (act > BRATS_ACT_LEAKY) {
   if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
-                       ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C);
-  else
-    hipLaunchKernelGGL(affine_act_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
-                       ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C);
+      hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
+                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C);
+    else
+      hipLaunchKernelGGL((affine_act_kernel<float, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
+                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C);
+  } else {
+  if (dtype == BRATS_BF16)
+      hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
+                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C);
+    else
+      hipLaunchKernelGGL((affine_act_kernel<float, false>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
+                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C);
+  }
   BRATS_CHECK_LAUNCH();
   return 0;
 }
@@ -168,7 +200,7 @@ extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scal
 // A thread owns one 16-byte channel vector (fixed for the whole kernel) and walks voxels: its per-channel constants
 // live in registers (read from LDS per element they made both passes LDS-bound at ~3.5 TB/s), two voxels are in
 // flight per iteration.
-template <typename T>
+template <typename T, bool HEAVY>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                             int ypitch, const float* __restrict__ scale_shift,
                                                             const float* __restrict__ mean_rstd, float* __restrict__ red, int act,
@@ -202,7 +234,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     auto body = [&](const float* g, const float* yy) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
-        const float u = g[j] * act_grad(yy[j] * sc[j] + sh[j], act, slope);
+        const float u = g[j] * act_grad<HEAVY>(yy[j] * sc[j] + sh[j], act, slope);
         a1[j] += u;
         a2[j] += u * (yy[j] * rs[j] + mo[j]);
       }
@@ -248,7 +280,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
 
 // pass 2: dy = rstd*(u*gamma - m1 - xhat*m2) = u*A + y*B + K with per-channel A = rstd*gamma, B = -rstd^2*m2,
 // K = rstd*(mean*rstd*m2 - m1);  block (0,0) also finishes dgamma/dbeta
-template <typename T>
+template <typename T, bool HEAVY>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                            int ypitch, const float* __restrict__ scale_shift,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
@@ -305,7 +337,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
   auto body = [&](const float* g, const float* yy, float* o) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      const float u = g[j] * act_grad(yy[j] * sc[j] + sh[j], act, slope);
+      const float u = g[j] * act_grad<HEAVY>(yy[j] * sc[j] + sh[j], act, slope);
       o[j] = u * ca[j] + (yy[j] * cb[j] + ck[j]);
     }
   };
@@ -348,18 +380,34 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
   dim3 g2(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
+  if (act > BRATS_ACT_LEAKY) {
   if (dtype == BRATS_BF16) {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                       ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                       ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                       voxels, C, groups);
+      hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                         ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                         voxels, C, groups);
+    } else {
+      hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, true>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
+                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
+                         ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                         voxels, C, groups);
+    }
   } else {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
-                       ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
-                       ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                       voxels, C, groups);
+  if (dtype == BRATS_BF16) {
+      hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, false>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                         ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                         voxels, C, groups);
+    } else {
+      hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, false>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
+                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
+                         ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                         voxels, C, groups);
+    }
   }
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -216,8 +216,9 @@ class EquiUnet(nn.Module):
         super().__init__()
         if norm_layer not in ("group", "instance"):
             raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance (got {norm_layer!r})")
-        if act not in ("relu", "leakyrelu"):
-            raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu only (got {act!r})")
+        if act not in ("relu", "leakyrelu", "elu", "swish", "mish"):
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu|elu|swish|mish (got {act!r}; "
+                                      "prelu has a learnable slope and is not built)")
         if dropout:
             raise NotImplementedError("dropout > 0 is not implemented (the published configs use 0)")
         if refinement:

@@ -12,7 +12,8 @@ import torch
 from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F32, PACK_DGRAD, PACK_FWD  # noqa: F401
 
-ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "leakyrelu": ACT_LEAKY}
+ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "leakyrelu": ACT_LEAKY, "elu": _lib.ACT_ELU, "swish": _lib.ACT_SWISH,
+        "mish": _lib.ACT_MISH}
 
 
 class KernelTimer:

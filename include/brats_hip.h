@@ -30,7 +30,9 @@ typedef void* brats_stream_t; /* hipStream_t */
 
 enum { BRATS_F32 = 0, BRATS_BF16 = 1 };
 enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
-enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2 };
+/* --act of the reference (src/arguments_train.py:49-50; MONAI Act factory): relu, leakyrelu(slope), elu(alpha=1),
+ * swish = x*sigmoid(x), mish = x*tanh(softplus(x)).  prelu (a learnable slope) is not built. */
+enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_ELU = 3, BRATS_ACT_SWISH = 4, BRATS_ACT_MISH = 5 };
 
 int brats_abi_version(void);
 const char* brats_last_error(void);

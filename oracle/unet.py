@@ -22,11 +22,17 @@ import torch.nn.functional as F
 
 # --------------------------------------------------------------------------- EquiUnet (GN + act)
 def _act(x, act):
-    # networks/factory.py:195-200 -> MONAI Act lookup; only relu / leakyrelu are in scope
+    # networks/factory.py:195-200 -> MONAI Act lookup (src/arguments_train.py:49-50: elu, relu, leakyrelu, prelu, swish, mish)
     if act == "relu":
         return F.relu(x)
     if act == "leakyrelu":
         return F.leaky_relu(x, 0.01)
+    if act == "elu":
+        return F.elu(x)            # MONAI Act["elu"] = nn.ELU (alpha 1)
+    if act == "swish":
+        return x * torch.sigmoid(x)  # MONAI Swish(alpha=1.0): input * sigmoid(alpha * input)
+    if act == "mish":
+        return F.mish(x)           # MONAI Mish: x * tanh(softplus(x))
     raise ValueError(act)
 
 

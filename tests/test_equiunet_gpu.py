@@ -233,3 +233,32 @@ def test_instance_norm_bf16_width48_vs_oracle():
     assert corr > 0.995, corr
     (out.float().mean() + sum(d.float().mean() for d in deeps)).backward()
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+@pytest.mark.parametrize("act", ["elu", "swish", "mish"])
+def test_other_activations_f32_network_vs_oracle(golden_dir, act):
+    """--act elu | swish | mish end to end in the exact-f32 mode: logits, loss and gradients against the oracle (and,
+    for elu, against the reference's own golden vectors; MONAI's Swish / Mish are restated in the oracle)."""
+    from brats21_amd import get_model
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(8))
+    m = get_model(argparse.Namespace(model="equiunet", width=8, norm="instance", act=act, num_classes=3, dropout=0))
+    m.load_state_dict(sd)
+    m.precision = "fp32"
+    m = m.cuda().train()
+    size = (16, 16, 16)
+    x, t = synth.closed_form_image(1, 4, size), synth.nested_spheres(1, size)
+    out, deeps = m(x.cuda())
+    loss = unet.deep_supervision_loss((out, deeps), t.cuda())
+    loss.backward()
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = unet.equiunet_forward(sd_ref, x, act=act, norm="instance")
+    loss_ref = unet.deep_supervision_loss(out_ref, t)
+    loss_ref.backward()
+    assert float((out.detach().cpu() - out_ref[0].detach()).abs().max()) < LOGIT_ATOL
+    assert abs(loss.item() - loss_ref.item()) < 1e-4
+    worst = max(float((p.grad.cpu() - sd_ref[k].grad).norm() / (sd_ref[k].grad.norm() + 1e-12)) for k, p in m.named_parameters())
+    assert worst < 5e-3, worst
+    if act == "elu":
+        g = _golden(golden_dir, "equiunet_w8_16_elu.npz")
+        assert np.abs(out.detach().cpu().numpy() - g["logits"]).max() < LOGIT_ATOL
+        assert abs(loss.item() - float(g["loss"])) < 1e-4

@@ -385,3 +385,31 @@ def test_conv3d_full_size_layer_vs_torch():
     ref1, ref2 = y_ref.detach().double().sum((0, 2, 3, 4)), (y_ref.detach().double() ** 2).sum((0, 2, 3, 4))
     torch.testing.assert_close(st[:, 0], ref1, atol=2e-2 * s ** 1.5, rtol=1e-3)
     torch.testing.assert_close(st[:, 1], ref2, atol=1e-2, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("act", ["elu", "swish", "mish"])
+def test_groupnorm_other_activations_fwd_bwd(dtype, act):
+    """--act elu | swish | mish (src/arguments_train.py:49-50) through the fused norm + activation kernels against
+    torch autograd of GroupNorm(8) followed by the same activation."""
+    from brats21_amd import ops
+    dev = _dev()
+    c, size = 16, (6, 8, 10)
+    fn = {"elu": F.elu, "swish": lambda t: t * torch.sigmoid(t), "mish": F.mish}[act]
+    y = _q(_rand((2, c, *size), 31, 1.5), dtype)
+    gamma, beta = _rand((c,), 32, 0.5) + 1.0, _rand((c,), 33, 0.3)
+    dz = _q(_rand((2, c, *size), 34), dtype)
+    yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z_ref = fn(F.group_norm(yr, 8, gr, br, 1e-5))
+    z_ref.backward(dz)
+    yd = _to_ndhwc(y, dtype, dev)
+    # statistics as the conv epilogue would deliver them: one "tile" per sample
+    st = torch.stack([y.double().sum((2, 3, 4)), (y.double() ** 2).sum((2, 3, 4))], -1).float().to(dev)[:, None]
+    vox = size[0] * size[1] * size[2]
+    mean_rstd, scale_shift = ops.gn_finalize(st.contiguous(), 2, c, 8, vox, gamma.to(dev), beta.to(dev))
+    z = ops.affine_act(yd, scale_shift, act)
+    torch.testing.assert_close(_from_ndhwc(z), z_ref.detach(), atol=_tol(dtype, 2e-5, 3e-2), rtol=_tol(dtype, 1e-5, 2e-2))
+    dy, dgamma, dbeta = ops.gn_act_bwd(_to_ndhwc(dz, dtype, dev), yd, scale_shift, mean_rstd, gamma.to(dev), 8, act)
+    torch.testing.assert_close(_from_ndhwc(dy), yr.grad, atol=_tol(dtype, 5e-5, 5e-2), rtol=_tol(dtype, 1e-4, 5e-2))
+    torch.testing.assert_close(dgamma.cpu(), gr.grad, atol=_tol(dtype, 2e-3, 0.15), rtol=_tol(dtype, 1e-4, 2e-2))
+    torch.testing.assert_close(dbeta.cpu(), br.grad, atol=_tol(dtype, 2e-3, 0.15), rtol=_tol(dtype, 1e-4, 2e-2))

@@ -216,3 +216,13 @@ def test_equiunet_instance_norm_oracle_matches_reference(golden_dir):
     names = json.loads(str(g["grad_names"]))
     norms = np.array([float(sd[k].grad.double().norm()) for k in names])
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+
+
+def test_equiunet_elu_oracle_matches_reference(golden_dir):
+    g = _load(golden_dir, "equiunet_w8_16_elu.npz")
+    meta, sd, out, loss = _run(lambda sd, x: unet.equiunet_forward(sd, x, act="elu", norm="instance"), unet.equiunet_state_shapes, g)
+    np.testing.assert_allclose(out[0].detach().numpy(), g["logits"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
