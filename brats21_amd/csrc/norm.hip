@@ -58,15 +58,29 @@ __global__ void gn_finalize_kernel(double* __restrict__ chan, int splits, int N,
   const int cpg = C / groups;
   __shared__ double r1[256], r2[256];
   double s1 = 0.0, s2 = 0.0;
-  if ((int)threadIdx.x < cpg) {
-    const int c = g * cpg + threadIdx.x;
+  {
+    // thread (cl, zl): channel cl of the group, slices zl, zl + ZL, ...; then the ZL slice sums are added in order
+    const int ZL = 256 / cpg;  // >= 1 (cpg <= 256)
+    const int cl = threadIdx.x % cpg, zl = threadIdx.x / cpg;
     const double* part = chan + (size_t)N * C * 2;
-    for (int z = 0; z < splits; ++z) {
-      s1 += part[(((size_t)z * N + n) * C + c) * 2];
-      s2 += part[(((size_t)z * N + n) * C + c) * 2 + 1];
+    double p1 = 0.0, p2 = 0.0;
+    if (zl < ZL) {
+      const int c = g * cpg + cl;
+      for (int z = zl; z < splits; z += ZL) {
+        p1 += part[(((size_t)z * N + n) * C + c) * 2];
+        p2 += part[(((size_t)z * N + n) * C + c) * 2 + 1];
+      }
     }
-    chan[((size_t)n * C + c) * 2] = s1;  // per-channel totals (EvoNorm's backward reads them)
-    chan[((size_t)n * C + c) * 2 + 1] = s2;
+    r1[threadIdx.x] = p1;
+    r2[threadIdx.x] = p2;
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+      for (int z = 0; z < ZL; ++z) { s1 += r1[z * cpg + threadIdx.x]; s2 += r2[z * cpg + threadIdx.x]; }
+      const int c = g * cpg + threadIdx.x;
+      chan[((size_t)n * C + c) * 2] = s1;  // per-channel totals (EvoNorm's backward reads them)
+      chan[((size_t)n * C + c) * 2 + 1] = s2;
+    }
+    __syncthreads();
   }
   r1[threadIdx.x] = s1;
   r2[threadIdx.x] = s2;
@@ -271,10 +285,33 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     }
   }
   __syncthreads();
+  // per-block partial sums, combined in block order by gn_bwd_finish_kernel (bitwise reproducible; no atomics, no memset)
+  float* part = red + (size_t)gridDim.y * C * 2 + ((size_t)blockIdx.x * gridDim.y + n) * C * 2;
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
     float t = 0.f;
     for (int l = 0; l < vl_n; ++l) t += scr[l * C * 2 + i];
-    atomicAdd(red + (size_t)n * C * 2 + i, t);
+    part[i] = t;
+  }
+}
+
+// red[n][i] = sum over the nb blocks of pass 1 in a fixed order.  A block = 8 entries x 32 slices (slice g adds blocks
+// g, g+32, ...; the 32 slice sums are then added in slice order).
+__global__ void __launch_bounds__(256) gn_bwd_finish_kernel(float* __restrict__ red, int nb, int total /* N*2C */) {
+  const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + e;
+  const float* part = red + total;
+  float s = 0.f;
+  if (i < total) {
+#pragma unroll 4
+    for (int b = g; b < nb; b += 32) s += part[(size_t)b * total + i];
+  }
+  __shared__ float sm[32][8];
+  sm[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+#pragma unroll
+    for (int k = 1; k < 32; ++k) s += sm[k][e];
+    red[i] = s;
   }
 }
 
@@ -361,6 +398,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+constexpr int GN_BWD_MAX_BLOCKS = 512;
+extern "C" size_t brats_gn_bwd_ws_floats(int N, int C) { return (size_t)(1 + GN_BWD_MAX_BLOCKS) * N * C * 2; }
+
 extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                                 const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red,
                                 float* dgamma, float* dbeta, int dtype, int act, float slope, int N, int voxels,
@@ -370,13 +410,10 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: C=%d / pitches must be multiples of %d", C, vw);
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * C * 2 * sizeof(float), st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "gn_act_bwd: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
-  // pass 1 ends with 2C atomics per block onto N*2C addresses: few, fat blocks (the atomics of 2048 blocks per sample
-  // serialised on 96 addresses took longer than the streaming itself)
-  dim3 g1(gx < 1 ? 1 : (gx > 512 ? 512 : gx), N);
+  // pass 1 leaves one partial sum per block; gn_bwd_finish_kernel adds them in block order
+  dim3 g1(gx < 1 ? 1 : (gx > GN_BWD_MAX_BLOCKS ? GN_BWD_MAX_BLOCKS : gx), N);
   const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
   dim3 g2(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
@@ -384,12 +421,14 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   if (dtype == BRATS_BF16) {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
                          voxels, C, groups);
     } else {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, true>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
                          voxels, C, groups);
@@ -398,12 +437,14 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   if (dtype == BRATS_BF16) {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, false>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
                          voxels, C, groups);
     } else {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, false>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
                          voxels, C, groups);

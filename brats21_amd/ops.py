@@ -266,7 +266,7 @@ def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope
     yp, _, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
     dy = new_act(n, d, h, w, c, y.dtype, y.device)
-    red = torch.empty((n, c, 2), dtype=torch.float32, device=y.device)
+    red = torch.empty(_lib.lib().brats_gn_bwd_ws_floats(n, c), dtype=torch.float32, device=y.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
     _lib.check(_lib.lib().brats_gn_act_bwd(dzp, dzpitch, yp, ypitch, scale_shift.data_ptr(), mean_rstd.data_ptr(),

@@ -105,11 +105,14 @@ int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, in
 int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
                          int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
- * u = dz * act'(.) into `red` [N][C][2] (zeroed by the call); pass 2 writes dy and finishes
+ * u = dz * act'(.) into `red` (workspace of brats_gn_bwd_ws_floats() elements); pass 2 writes dy and finishes
  * dgamma/dbeta [C]. */
+/* f32 elements of the `red` workspace of brats_gn_act_bwd: [N][C][2] totals followed by per-block partials (no zeroing
+ * required; the partials are added in block order, so the result is bitwise reproducible) */
+size_t brats_gn_bwd_ws_floats(int N, int C);
 int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                      const float* mean_rstd, const float* gamma, void* dy, int dypitch,
-                     float* red /*[N][C][2]*/, float* dgamma, float* dbeta,
+                     float* red /* workspace */, float* dgamma, float* dbeta,
                      int dtype, int act, float slope, int N, int voxels, int C, int groups,
                      brats_stream_t s);
 
