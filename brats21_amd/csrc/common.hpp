@@ -77,3 +77,7 @@ void brats_set_error(const char* fmt, ...);
   BRATS_FAIL(BRATS_E_HIP, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// out[i] = sum_{b < nb} part[b * total + i] in a fixed order (bitwise reproducible reductions without float atomics);
+// implemented in dice.hip
+int brats_ordered_sum(const float* part, float* out, int nb, int total, hipStream_t st);

@@ -6,7 +6,7 @@
 //   grad  : dx = (a_k * t + b_k * 2p) * p * (1 - p)        (a_k = dL/dI_k, b_k = dL/dP2_k, read from device memory)
 #include "common.hpp"
 
-__global__ void dice_stats_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ sums, int K,
+__global__ void dice_stats_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ part, int K,
                                   size_t voxels) {
   // grid: (blocks, N*K); each block reduces a slice of one (n, k) plane
   const int nk = blockIdx.y, k = nk % K;
@@ -41,7 +41,32 @@ __global__ void dice_stats_kernel(const float* __restrict__ x, const float* __re
     }
     __syncthreads();
   }
-  if (threadIdx.x < 3) atomicAdd(sums + k * 3 + threadIdx.x, r[threadIdx.x][0]);
+  // one partial per block: part[(n * gridDim.x + blockIdx.x)][K][3]; brats_ordered_sum adds them in block order
+  if (threadIdx.x < 3) part[(((size_t)(nk / K) * gridDim.x + blockIdx.x) * K + k) * 3 + threadIdx.x] = r[threadIdx.x][0];
+}
+
+// out[i] = sum over nb partial vectors, 8 entries x 32 slices per block, slices added in order
+__global__ void __launch_bounds__(256) ordered_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, int total) {
+  const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+  const int i = blockIdx.x * 8 + e;
+  float s = 0.f;
+  if (i < total) {
+#pragma unroll 4
+    for (int b = g; b < nb; b += 32) s += part[(size_t)b * total + i];
+  }
+  __shared__ float sm[32][8];
+  sm[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+#pragma unroll
+    for (int k = 1; k < 32; ++k) s += sm[k][e];
+    out[i] = s;
+  }
+}
+
+int brats_ordered_sum(const float* part, float* out, int nb, int total, hipStream_t st) {
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3((total + 7) / 8), dim3(256), 0, st, part, out, nb, total);
+  return 0;
 }
 
 __global__ void dice_grad_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ coef,
@@ -70,15 +95,17 @@ __global__ void dice_grad_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-extern "C" int brats_dice_stats(const float* logits, const float* target, float* sums /*[K][3], zeroed here*/, int N, int K,
+constexpr int DICE_MAX_BLOCKS = 512;
+extern "C" size_t brats_dice_ws_floats(int N, int K) { return (size_t)N * DICE_MAX_BLOCKS * K * 3; }
+
+extern "C" int brats_dice_stats(const float* logits, const float* target, float* sums /*[K][3]*/, float* ws, int N, int K,
                                 size_t voxels, brats_stream_t s) {
-  if (!logits || !target || !sums || N <= 0 || K <= 0) BRATS_FAIL(BRATS_E_ARG, "dice_stats: bad argument");
+  if (!logits || !target || !sums || !ws || N <= 0 || K <= 0) BRATS_FAIL(BRATS_E_ARG, "dice_stats: bad argument");
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(sums, 0, (size_t)K * 3 * sizeof(float), st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "dice_stats: memset: %s", hipGetErrorString(e));
   size_t gx = (voxels / 4 + 255) / 256 / 4;
-  gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
-  hipLaunchKernelGGL(dice_stats_kernel, dim3((unsigned)gx, N * K), dim3(256), 0, st, logits, target, sums, K, voxels);
+  gx = gx < 1 ? 1 : (gx > DICE_MAX_BLOCKS ? DICE_MAX_BLOCKS : gx);
+  hipLaunchKernelGGL(dice_stats_kernel, dim3((unsigned)gx, N * K), dim3(256), 0, st, logits, target, ws, K, voxels);
+  brats_ordered_sum(ws, sums, N * (int)gx, K * 3, st);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

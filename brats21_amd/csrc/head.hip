@@ -120,7 +120,7 @@ extern "C" int brats_head_fwd(const void* x, int xpitch, const float* w, const f
 // dx[v][c] = sum_k dlow[k][v]*w[k][c];  dw[k][c] += sum_v dlow[k][v]*x[v][c];  db[k] += sum_v dlow[k][v]
 template <typename T>
 __global__ void head_bwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ dlow,
-                                T* __restrict__ dx, int dxpitch, float* __restrict__ dw, float* __restrict__ db, int C, int K,
+                                T* __restrict__ dx, int dxpitch, float* __restrict__ dw /* per-block partials */, int C, int K,
                                 size_t voxels) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
@@ -169,23 +169,30 @@ __global__ void head_bwd_kernel(const T* __restrict__ x, int xpitch, const float
     }
   }
   __syncthreads();
+  // one partial vector [K*C + K] per block, added in block order afterwards (no float atomics)
+  float* part = dw + ((size_t)n * gridDim.x + blockIdx.x) * (K * C + K);
   for (int i = threadIdx.x; i < K * C; i += blockDim.x) {
     float t = 0.f;
     for (int l = 0; l < vl_n; ++l) t += scr[l * K * C + i];
-    atomicAdd(dw + i, t);
+    part[i] = t;
   }
   if ((int)threadIdx.x < K) {
     float t = 0.f;
     for (int l = 0; l < vl_n; ++l) t += scr[vl_n * K * C + l * K + threadIdx.x];
-    atomicAdd(db + threadIdx.x, t);
+    part[K * C + threadIdx.x] = t;
   }
 }
 
-extern "C" size_t brats_head_bwd_ws_bytes(int N, int K, int D, int H, int W, int scale) {
+constexpr int HEAD_MAX_BLOCKS = 1024;
+static size_t head_lerp_floats(int N, int K, int D, int H, int W, int scale) {
   if (scale <= 1) return 0;
   const size_t p = (size_t)N * K;
   const size_t dlow = p * D * H * W, t1 = p * D * (H * scale) * (W * scale), t2 = p * D * H * (W * scale);
-  return (dlow + t1 + t2) * sizeof(float);
+  return dlow + t1 + t2;
+}
+// workspace = up-sampling adjoint temporaries (scale > 1) + per-block partial sums of dw / db + the [K*C + K] totals
+extern "C" size_t brats_head_bwd_ws_bytes(int N, int C, int K, int D, int H, int W, int scale) {
+  return (head_lerp_floats(N, K, D, H, W, scale) + (size_t)(N * HEAD_MAX_BLOCKS + 1) * (K * C + K)) * sizeof(float);
 }
 
 extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout, float* ws, void* dx, int dxpitch,
@@ -195,7 +202,7 @@ extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const f
   if (!x || !w || !dout || !dw || !db || K < 1 || K > HEAD_KMAX || C % vw || xpitch % vw || (dx && dxpitch % vw) ||
       C / vw > 128)
     BRATS_FAIL(BRATS_E_ARG, "head_bwd: bad argument");
-  if (scale > 1 && !ws) BRATS_FAIL(BRATS_E_ARG, "head_bwd: workspace required when scale > 1");
+  if (!ws) BRATS_FAIL(BRATS_E_ARG, "head_bwd: workspace required");
   hipStream_t st = (hipStream_t)s;
   const size_t vox = (size_t)D * H * W, p = (size_t)N * K;
   const float* dlow = dout;
@@ -209,19 +216,22 @@ extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const f
     if ((rc = brats_lerp_adjoint_f32_planes(t2, dl, p * D * H, W * scale, W, 1, st))) return rc;
     dlow = dl;
   }
-  hipError_t e = hipMemsetAsync(dw, 0, (size_t)K * C * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)K * sizeof(float), st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "head_bwd: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = (vox + (size_t)vl * 16 - 1) / ((size_t)vl * 16);
-  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 1024 ? 1024 : gx)), N);
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > HEAD_MAX_BLOCKS ? HEAD_MAX_BLOCKS : gx)), N);
   const size_t lds = (size_t)(K * C + vl * K * C + vl * K) * sizeof(float);
+  float* part = ws + head_lerp_floats(N, K, D, H, W, scale);
+  float* tot = part + (size_t)N * HEAD_MAX_BLOCKS * (K * C + K);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, w, dlow, (bf16_t*)dx,
-                       dxpitch, dw, db, C, K, vox);
+                       dxpitch, part, C, K, vox);
   else
     hipLaunchKernelGGL(head_bwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, w, dlow, (float*)dx, dxpitch,
-                       dw, db, C, K, vox);
+                       part, C, K, vox);
+  brats_ordered_sum(part, tot, N * (int)grid.x, K * C + K, st);
+  hipError_t e = hipMemcpyAsync(dw, tot, (size_t)K * C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, tot + (size_t)K * C, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "head_bwd: copy: %s", hipGetErrorString(e));
   BRATS_CHECK_LAUNCH();
   return 0;
 }

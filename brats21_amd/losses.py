@@ -44,8 +44,9 @@ class _FusedDiceFn(torch.autograd.Function):
         vox = t[0, 0].numel()
         hs = [h.contiguous().float() for h in heads]
         sums = torch.empty((len(hs), k, 3), dtype=torch.float32, device=t.device)
+        ws = torch.empty(lib.brats_dice_ws_floats(n, k), dtype=torch.float32, device=t.device)  # per-block partials
         for i, h in enumerate(hs):
-            _lib.check(lib.brats_dice_stats(h.data_ptr(), t.data_ptr(), sums[i].data_ptr(), n, k, vox, st), "dice_stats")
+            _lib.check(lib.brats_dice_stats(h.data_ptr(), t.data_ptr(), sums[i].data_ptr(), ws.data_ptr(), n, k, vox, st), "dice_stats")
         inter, p2, t2 = sums[..., 0], sums[..., 1], sums[..., 2]
         hk = float(len(hs) * k)
         if jaccard:

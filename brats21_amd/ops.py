@@ -347,7 +347,7 @@ def head_bwd(x, weight, dout, scale=1, want_dx=True):
     k = weight.shape[0]
     wf = weight.detach().reshape(k, c).contiguous().float()
     dout = dout.contiguous().float()
-    nbytes = _lib.lib().brats_head_bwd_ws_bytes(n, k, d, h, w, scale)
+    nbytes = _lib.lib().brats_head_bwd_ws_bytes(n, c, k, d, h, w, scale)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
     dx = new_act(n, d, h, w, c, x.dtype, x.device) if want_dx else None
     dw = torch.empty((k, c), dtype=torch.float32, device=x.device)

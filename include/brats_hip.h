@@ -168,8 +168,9 @@ int brats_head_fwd(const void* x, int xpitch, const float* w /*[K][C]*/, const f
                    float* out /*[N][K][D*s][H*s][W*s]*/, int dtype, int N, int C, int K,
                    int D, int H, int W, int scale, brats_stream_t s);
 /* dout [N][K][Ds][Hs][Ws] f32 -> dx (NDHWC dtype, may be NULL), dw [K][C], db [K] (overwritten).
- * ws: f32 workspace of brats_head_bwd_ws_bytes() (unused when scale == 1). */
-size_t brats_head_bwd_ws_bytes(int N, int K, int D, int H, int W, int scale);
+ * ws: f32 workspace of brats_head_bwd_ws_bytes() (up-sampling adjoint temporaries + per-block partial sums of dw / db,
+ * added in a fixed order: no float atomics). */
+size_t brats_head_bwd_ws_bytes(int N, int C, int K, int D, int H, int W, int scale);
 int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout, float* ws,
                    void* dx, int dxpitch, float* dw, float* db, int dtype, int N, int C, int K,
                    int D, int H, int W, int scale, brats_stream_t s);
@@ -197,7 +198,9 @@ int brats_spatial_signed_perm(const float* src, float* dst, int planes, int s0, 
 /* ---- fused sigmoid-Dice / Jaccard passes (semantics of monai DiceLoss(sigmoid,
  * squared_pred, batch=True), src/definer.py:184-203).  NCDHW f32 logits / target [N][K][voxels].
  * stats: sums[k] = {sum t*p, sum p*p, sum t*t}; grad: dx = (coef[k][0]*t + coef[k][1]*2p) * p*(1-p). */
-int brats_dice_stats(const float* logits, const float* target, float* sums /*[K][3]*/, int N, int K,
+/* ws: f32 workspace of brats_dice_ws_floats(N, K) elements (per-block partial sums, added in a fixed order) */
+size_t brats_dice_ws_floats(int N, int K);
+int brats_dice_stats(const float* logits, const float* target, float* sums /*[K][3]*/, float* ws, int N, int K,
                      size_t voxels, brats_stream_t s);
 int brats_dice_grad(const float* logits, const float* target, const float* coef /*[K][2]*/,
                     float* dlogits, int N, int K, size_t voxels, brats_stream_t s);
