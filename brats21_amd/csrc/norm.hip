@@ -515,13 +515,19 @@ __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const fl
       for (int j = 0; j < VW; ++j) scr[myvl * C + c0 + j] = acc[j];
     }
     __syncthreads();
+    float* part = chansum + (size_t)gridDim.y * C + ((size_t)blockIdx.x * gridDim.y + n) * C;  // per-block partials
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float t = 0.f;
       for (int l = 0; l < vl_n; ++l) t += scr[l * C + c];
-      atomicAdd(chansum + (size_t)n * C + c, t);
+      part[c] = t;
     }
   }
 }
+
+// per-(n, channel) sums over voxels are produced as per-block partials [blocks][N][C*vals] after the [N][C*vals] totals and
+// added in block order (brats_ordered_sum): no float atomics, bitwise reproducible
+constexpr int CHAN_MAX_BLOCKS = 1024;
+extern "C" size_t brats_chan_ws_floats(int N, int C, int vals) { return (size_t)(1 + CHAN_MAX_BLOCKS) * N * C * vals; }
 
 extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
                                  void* z, int zpitch, float* chansum, int dtype, int N, int voxels, int C, int groups,
@@ -530,13 +536,9 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
   if (!x || !z || !mean_rstd || !gamma || !beta || C % vw || C % groups || xpitch % vw || zpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_fwd: bad argument (C, pitches multiples of %d)", vw);
   hipStream_t st = (hipStream_t)s;
-  if (chansum) {
-    hipError_t e = hipMemsetAsync(chansum, 0, (size_t)N * C * sizeof(float), st);
-    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "evonorm_fwd: memset: %s", hipGetErrorString(e));
-  }
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
-  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > CHAN_MAX_BLOCKS ? CHAN_MAX_BLOCKS : gx)), N);
   const size_t lds = (size_t)(2 * C + vl * C) * sizeof(float);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(evonorm_fwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
@@ -544,6 +546,7 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
   else
     hipLaunchKernelGGL(evonorm_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, mean_rstd, gamma, beta,
                        (float*)z, zpitch, chansum, voxels, C, groups);
+  if (chansum) brats_ordered_sum(chansum + (size_t)N * C, chansum, (int)grid.x, N * C, st);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
@@ -601,10 +604,11 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
     }
   }
   __syncthreads();
+  float* part = red + (size_t)gridDim.y * C * 3 + ((size_t)blockIdx.x * gridDim.y + n) * C * 3;  // per-block partials
   for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
     float t = 0.f;
     for (int l = 0; l < vl_n; ++l) t += scr[l * C * 3 + i];
-    atomicAdd(red + (size_t)n * C * 3 + i, t);
+    part[i] = t;
   }
 }
 
@@ -700,8 +704,6 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
   if (C % vw || C % groups || dzpitch % vw || xpitch % vw || dxpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: C=%d / pitches must be multiples of %d", C, vw);
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * C * 3 * sizeof(float), st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "evonorm_bwd: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
   dim3 g1((unsigned)(gx < 1 ? 1 : (gx > 512 ? 512 : gx)), N);  // few fat blocks: 3C atomics per block onto N*3C addresses
@@ -711,11 +713,13 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
   if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
                        xpitch, red, voxels, C);
+    brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
                        xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups);
   } else {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)x,
                        xpitch, red, voxels, C);
+    brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
                        xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups);
   }
@@ -783,10 +787,11 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T*
     for (int j = 0; j < VW; ++j) sm[myvl * C + c0 + j] = acc[j];
   }
   __syncthreads();
+  float* part = out + (size_t)gridDim.y * C + ((size_t)blockIdx.x * gridDim.y + n) * C;  // per-block partials
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float t = 0.f;
     for (int l = 0; l < vl_n; ++l) t += sm[l * C + c];
-    atomicAdd(out + (size_t)n * C + c, t);
+    part[c] = t;
   }
 }
 
@@ -795,8 +800,6 @@ extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int b
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!a || !out || C % vw || apitch % vw || (b && bpitch % vw) || C / vw > 256) BRATS_FAIL(BRATS_E_ARG, "channel_dot: bad argument");
   hipStream_t st = (hipStream_t)s;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)N * C * sizeof(float), st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "channel_dot: memset: %s", hipGetErrorString(e));
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
   dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 512 ? 512 : gx)), N);
@@ -805,6 +808,7 @@ extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int b
     hipLaunchKernelGGL(channel_dot_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)a, apitch, (const bf16_t*)b, bpitch, out, voxels, C);
   else
     hipLaunchKernelGGL(channel_dot_kernel<float>, grid, dim3(256), lds, st, (const float*)a, apitch, (const float*)b, bpitch, out, voxels, C);
+  brats_ordered_sum(out + (size_t)N * C, out, (int)grid.x, N * C, st);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

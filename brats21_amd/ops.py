@@ -375,11 +375,11 @@ def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False):
     if out is None:
         out = new_act(n, d, h, w, c, y.dtype, y.device)
     optr, _, op = _desc(out)
-    cs = torch.empty((n, c), dtype=torch.float32, device=y.device) if want_chansum else None
+    cs = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 1), dtype=torch.float32, device=y.device) if want_chansum else None
     _lib.check(_lib.lib().brats_evonorm_fwd(ptr, p, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), optr, op,
                                             cs.data_ptr() if cs is not None else None, _code(y.dtype), n, d * h * w, c,
                                             groups, _stream()), "evonorm_fwd")
-    return out, cs
+    return out, (cs[:n * c].view(n, c) if cs is not None else None)
 
 
 def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None):
@@ -388,7 +388,7 @@ def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None):
     yp, _, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
     dy = new_act(n, d, h, w, c, y.dtype, y.device)
-    red = torch.empty((n, c, 3), dtype=torch.float32, device=y.device)
+    red = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 3), dtype=torch.float32, device=y.device)
     dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
     dcb = torch.empty(c, dtype=torch.float32, device=y.device) if chan is not None else None
@@ -407,10 +407,10 @@ def channel_dot(a, b=None):
     if b is not None:
         bp, _, bpitch = _desc(b)
     n, d, h, w, _ = a.shape
-    out = torch.empty((n, c), dtype=torch.float32, device=a.device)
+    out = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 1), dtype=torch.float32, device=a.device)
     _lib.check(_lib.lib().brats_channel_dot(ap, apitch, bp, bpitch, out.data_ptr(), _code(a.dtype), n, d * h * w, c,
                                             _stream()), "channel_dot")
-    return out
+    return out[:n * c].view(n, c)
 
 
 def channel_scale(a, scale, add=None, out=None):

@@ -120,6 +120,10 @@ int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, con
  * z = x*sigmoid(x) * rstd_g * gamma_c + beta_c with the UNBIASED group variance.  `stats` are the
  * conv epilogue's tile partials; mean_rstd [N][groups][2].  chansum (may be NULL) [N][C] receives
  * sum_v z = the global-average-pool numerator of the following ResidualSELayer (:204-205). */
+/* f32 elements of the reduction outputs `chansum` (vals = 1), `red` of brats_evonorm_bwd (vals = 3) and `out` of
+ * brats_channel_dot (vals = 1): [N][C*vals] totals (valid after the call) followed by per-block partial sums that are
+ * added in block order -- no zeroing required, no float atomics. */
+size_t brats_chan_ws_floats(int N, int C, int vals);
 int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
                            double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
                            brats_stream_t s);

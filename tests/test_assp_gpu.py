@@ -4,6 +4,7 @@ and against the CPU oracle."""
 import argparse
 import json
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -131,3 +132,29 @@ def test_assp_bf16_and_width48_run():
     err = (out_b.detach().cpu() - out_ref[0]).abs()
     assert float(err.mean()) < 0.05 and float(err.max()) < 1.0, (float(err.mean()), float(err.max()))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for k, p in m.named_parameters() if not k.endswith(".v"))
+
+
+def test_assp_training_step_is_bitwise_reproducible():
+    """EvoNorm / SE / Dice / head reductions add per-block partial sums in a fixed order (no float atomics): two runs
+    of the same three bf16 steps give identical losses and parameters."""
+    import contextlib
+    import io
+    from brats21_amd import get_model
+    from brats21_amd.engine import TrainStep
+    from brats21_amd.optim import Ranger2020
+    dev = torch.device("cuda:0")
+    ns = argparse.Namespace(model="equiunet_assp_evo", width=16, norm="group", act="relu", num_classes=3, dropout=0)
+    x = synth.random_image(2, 4, (32, 32, 32), seed=9).to(dev)
+    t = synth.nested_spheres(2, (32, 32, 32)).to(dev)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = get_model(ns).to(dev).train()
+            opt = Ranger2020(m.parameters(), lr=3e-3, use_gc=False)
+        step = TrainStep(m, opt, amp=True)
+        losses = [float(step(x, t).detach()) for _ in range(3)]
+        runs.append((losses, torch.cat([p.detach().flatten()[:500] for p in m.parameters()]).clone()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
