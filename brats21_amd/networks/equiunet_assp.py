@@ -6,7 +6,6 @@ does, :233), same ``state_dict`` keys / shapes -- including the statically unuse
 and ``running_var`` buffer (:76-83) -- same ``forward(x) -> (logits, [deep3, deep2])`` contract.
 One autograd node; explicit forward / backward programs over NDHWC activations (see equiunet.py).
 """
-import math
 import warnings
 
 import torch

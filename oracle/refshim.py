@@ -23,7 +23,6 @@ import types
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 REFERENCE_ROOT = "/root/reference"
 

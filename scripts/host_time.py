@@ -1,6 +1,6 @@
 """Host enqueue time vs wall time of a training step (is the eager step launch-bound on this host?), with and without
 the gradient-bucket hooks of the data-parallel path."""
-import sys, time, argparse, contextlib, io, os, torch
+import sys, time, argparse, contextlib, io, torch
 sys.path.insert(0, '.')
 from brats21_amd import get_model, synth
 from brats21_amd.engine import TrainStep
