@@ -97,8 +97,8 @@ def inference_bench(model, dev, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=48)
     ap.add_argument("--batch", type=int, default=2, help="patches per GPU")
     ap.add_argument("--patch", type=int, default=128)
