@@ -156,9 +156,20 @@ DEVI float act_grad(float x, int act, float slope) {  // derivative at pre-activ
   return 1.f;
 }
 
+// |max| of a tensor as a side product of the kernel that writes it (the fp8 convolutions scale their input by it):
+// wave maximum by DPP-free shuffles, one integer atomicMax on the bits of the non-negative float per wave.  max is
+// order-independent, so this atomic keeps results bitwise reproducible.  The slot must be zero before the launch.
+template <typename T> DEVI void record_absmax(float mx, uint32_t* amax) {
+  mx = to_f<T>(from_f<T>(mx));  // rounding is monotonic: the maximum of the stored (rounded) values
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+}
+
 template <typename T, bool HEAVY>
 __global__ void affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
-                                  T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C) {
+                                  T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C,
+                                  uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float ss[];  // [C][2]
   const int n = blockIdx.y;
@@ -168,15 +179,20 @@ __global__ void affine_act_kernel(const T* __restrict__ y, int ypitch, const flo
   const size_t total = (size_t)voxels * cv;
   const T* yb = y + (size_t)n * voxels * ypitch;
   T* zb = z + (size_t)n * voxels * zpitch;
+  float mx = 0.f;
   for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
     const size_t vox = it / cv;
     const int c0 = (int)(it % cv) * VW;
     float a[VW];
     Vec<T, VW>::load(yb + vox * ypitch + c0, a);
 #pragma unroll
-    for (int j = 0; j < VW; ++j) a[j] = act_fwd<HEAVY>(a[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1], act, slope);
+    for (int j = 0; j < VW; ++j) {
+      a[j] = act_fwd<HEAVY>(a[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1], act, slope);
+      mx = fmaxf(mx, fabsf(a[j]));
+    }
     Vec<T, VW>::store(zb + vox * zpitch + c0, a);
   }
+  if (amax) record_absmax<T>(mx, amax);
 }
 
 static inline int stream_grid(size_t total, int block) {
@@ -185,7 +201,7 @@ static inline int stream_grid(size_t total, int block) {
 }
 
 extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
-                                    int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s) {
+                                    int dtype, int act, float slope, int N, int voxels, int C, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!y || !z || !scale_shift || C % vw || ypitch % vw || zpitch % vw)
     BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d", vw);
@@ -193,17 +209,17 @@ extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scal
   if (act > BRATS_ACT_LEAKY) {
   if (dtype == BRATS_BF16)
       hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
-                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C);
+                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
     else
       hipLaunchKernelGGL((affine_act_kernel<float, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
-                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C);
+                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
   } else {
   if (dtype == BRATS_BF16)
       hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
-                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C);
+                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
     else
       hipLaunchKernelGGL((affine_act_kernel<float, false>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
-                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C);
+                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
   }
   BRATS_CHECK_LAUNCH();
   return 0;
@@ -323,7 +339,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ red, T* __restrict__ dy, int dypitch,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int act,
-                                                           float slope, int N, int voxels, int C, int groups) {
+                                                           float slope, int N, int voxels, int C, int groups,
+                                                           uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   float* m12 = sm;  // [groups][2]: m1, m2 per group
@@ -352,7 +369,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
   const int cv = C / VW;
   const int vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv;
-  if (myvl >= vl_n) return;
+  const bool live = myvl < vl_n;  // idle threads stay for the |max| wave reduction at the end
   const int c0 = mycv * VW;
   float sc[VW], sh[VW], ca[VW], cb[VW], ck[VW];
 #pragma unroll
@@ -370,12 +387,14 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
   const T* yb = y + (size_t)n * voxels * ypitch + c0;
   T* dyb = dy + (size_t)n * voxels * dypitch + c0;
   const size_t stride = (size_t)gridDim.x * vl_n;
-  size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+  size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
+  float mx = 0.f;
   auto body = [&](const float* g, const float* yy, float* o) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       const float u = g[j] * act_grad<HEAVY>(yy[j] * sc[j] + sh[j], act, slope);
       o[j] = u * ca[j] + (yy[j] * cb[j] + ck[j]);
+      mx = fmaxf(mx, fabsf(o[j]));
     }
   };
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
@@ -396,6 +415,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
     body(g0, y0, o0);
     Vec<T, VW>::store(dyb + vox * dypitch, o0);
   }
+  if (amax) record_absmax<T>(mx, amax);
 }
 
 constexpr int GN_BWD_MAX_BLOCKS = 512;
@@ -404,7 +424,7 @@ extern "C" size_t brats_gn_bwd_ws_floats(int N, int C) { return (size_t)(1 + GN_
 extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                                 const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red,
                                 float* dgamma, float* dbeta, int dtype, int act, float slope, int N, int voxels,
-                                int C, int groups, brats_stream_t s) {
+                                int C, int groups, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: null pointer");
   if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
@@ -424,14 +444,14 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
       hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups);
+                         voxels, C, groups, (uint32_t*)amax);
     } else {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, true>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
       hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups);
+                         voxels, C, groups, (uint32_t*)amax);
     }
   } else {
   if (dtype == BRATS_BF16) {
@@ -440,14 +460,14 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
       hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups);
+                         voxels, C, groups, (uint32_t*)amax);
     } else {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, false>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
       hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
       hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
                          ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups);
+                         voxels, C, groups, (uint32_t*)amax);
     }
   }
   BRATS_CHECK_LAUNCH();

@@ -218,6 +218,96 @@ def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=Fa
     return ((out, y2) if y2 is not None else out), stats
 
 
+# ------------------------------------------------------------------------------------------ fp8 conv
+def absmax(x):
+    """max|x| of an NDHWC tensor as a 1-element f32 device tensor (no host sync)."""
+    ptr, c, p = _desc(x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().brats_absmax(ptr, p, _code(x.dtype), x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3], c,
+                                       out.data_ptr(), _stream()), "absmax")
+    return out
+
+
+def conv_f8_chunk(c1, c2=0):
+    """Channel chunk of the fp8 kernel for an input of c1 (+c2) channels; 0 = not supported (use conv3d)."""
+    return _lib.lib().brats_conv3d_f8_chunk(c1, c2)
+
+
+def pack_weights_f8(w, mode, cin_pad=None, cin_off=0, cin_cnt=None, c1=None):
+    """e4m3 fragments + per-row power-of-two scales for conv3d_f8 (3x3x3 only); arguments as pack_weights()."""
+    key = None
+    if not torch.is_grad_enabled():
+        key = (id(w), "f8", mode, cin_pad, cin_off, cin_cnt, 0, c1)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+            return hit[3]
+    w0 = w
+    cout_w, cin_w, k = w.shape[0], w.shape[1], w.shape[2]
+    if k != 3:
+        raise _lib.BratsHipError("pack_weights_f8: 3x3x3 kernels only")
+    w = w.detach()
+    if cin_pad is not None and cin_pad != cin_w:
+        wp = torch.zeros((cout_w, cin_pad, k, k, k), dtype=torch.float32, device=w.device)
+        wp[:, :cin_w] = w
+        w, cin_w = wp, cin_pad
+    w = w.contiguous().float()
+    cin_cnt = cin_w - cin_off if cin_cnt is None else cin_cnt
+    kdim, rows = (cin_cnt, cout_w) if mode == PACK_FWD else (cout_w, cin_cnt)
+    ck = conv_f8_chunk(kdim) if (c1 is None or mode != PACK_FWD) else conv_f8_chunk(c1, kdim - c1)
+    if ck <= 0:
+        raise _lib.BratsHipError(f"pack_weights_f8: K channels {kdim} (c1={c1}) are not multiples of 16")
+    nbytes = _lib.lib().brats_conv3d_f8_packed_bytes(kdim, rows, ck)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(_lib.lib().brats_conv3d_f8_pack_weights(w.data_ptr(), packed.data_ptr(), mode, cout_w, cin_w, cin_off,
+                                                       cin_cnt, ck, _stream()), "conv3d_f8_pack_weights")
+    if key is not None:
+        if len(_PACK_CACHE) >= 1024:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (weakref.ref(w0), w0._version, w0.data_ptr(), packed)
+    return packed
+
+
+def conv3d_f8(x, packed_w, cout, dil=1, bias=None, out=None, want_stats=False, x2=None, split=None, amax=None, amax2=None,
+              xscale=None):
+    """conv3d() with the e4m3 MFMA kernel (bf16 tensors in and out).  amax / amax2: 1-element f32 tensors holding
+    max|x| / max|x2| (from affine_act / gn_act_bwd / absmax); when missing they are computed here (one extra pass)
+    unless a static power-of-two ``xscale`` is given."""
+    if x.dtype != torch.bfloat16:
+        raise _lib.BratsHipError("conv3d_f8: bf16 activations only")
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    ptr2, c2, p2 = (None, 0, 0)
+    if x2 is not None:
+        ptr2, c2, p2 = _desc(x2)
+    if xscale is None:
+        if amax is None:
+            amax = absmax(x)
+        if x2 is not None and amax2 is None:
+            amax2 = absmax(x2)
+    else:
+        amax = amax2 = None
+    y2 = None
+    if split is not None:
+        out = new_act(n, d, h, w, split, x.dtype, x.device)
+        y2 = new_act(n, d, h, w, cout - split, x.dtype, x.device)
+    elif out is None:
+        out = new_act(n, d, h, w, cout, x.dtype, x.device)
+    optr, oc, op = _desc(out)
+    if (y2 is None and oc != cout) or out.dtype != x.dtype:
+        raise _lib.BratsHipError("conv3d_f8: bad output tensor")
+    stats = None
+    if want_stats:
+        stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
+    with _span("conv_igemm_f8", c + c2, cout, 3, dil, n, d, h, w, "e4m3"):
+        _lib.check(_lib.lib().brats_conv3d_f8_fwd(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2),
+                                                  float(xscale) if xscale is not None else 0.0, packed_w.data_ptr(),
+                                                  _f32(bias), optr, op, y2.data_ptr() if y2 is not None else None,
+                                                  (cout - split) if y2 is not None else 0, split or 0,
+                                                  stats.data_ptr() if stats is not None else None, dil, n, d, h, w, cout,
+                                                  _stream()), "conv3d_f8_fwd")
+    return ((out, y2) if y2 is not None else out), stats
+
+
 def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
     """dW [cout, cin (+cin2), k,k,k] f32 (and dbias) from the layer input [x | x2] and the output gradient dy."""
     ptr, c, p = _desc(x)
@@ -249,19 +339,20 @@ def gn_finalize(stats, n, c, groups, voxels, gamma, beta, eps=1e-5):
     return mean_rstd, scale_shift
 
 
-def affine_act(y, scale_shift, act="relu", out=None, slope=0.01):
+def affine_act(y, scale_shift, act="relu", out=None, slope=0.01, amax=None):
+    """amax: optional zero-initialised 1-element f32 tensor that receives max|out| (scale source of conv3d_f8)."""
     ptr, c, p = _desc(y)
     n, d, h, w, _ = y.shape
     if out is None:
         out = new_act(n, d, h, w, c, y.dtype, y.device)
     optr, oc, op = _desc(out)
     _lib.check(_lib.lib().brats_affine_act_fwd(ptr, p, scale_shift.data_ptr(), optr, op, _code(y.dtype), ACTS[act], slope,
-                                               n, d * h * w, c, _stream()), "affine_act_fwd")
+                                               n, d * h * w, c, _f32(amax), _stream()), "affine_act_fwd")
     return out
 
 
-def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01):
-    """Returns (dy, dgamma, dbeta) for z = act(GroupNorm(y))."""
+def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None):
+    """Returns (dy, dgamma, dbeta) for z = act(GroupNorm(y)); amax (optional, zero-initialised) receives max|dy|."""
     dzp, c, dzpitch = _desc(dz)
     yp, _, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
@@ -272,7 +363,7 @@ def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope
     _lib.check(_lib.lib().brats_gn_act_bwd(dzp, dzpitch, yp, ypitch, scale_shift.data_ptr(), mean_rstd.data_ptr(),
                                            _f32(gamma), dy.data_ptr(), c, red.data_ptr(), dgamma.data_ptr(),
                                            dbeta.data_ptr(), _code(y.dtype), ACTS[act], slope, n, d * h * w, c, groups,
-                                           _stream()), "gn_act_bwd")
+                                           _f32(amax), _stream()), "gn_act_bwd")
     return dy, dgamma, dbeta
 
 

@@ -78,6 +78,23 @@ int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2,
                      void* y2, int y2pitch, int ysplit, float* stats,
                      int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                      brats_stream_t s);
+/* ---- fp8 (OCP e4m3) variant of the 3x3x3 convolution (BASELINE.json configs[4], "fp8 MFMA conv path"): bf16 NDHWC
+ * activations in and out; the input is quantised to e4m3 while it is staged (x / 2^e, round-to-nearest-even, e chosen
+ * from the tensor's |max| so that it lands in [128, 256)), the weights are packed as e4m3 with one power-of-two scale
+ * per output channel, the MMA is v_mfma_scale_f32_16x16x128_f8f6f4 with f32 accumulation.  Replaces the same
+ * nn.Conv3d / dgrad as brats_conv3d_fwd.  Channel counts must be multiples of 16. */
+int brats_conv3d_f8_chunk(int c1, int c2);                      /* 48, 32, 16 or 0 = unsupported */
+size_t brats_conv3d_f8_packed_bytes(int cin, int cout, int ck); /* scales [ceil16(cout)] f32 + e4m3 fragments */
+int brats_conv3d_f8_pack_weights(const float* w, void* packed, int mode, int cout_w, int cin_w, int cin_off,
+                                 int cin_cnt, int ck, brats_stream_t s);
+/* amax1 / amax2: device scalars holding max|x1| / max|x2| (written by brats_affine_act_fwd, brats_gn_act_bwd or
+ * brats_absmax); both NULL -> the static power-of-two `xscale` is used (values beyond 448*xscale would become NaN) */
+int brats_conv3d_f8_fwd(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+                        const float* amax2, float xscale, const void* packed_w, const float* bias, void* y, int ypitch,
+                        void* y2, int y2pitch, int ysplit, float* stats, int dil, int N, int D, int H, int W, int cout,
+                        brats_stream_t s);
+/* out[0] = max |x| over `rows` voxels x C channels of an NDHWC tensor (channel pitch `pitch`) */
+int brats_absmax(const void* x, int pitch, int dtype, size_t rows, int C, float* out, brats_stream_t s);
 /* wgrad: dW[co][ci][tap] = sum_v dy[v][co] * x[v + off(tap)][ci]  (x = virtual concat as above).
  * `ws` = f32 workspace of brats_conv3d_wgrad_ws_bytes(); dw = [cout][c1+c2][k^3] f32, overwritten.
  * dbias (may be NULL): [cout] f32 = sum_v dy. */
@@ -102,8 +119,10 @@ int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, in
                       double count_per_channel, float eps, const float* gamma, const float* beta,
                       float* mean_rstd /*[N][groups][2]*/, float* scale_shift /*[N][C][2]*/,
                       double* chan_ws /* f64 workspace of brats_gn_ws_doubles() elements */, brats_stream_t s);
+/* amax (optional, device scalar that is ZERO before the call): receives max|z|, the scale source of the fp8
+ * convolutions (brats_conv3d_f8_fwd) */
 int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
-                         int dtype, int act, float slope, int N, int voxels, int C, brats_stream_t s);
+                         int dtype, int act, float slope, int N, int voxels, int C, float* amax, brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
  * u = dz * act'(.) into `red` (workspace of brats_gn_bwd_ws_floats() elements); pass 2 writes dy and finishes
  * dgamma/dbeta [C]. */
@@ -114,7 +133,7 @@ int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, con
                      const float* mean_rstd, const float* gamma, void* dy, int dypitch,
                      float* red /* workspace */, float* dgamma, float* dbeta,
                      int dtype, int act, float slope, int N, int voxels, int C, int groups,
-                     brats_stream_t s);
+                     float* amax /* optional, zero before the call: receives max|dy| */, brats_stream_t s);
 
 /* ---- EvoNorm-S0 (EvoNorm3D networks/equiunet2021.py:55-118, group_std :48-52; groups = 8) ---------
  * z = x*sigmoid(x) * rstd_g * gamma_c + beta_c with the UNBIASED group variance.  `stats` are the
