@@ -22,6 +22,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0    # dense MX-scaled e4m3 MFMA (--fp8 only)
 
 
 def conv_flops(cin, cout, k, n, d, h, w):
@@ -114,6 +115,9 @@ def main():
     ap.add_argument("--sw-batch", type=int, default=3, help="sliding-window windows per forward in the inference leg")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one hipGraph (single GPU; no per-kernel timers, so roofline is null)")
+    ap.add_argument("--fp8", default=None, choices=["fwd", "all"],
+                    help="NOT the headline configuration: run the 3x3x3 convolutions forward (fwd) or forward + input "
+                         "gradients (all) on the e4m3 MFMA kernel (BASELINE.json configs[4]); weight gradients stay bf16")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
     args = ap.parse_args()
 
@@ -135,6 +139,9 @@ def main():
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         model = get_model(ns).to(dev).train()
+    if args.fp8:
+        assert args.precision == "bf16", "--fp8 needs bf16 activations"
+        model.conv_fp8 = args.fp8
     crit = DiceLoss().to(dev)
     if args.optimizer == "ranger":  # src/definer.py:316-331 + the CLI defaults lr 1e-4, weight_decay 1e-5
         with contextlib.redirect_stdout(io.StringIO()):
@@ -198,7 +205,7 @@ def main():
       cnt, avg_ms, tot_ms = table[dom_key]
       kind, cin, cout, k, dil, n, d, h, w, dt = dom_key
       fl = conv_flops(cin, cout, k, n, d, h, w)
-      peak = PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS
+      peak = PEAK_FP8_TFLOPS if dt == "e4m3" else (PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS)
       achieved = fl / (avg_ms * 1e-3) / 1e12
       roofline = {"bound": "mfma", "kernel": f"{kind} cin={cin} cout={cout} k={k} dil={dil} @{n}x{d}x{h}x{w}",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -216,7 +223,8 @@ def main():
     res = {
         "metric": "train patches/sec (4x128^3, width-48)", "value": round(patches / elapsed, 4), "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision + (f"+e4m3 conv ({args.fp8})" if args.fp8 else ""), "data": "synthetic",
         "config": {"workload": f"{args.model} width={args.width}, batch={args.batch}/GPU of 4x{args.patch}^3 synthetic patches, "
                                f"fwd + deep-supervision Dice + bwd + {args.optimizer} (BASELINE.json configs[1])",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},

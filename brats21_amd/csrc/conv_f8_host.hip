@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) absmax_kernel(const T* __restrict__ x, in
     if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(red[0]));
+  if (threadIdx.x == 0 && __float_as_uint(red[0]) > *(volatile uint32_t*)out) atomicMax(out, __float_as_uint(red[0]));
 }
 
 extern "C" int brats_absmax(const void* x, int pitch, int dtype, size_t rows, int C, float* out, brats_stream_t s) {

@@ -163,35 +163,75 @@ template <typename T> DEVI void record_absmax(float mx, uint32_t* amax) {
   mx = to_f<T>(from_f<T>(mx));  // rounding is monotonic: the maximum of the stored (rounded) values
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(mx));
+  // one access per BLOCK: tens of thousands of waves reading / updating one address serialise in a single L2 channel
+  // (+20 us per launch when every wave did it).  The slot only grows, so a plain, possibly stale read filters all but
+  // the few blocks that would still raise it.
+  __shared__ float wmax[16];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, wmax[w]);
+    const uint32_t bits = __float_as_uint(mx);
+    if (bits > *(volatile uint32_t*)amax) atomicMax(amax, bits);
+  }
 }
 
+// A thread owns one 16-byte channel vector (its scale / shift live in registers) and walks voxels, two in flight;
+// relu -- the published configuration -- is specialised so that the loop body is cvt, fma, max, cvt per element.
 template <typename T, bool HEAVY>
-__global__ void affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
-                                  T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C,
-                                  uint32_t* __restrict__ amax) {
+__global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
+                                                         T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C,
+                                                         uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
-  extern __shared__ float ss[];  // [C][2]
   const int n = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) ss[i] = scale_shift[(size_t)n * C * 2 + i];
-  __syncthreads();
   const int cv = C / VW;
-  const size_t total = (size_t)voxels * cv;
-  const T* yb = y + (size_t)n * voxels * ypitch;
-  T* zb = z + (size_t)n * voxels * zpitch;
-  float mx = 0.f;
-  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-    const size_t vox = it / cv;
-    const int c0 = (int)(it % cv) * VW;
-    float a[VW];
-    Vec<T, VW>::load(yb + vox * ypitch + c0, a);
+  const int vl_n = blockDim.x / cv;  // voxel lanes per block
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv;
+  const bool live = myvl < vl_n;
+  const int c0 = mycv * VW;
+  float sc[VW], sh[VW];
 #pragma unroll
-    for (int j = 0; j < VW; ++j) {
-      a[j] = act_fwd<HEAVY>(a[j] * ss[(c0 + j) * 2] + ss[(c0 + j) * 2 + 1], act, slope);
-      mx = fmaxf(mx, fabsf(a[j]));
-    }
-    Vec<T, VW>::store(zb + vox * zpitch + c0, a);
+  for (int j = 0; j < VW; ++j) {
+    sc[j] = scale_shift[((size_t)n * C + c0 + j) * 2];
+    sh[j] = scale_shift[((size_t)n * C + c0 + j) * 2 + 1];
   }
+  const T* yb = y + (size_t)n * voxels * ypitch + c0;
+  T* zb = z + (size_t)n * voxels * zpitch + c0;
+  const int stride = gridDim.x * vl_n;
+  float mx = 0.f;
+  auto run = [&](auto relu_) {
+    constexpr bool RELU = decltype(relu_)::value;
+    auto body = [&](float* a) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const float t = a[j] * sc[j] + sh[j];
+        if constexpr (RELU) a[j] = __builtin_fmaxf(t, 0.f);
+        else a[j] = act_fwd<HEAVY>(t, act, slope);
+      }
+      if (amax) {
+#pragma unroll
+        for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a[j])), __builtin_fabsf(a[j + 1]));
+      }
+    };
+    int vox = live ? blockIdx.x * vl_n + myvl : voxels;
+    for (; vox + stride < voxels; vox += 2 * stride) {
+      float a0[VW], a1[VW];
+      Vec<T, VW>::load(yb + (size_t)vox * ypitch, a0);
+      Vec<T, VW>::load(yb + (size_t)(vox + stride) * ypitch, a1);
+      body(a0);
+      body(a1);
+      Vec<T, VW>::store(zb + (size_t)vox * zpitch, a0);
+      Vec<T, VW>::store(zb + (size_t)(vox + stride) * zpitch, a1);
+    }
+    if (vox < voxels) {
+      float a0[VW];
+      Vec<T, VW>::load(yb + (size_t)vox * ypitch, a0);
+      body(a0);
+      Vec<T, VW>::store(zb + (size_t)vox * zpitch, a0);
+    }
+  };
+  if (!HEAVY && act == BRATS_ACT_RELU) run(std::true_type{});
+  else run(std::false_type{});
   if (amax) record_absmax<T>(mx, amax);
 }
 
@@ -203,23 +243,27 @@ static inline int stream_grid(size_t total, int block) {
 extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
                                     int dtype, int act, float slope, int N, int voxels, int C, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
-  if (!y || !z || !scale_shift || C % vw || ypitch % vw || zpitch % vw)
-    BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d", vw);
-  dim3 grid(stream_grid((size_t)voxels * (C / vw), 256), N);
+  if (!y || !z || !scale_shift || C % vw || ypitch % vw || zpitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d (C <= %d)", vw, 256 * vw);
+  const int vl = 256 / (C / vw);
+  const int gx = (voxels + vl * 8 - 1) / (vl * 8);
+  dim3 grid(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
+  hipStream_t st = (hipStream_t)s;
+  uint32_t* am = (uint32_t*)amax;
   if (act > BRATS_ACT_LEAKY) {
-  if (dtype == BRATS_BF16)
-      hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
-                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
+    if (dtype == BRATS_BF16)
+      hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
+                         zpitch, act, slope, voxels, C, am);
     else
-      hipLaunchKernelGGL((affine_act_kernel<float, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
-                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
+      hipLaunchKernelGGL((affine_act_kernel<float, true>), grid, dim3(256), 0, st, (const float*)y, ypitch, scale_shift, (float*)z,
+                         zpitch, act, slope, voxels, C, am);
   } else {
-  if (dtype == BRATS_BF16)
-      hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)y,
-                         ypitch, scale_shift, (bf16_t*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
+    if (dtype == BRATS_BF16)
+      hipLaunchKernelGGL((affine_act_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
+                         zpitch, act, slope, voxels, C, am);
     else
-      hipLaunchKernelGGL((affine_act_kernel<float, false>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)y,
-                         ypitch, scale_shift, (float*)z, zpitch, act, slope, voxels, C, (uint32_t*)amax);
+      hipLaunchKernelGGL((affine_act_kernel<float, false>), grid, dim3(256), 0, st, (const float*)y, ypitch, scale_shift, (float*)z,
+                         zpitch, act, slope, voxels, C, am);
   }
   BRATS_CHECK_LAUNCH();
   return 0;
@@ -394,7 +438,10 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
     for (int j = 0; j < VW; ++j) {
       const float u = g[j] * act_grad<HEAVY>(yy[j] * sc[j] + sh[j], act, slope);
       o[j] = u * ca[j] + (yy[j] * cb[j] + ck[j]);
-      mx = fmaxf(mx, fabsf(o[j]));
+    }
+    if (amax) {
+#pragma unroll
+      for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
     }
   };
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {

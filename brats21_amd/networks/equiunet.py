@@ -69,29 +69,68 @@ def _head(cin, k):
 
 
 # ------------------------------------------------------------------------------------------ programs
-def _cgr_fwd(unit, x, dtype, act, out=None, x2=None):
+class _AmaxSlots:
+    """Zero-initialised device scalars for the |max| side outputs of the producer kernels (one fill per pass)."""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.i = 0
+
+    def take(self):
+        s = self.buf[self.i:self.i + 1]
+        self.i += 1
+        return s
+
+
+def _inherit_amax(dst, src):
+    """max-pooling / trilinear interpolation never exceed the |max| of their input."""
+    a = getattr(src, "_amax", None)
+    if a is not None:
+        dst._amax = a
+    return dst
+
+
+def _f8_ok(fp8, dtype, x, x2=None):
+    return bool(fp8) and dtype == torch.bfloat16 and ops.conv_f8_chunk(x.shape[-1], x2.shape[-1] if x2 is not None else 0) > 0
+
+
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
-    -> finalize -> normalise+act."""
+    -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
+    x recorded); the normalise+act pass records the |max| of its own output for the next layer."""
     w = unit.conv.weight
     cout = w.shape[0]
     cin_pad = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
-    wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=x.shape[-1] if x2 is not None else None)
-    y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
+    c1 = x.shape[-1] if x2 is not None else None
+    if _f8_ok(fp8, dtype, x, x2):
+        wpk = ops.pack_weights_f8(w, PACK_FWD, cin_pad=cin_pad, c1=c1)
+        y, stats = ops.conv3d_f8(x, wpk, cout, unit.dilation, want_stats=True, x2=x2, amax=getattr(x, "_amax", None),
+                                 amax2=getattr(x2, "_amax", None) if x2 is not None else None)
+    else:
+        wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=c1)
+        y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
     n, d, h, wd, _ = y.shape
     mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
-    z = ops.affine_act(y, scale_shift, act, out=out)
+    amax = slots.take() if slots is not None else None
+    z = ops.affine_act(y, scale_shift, act, out=out, amax=amax)
+    if amax is not None:
+        z._amax = amax
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
-def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None):
-    """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit."""
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None):
+    """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
+    fp8 == "all": the input gradient (dgrad) runs on the e4m3 kernel too, scaled by the |max| of dy that the GroupNorm
+    backward records; the weight gradient stays bf16."""
     unit, x, x2, y, mean_rstd, scale_shift = rec
-    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, act)
+    cin = unit.conv.weight.shape[1]
+    f8 = fp8 == "all" and need_dx and dtype == torch.bfloat16 and ops.conv_f8_chunk(y.shape[-1]) > 0
+    amax = slots.take() if (f8 and slots is not None) else None
+    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, act, amax=amax)
     if x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
         dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
     else:
         dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2)
-    cin = unit.conv.weight.shape[1]
     grads[names[unit.conv.weight]] = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
     grads[names[unit.bn.weight]] = dgamma
     grads[names[unit.bn.bias]] = dbeta
@@ -100,15 +139,24 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None):
             sink(names[prm], grads[names[prm]])
     if not need_dx:
         return None
-    wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
+    if f8:
+        wpk = ops.pack_weights_f8(unit.conv.weight, PACK_DGRAD)
+
+        def dgrad(**kw):
+            return ops.conv3d_f8(dy, wpk, cin, unit.dilation, amax=amax, **kw)
+    else:
+        wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
+
+        def dgrad(**kw):
+            return ops.conv3d(dy, wpk, cin, 3, unit.dilation, **kw)
     if x2 is None:
-        dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation)
+        dx, _ = dgrad()
         return dx
     c1 = x.shape[-1]
     if c1 % ops.split_granule(cin) == 0:
-        dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation, split=c1)  # (dx1, dx2): two dense tensors, one launch
+        dx, _ = dgrad(split=c1)  # (dx1, dx2): two dense tensors, one launch
         return dx
-    dx, _ = ops.conv3d(dy, wpk, cin, 3, unit.dilation)  # narrow test widths: slice views of one tensor
+    dx, _ = dgrad()  # narrow test widths: slice views of one tensor
     return dx[..., :c1], dx[..., c1:]
 
 
@@ -122,25 +170,34 @@ class _EquiUnetFn(torch.autograd.Function):
         dev = x.device
         tape = []
 
+        fp8 = m.conv_fp8 if dtype == torch.bfloat16 else None
+        slots = _AmaxSlots(32, dev) if fp8 else None
+
         def cgr(unit, xin, x2=None):
-            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2)
+            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots)
             tape.append(rec)
             return z
+
+        def pool(t):
+            return _inherit_amax(ops.maxpool2(t), t)
+
+        def up(t):
+            return _inherit_amax(ops.upsample(t, 2), t)
 
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
         # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
         # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
         down1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0))
-        down2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, ops.maxpool2(down1)))
-        down3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, ops.maxpool2(down2)))
-        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, ops.maxpool2(down3)))
+        down2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, pool(down1)))
+        down3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, pool(down2)))
+        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, pool(down3)))
         # bottom (:477-478): dilated block, then conv over cat[down4, bottom]
         bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4))
         bottom_2 = cgr(m.bottom_2, down4, x2=bottom)
         # decoder (:481-486)
-        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, down3, x2=ops.upsample(bottom_2, 2)))
-        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, down2, x2=ops.upsample(up3, 2)))
-        up1 = cgr(m.decoder1.ConvBnRelu2, cgr(m.decoder1.ConvBnRelu1, down1, x2=ops.upsample(up2, 2)))
+        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, down3, x2=up(bottom_2)))
+        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, down2, x2=up(up3)))
+        up1 = cgr(m.decoder1.ConvBnRelu2, cgr(m.decoder1.ConvBnRelu1, down1, x2=up(up2)))
         outs = [ops.head(up1, m.outconv.weight, m.outconv.bias, 1)]
         heads = [(m.outconv, up1, 1)]
         if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
@@ -162,8 +219,11 @@ class _EquiUnetFn(torch.autograd.Function):
         down1, down2, down3, down4, bottom, bottom_2, up3, up2, up1 = ctx.bufs
         rec = {r[0]: r for r in tape}
 
+        fp8 = m.conv_fp8 if dtype == torch.bfloat16 else None
+        slots = _AmaxSlots(32, douts[0].device) if fp8 == "all" else None
+
         def cbw(unit, dz, need_dx=True):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink)
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
@@ -230,6 +290,9 @@ class EquiUnet(nn.Module):
         self.act = act
         self.features = list(features)
         self.precision = "auto"
+        # None | "fwd" | "all": run the 3x3x3 convolutions (forward / forward + input gradients) on the e4m3 MFMA kernel
+        # when the activations are bf16 (BASELINE.json configs[4]); the weight gradients stay bf16
+        self.conv_fp8 = None
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
         f = self.features

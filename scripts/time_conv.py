@@ -12,7 +12,12 @@ dy = torch.randn(N, s, s, s, cout, device=dev).to(dt)
 w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
 wpk = ops.pack_weights(w, dt, ops.PACK_FWD, dil=dil)
 fl = 2.0 * cin * 27 * cout * N * s ** 3
-for name, fn in (("fwd", lambda: ops.conv3d(x, wpk, cout, 3, dil, want_stats=True)), ("wgrad", lambda: ops.conv3d_wgrad(x, dy, 3, dil))):
+cases = [("fwd", lambda: ops.conv3d(x, wpk, cout, 3, dil, want_stats=True)), ("wgrad", lambda: ops.conv3d_wgrad(x, dy, 3, dil))]
+if ops.conv_f8_chunk(cin) > 0:  # the e4m3 kernel of the same layer (scale source already on the device)
+    wpk8 = ops.pack_weights_f8(w, ops.PACK_FWD)
+    amax = ops.absmax(x)
+    cases.insert(1, ("fwd_f8", lambda: ops.conv3d_f8(x, wpk8, cout, dil, want_stats=True, amax=amax)))
+for name, fn in cases:
     for _ in range(3): fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
