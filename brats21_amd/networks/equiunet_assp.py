@@ -77,6 +77,9 @@ class _Ctx:
 
     def __init__(self, model, dtype):
         self.m, self.dtype = model, dtype
+        # e4m3 convolutions (EquiUnet.conv_fp8 semantics).  The EvoNorm / SE kernels do not record the |max| of their
+        # outputs yet, so every fp8 convolution here pays one extra read pass (ops.absmax) for its scale.
+        self.fp8 = getattr(model, "conv_fp8", None) if dtype == torch.bfloat16 else None
         self.names = {p: i for i, p in enumerate(model.parameters())}
         self.grads = {}
 
@@ -97,6 +100,10 @@ def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
         wpk = ops.pack_weights(w1, cx.dtype, PACK_FWD)
         y, stats = ops.conv3d(col, wpk, cout, 1, 1, bias=_flat(conv.bias), out=out, want_stats=want_stats)
         return y, stats, ("col", col, dil)
+    if cx.fp8 and k == 3 and ops.conv_f8_chunk(x.shape[-1]) > 0:
+        wpk = ops.pack_weights_f8(w, PACK_FWD, cin_pad=x.shape[-1])
+        y, stats = ops.conv3d_f8(x, wpk, cout, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
+        return y, stats, ("direct", x, dil)
     wpk = ops.pack_weights(w, cx.dtype, PACK_FWD, cin_pad=x.shape[-1], dil=dil)
     y, stats = ops.conv3d(x, wpk, cout, k, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
     return y, stats, ("direct", x, dil)
@@ -125,6 +132,9 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     cx.put(conv.bias, db)
     if not need_dx:
         return None
+    if cx.fp8 == "all" and k == 3 and ops.conv_f8_chunk(cout) > 0:
+        dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil)
+        return dx
     dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil)
     return dx
 
@@ -288,6 +298,7 @@ class EquiUnetASSPEvo(nn.Module):
         self.act = act.upper()
         self.features = list(features)
         self.precision = "auto"
+        self.conv_fp8 = None  # None | "fwd" | "all": e4m3 kernel for the 3x3x3 convolutions (see EquiUnet.conv_fp8)
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None
         f = self.features
