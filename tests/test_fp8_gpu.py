@@ -186,3 +186,31 @@ def test_fp8_forward_and_training_step_track_bf16(name):
     b = run("all")
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     model.conv_fp8 = None
+
+
+def test_conv3d_f8_zero_input_and_nan_propagation():
+    """|max| = 0 must not divide by zero (scale clamps to 2^-126: output = bias); a NaN / Inf in the input makes the
+    recorded |max| non-finite, the scale falls back to 1 and the bad value reaches the output as NaN instead of being
+    silently clipped."""
+    from brats21_amd import ops
+    from brats21_amd._lib import PACK_FWD
+    dev = _dev()
+    cin, cout, size = 48, 48, (4, 4, 16)
+    w = _rand((cout, cin, 3, 3, 3), 2, 0.05)
+    b = _rand((cout,), 3, 0.1)
+    wpk = ops.pack_weights_f8(w.to(dev), PACK_FWD)
+    x = torch.zeros(1, *size, cin, device=dev, dtype=torch.bfloat16)
+    y, _ = ops.conv3d_f8(x, wpk, cout, 1, bias=b.to(dev))
+    assert torch.equal(y.float().cpu(), b.to(torch.bfloat16).float().expand(1, *size, cout))
+    x = _ndhwc(_rand((1, cin) + size, 4), dev)
+    x[0, 1, 1, 8, 5] = float("nan")
+    y, _ = ops.conv3d_f8(x, wpk, cout, 1, bias=b.to(dev))
+    yc = y.float().cpu()
+    assert torch.isnan(yc[0, 1, 1, 8]).all()          # the voxel itself (centre tap) ...
+    assert torch.isnan(yc[0, 0:3, 0:3, 7:10]).all()   # ... and its 3x3x3 neighbourhood
+    assert torch.isfinite(yc[0, 3, 3, 0]).all()       # far away: untouched
+    # an all-zero weight row keeps its output channel at the bias
+    w2 = w.clone()
+    w2[7] = 0
+    y, _ = ops.conv3d_f8(_ndhwc(_rand((1, cin) + size, 5), dev), ops.pack_weights_f8(w2.to(dev), PACK_FWD), cout, 1, bias=b.to(dev))
+    assert torch.equal(y[..., 7].float().cpu(), b[7].to(torch.bfloat16).float().expand(1, *size))
