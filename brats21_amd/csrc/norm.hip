@@ -544,7 +544,8 @@ DEVI float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 template <typename T>
 __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
-                                   int zpitch, float* __restrict__ chansum, int voxels, int C, int groups) {
+                                   int zpitch, float* __restrict__ chansum, int voxels, int C, int groups,
+                                   uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];  // sc[C] = rstd*gamma, be[C], then reduction scratch
   float* sc = sm;
@@ -558,6 +559,7 @@ __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const fl
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
   float acc[VW];
+  float mx = 0.f;
 #pragma unroll
   for (int j = 0; j < VW; ++j) acc[j] = 0.f;
   if (myvl < vl_n) {
@@ -571,9 +573,14 @@ __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const fl
         a[j] = a[j] * sigmoidf_(a[j]) * sc[c0 + j] + be[c0 + j];
         acc[j] += a[j];
       }
+      if (amax) {
+#pragma unroll
+        for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a[j])), __builtin_fabsf(a[j + 1]));
+      }
       Vec<T, VW>::store(zb + vox * zpitch + c0, a);
     }
   }
+  if (amax) record_absmax<T>(mx, amax);
   if (chansum) {
     float* scr = sm + 2 * C;  // [vl_n][C]
     __syncthreads();
@@ -598,7 +605,7 @@ extern "C" size_t brats_chan_ws_floats(int N, int C, int vals) { return (size_t)
 
 extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
                                  void* z, int zpitch, float* chansum, int dtype, int N, int voxels, int C, int groups,
-                                 brats_stream_t s) {
+                                 float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !z || !mean_rstd || !gamma || !beta || C % vw || C % groups || xpitch % vw || zpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_fwd: bad argument (C, pitches multiples of %d)", vw);
@@ -609,10 +616,10 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
   const size_t lds = (size_t)(2 * C + vl * C) * sizeof(float);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(evonorm_fwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
-                       (bf16_t*)z, zpitch, chansum, voxels, C, groups);
+                       (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
   else
     hipLaunchKernelGGL(evonorm_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, mean_rstd, gamma, beta,
-                       (float*)z, zpitch, chansum, voxels, C, groups);
+                       (float*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
   if (chansum) brats_ordered_sum(chansum + (size_t)N * C, chansum, (int)grid.x, N * C, st);
   BRATS_CHECK_LAUNCH();
   return 0;
@@ -685,7 +692,8 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                          const float* __restrict__ red, T* __restrict__ dx, int dxpitch,
                                          float* __restrict__ dgamma, float* __restrict__ dbeta, const double* __restrict__ chan,
-                                         float* __restrict__ dconvbias, int N, int voxels, int C, int groups) {
+                                         float* __restrict__ dconvbias, int N, int voxels, int C, int groups,
+                                         uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   float* gr = sm;          // [C] gamma * r
@@ -724,13 +732,14 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
   __syncthreads();
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
-  if (myvl >= vl_n) return;
+  const bool live = myvl < vl_n;  // idle threads stay for the |max| reduction
   float cg[VW], cm[VW], ck[VW];  // per-channel constants in registers (not re-read from LDS per element)
 #pragma unroll
   for (int j = 0; j < VW; ++j) { cg[j] = gr[c0 + j]; cm[j] = mu[c0 + j]; ck[j] = kk[c0 + j]; }
   const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
   const T* xb = x + (size_t)n * voxels * xpitch + c0;
   T* dxb = dx + (size_t)n * voxels * dxpitch + c0;
+  float mx = 0.f;
   auto body = [&](const float* g, const float* xx, float* o) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
@@ -738,9 +747,13 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
       const float dnum = sg * (1.f + xx[j] * (1.f - sg));
       o[j] = g[j] * cg[j] * dnum - ck[j] * (xx[j] - cm[j]);
     }
+    if (amax) {
+#pragma unroll
+      for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
+    }
   };
   const size_t stride = (size_t)gridDim.x * vl_n;
-  size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+  size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float g0[VW], x0[VW], g1[VW], x1[VW], o0[VW], o1[VW];
     Vec<T, VW>::load(dzb + vox * dzpitch, g0);
@@ -759,12 +772,13 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
     body(g0, x0, o0);
     Vec<T, VW>::store(dxb + vox * dxpitch, o0);
   }
+  if (amax) record_absmax<T>(mx, amax);
 }
 
 extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
                                  const float* gamma, void* dx, int dxpitch, float* red, float* dgamma, float* dbeta,
                                  const double* chan_sums, float* dconvbias, int dtype, int N, int voxels, int C, int groups,
-                                 brats_stream_t s) {
+                                 float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !x || !dx || !red || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: null pointer");
   if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: dconvbias needs the forward per-channel sums");
@@ -782,13 +796,13 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
                        xpitch, red, voxels, C);
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups);
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax);
   } else {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)x,
                        xpitch, red, voxels, C);
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
-                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups);
+                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax);
   }
   BRATS_CHECK_LAUNCH();
   return 0;
@@ -883,7 +897,7 @@ extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int b
 // dst[v][c] = a[v][c]*sa[n][c] (+ b[v][c]*sb[n][c]) (+ add[n][c])  -- SE scale / residual and their backward
 template <typename T>
 __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const float* __restrict__ sa, const float* __restrict__ add,
-                                     T* __restrict__ dst, int dpitch, int voxels, int C) {
+                                     T* __restrict__ dst, int dpitch, int voxels, int C, uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];  // sa[C], add[C]
   const int n = blockIdx.y;
@@ -894,20 +908,25 @@ __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const 
   __syncthreads();
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
-  if (myvl >= vl_n) return;
+  const bool live = myvl < vl_n;
+  float mx = 0.f;
   float cs[VW], ca[VW];
 #pragma unroll
   for (int j = 0; j < VW; ++j) { cs[j] = sm[c0 + j]; ca[j] = sm[C + c0 + j]; }
   const T* ab = a + (size_t)n * voxels * apitch + c0;
   T* db = dst + (size_t)n * voxels * dpitch + c0;
   const size_t stride = (size_t)gridDim.x * vl_n;
-  size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+  size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float x0[VW], x1[VW];
     Vec<T, VW>::load(ab + vox * apitch, x0);
     Vec<T, VW>::load(ab + (vox + stride) * apitch, x1);
 #pragma unroll
     for (int j = 0; j < VW; ++j) { x0[j] = x0[j] * cs[j] + ca[j]; x1[j] = x1[j] * cs[j] + ca[j]; }
+    if (amax) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(x0[j])), __builtin_fabsf(x1[j]));
+    }
     Vec<T, VW>::store(db + vox * dpitch, x0);
     Vec<T, VW>::store(db + (vox + stride) * dpitch, x1);
   }
@@ -916,21 +935,26 @@ __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const 
     Vec<T, VW>::load(ab + vox * apitch, x0);
 #pragma unroll
     for (int j = 0; j < VW; ++j) x0[j] = x0[j] * cs[j] + ca[j];
+    if (amax) {
+#pragma unroll
+      for (int j = 0; j < VW; ++j) mx = __builtin_fmaxf(mx, __builtin_fabsf(x0[j]));
+    }
     Vec<T, VW>::store(db + vox * dpitch, x0);
   }
+  if (amax) record_absmax<T>(mx, amax);
 }
 
 extern "C" int brats_channel_scale(const void* a, int apitch, const float* scale, const float* add, void* dst, int dpitch,
-                                   int dtype, int N, int voxels, int C, brats_stream_t s) {
+                                   int dtype, int N, int voxels, int C, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!a || !scale || !dst || C % vw || apitch % vw || dpitch % vw) BRATS_FAIL(BRATS_E_ARG, "channel_scale: bad argument");
   dim3 grid(stream_grid((size_t)voxels * (C / vw), 256), N);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)a, apitch,
-                       scale, add, (bf16_t*)dst, dpitch, voxels, C);
+                       scale, add, (bf16_t*)dst, dpitch, voxels, C, (uint32_t*)amax);
   else
     hipLaunchKernelGGL(channel_scale_kernel<float>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const float*)a, apitch,
-                       scale, add, (float*)dst, dpitch, voxels, C);
+                       scale, add, (float*)dst, dpitch, voxels, C, (uint32_t*)amax);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

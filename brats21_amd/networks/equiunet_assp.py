@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .._lib import PACK_DGRAD, PACK_FWD, BratsHipError
-from .equiunet import _ConvParams
+from .equiunet import _AmaxSlots, _ConvParams, _inherit_amax
 
 
 # ------------------------------------------------------------------------------------------ parameter holders
@@ -77,11 +77,19 @@ class _Ctx:
 
     def __init__(self, model, dtype):
         self.m, self.dtype = model, dtype
-        # e4m3 convolutions (EquiUnet.conv_fp8 semantics).  The EvoNorm / SE kernels do not record the |max| of their
-        # outputs yet, so every fp8 convolution here pays one extra read pass (ops.absmax) for its scale.
+        # e4m3 convolutions (EquiUnet.conv_fp8 semantics): the EvoNorm / SE kernels record the |max| of what they write
+        # into slots taken here; a tensor without a recorded |max| falls back to ops.absmax inside ops.conv3d_f8
         self.fp8 = getattr(model, "conv_fp8", None) if dtype == torch.bfloat16 else None
+        self.slots = None
         self.names = {p: i for i, p in enumerate(model.parameters())}
         self.grads = {}
+
+    def slot(self, device):
+        if not self.fp8:
+            return None
+        if self.slots is None or self.slots.i >= self.slots.buf.numel():
+            self.slots = _AmaxSlots(64, device)
+        return self.slots.take()
 
     def put(self, param, grad):
         i = self.names[param]
@@ -102,7 +110,8 @@ def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
         return y, stats, ("col", col, dil)
     if cx.fp8 and k == 3 and ops.conv_f8_chunk(x.shape[-1]) > 0:
         wpk = ops.pack_weights_f8(w, PACK_FWD, cin_pad=x.shape[-1])
-        y, stats = ops.conv3d_f8(x, wpk, cout, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
+        y, stats = ops.conv3d_f8(x, wpk, cout, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats,
+                                 amax=getattr(x, "_amax", None))
         return y, stats, ("direct", x, dil)
     wpk = ops.pack_weights(w, cx.dtype, PACK_FWD, cin_pad=x.shape[-1], dil=dil)
     y, stats = ops.conv3d(x, wpk, cout, k, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
@@ -133,7 +142,7 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     if not need_dx:
         return None
     if cx.fp8 == "all" and k == 3 and ops.conv_f8_chunk(cout) > 0:
-        dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil)
+        dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil, amax=getattr(dy, "_amax", None))
         return dx
     dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil)
     return dx
@@ -143,13 +152,19 @@ def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
     y, stats, saved = _conv_any_fwd(cx, conv, x, 1, True)
     n, d, h, w, c = y.shape
     mr, chan = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
-    z, cs = ops.evonorm(y, mr, _flat(evo.gamma), _flat(evo.beta), 8, out=out, want_chansum=want_chansum)
+    amax = cx.slot(y.device)
+    z, cs = ops.evonorm(y, mr, _flat(evo.gamma), _flat(evo.beta), 8, out=out, want_chansum=want_chansum, amax=amax)
+    if amax is not None:
+        z._amax = amax
     return z, cs, (conv, evo, saved, y, mr, chan)
 
 
 def _conv_evo_bwd(cx, rec, dz, need_dx=True):
     conv, evo, saved, y, mr, chan = rec
-    dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan)
+    amax = cx.slot(y.device) if (cx.fp8 == "all" and need_dx) else None
+    dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax)
+    if amax is not None:
+        dy._amax = amax
     cx.put(evo.gamma, dgamma)
     cx.put(evo.beta, dbeta)
     return _conv_any_bwd(cx, conv, saved, dy, need_dx, db=dcb)
@@ -165,7 +180,10 @@ def _block_fwd(cx, blk, x, out=None):
     with torch.enable_grad(), torch.autocast("cuda", enabled=False):  # [N, C] GEMVs stay f32
         gap = (cs / float(d * h * w)).detach().requires_grad_(True)
         gate = torch.sigmoid(F.linear(F.relu(F.linear(gap, fc1.weight, fc1.bias)), fc2.weight, fc2.bias))
-    o = ops.channel_scale(z2, (1.0 + gate.detach()), out=out)
+    amax = cx.slot(z2.device)
+    o = ops.channel_scale(z2, (1.0 + gate.detach()), out=out, amax=amax)
+    if amax is not None:
+        o._amax = amax
     return o, (blk, r1, r2, z2, gap, gate)
 
 
@@ -193,11 +211,18 @@ class _AsspFn(torch.autograd.Function):
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
+        def pool(t):  # max and average of a 2x2x2 cell never exceed the |max| of the input
+            return _inherit_amax(ops.maxpool2(t, with_avg=True), t)
+
+        def cat_amax(cat, a, b):  # a concat buffer written by two producers: |max| = the larger of theirs
+            if cx.fp8 and hasattr(a, "_amax") and hasattr(b, "_amax"):
+                cat._amax = torch.maximum(a._amax, b._amax)
+
         # encoder (networks/equiunet2021.py:291-298)
         down1, rb1 = _block_fwd(cx, m.encoder1, x0)
-        down2, rb2 = _block_fwd(cx, m.encoder2, ops.maxpool2(down1, with_avg=True))
-        down3, rb3 = _block_fwd(cx, m.encoder3, ops.maxpool2(down2, with_avg=True))
-        down4, rb4 = _block_fwd(cx, m.encoder4, ops.maxpool2(down3, with_avg=True))
+        down2, rb2 = _block_fwd(cx, m.encoder2, pool(down1))
+        down3, rb3 = _block_fwd(cx, m.encoder3, pool(down2))
+        down4, rb4 = _block_fwd(cx, m.encoder4, pool(down3))
         # ASPP (:299, :187-189): the four branches write into channel slices of one buffer
         q4 = f[3] // 4
         acat = ops.new_act(n, d // 8, h // 8, w // 8, f[3], dtype, dev)
@@ -210,17 +235,20 @@ class _AsspFn(torch.autograd.Function):
         cat1 = ops.new_act(n, d, h, w, 2 * h0, dtype, dev)
         cat2 = ops.new_act(n, d // 2, h // 2, w // 2, 2 * h1, dtype, dev)
         cat3 = ops.new_act(n, d // 4, h // 4, w // 4, 2 * h2, dtype, dev)
-        _, _, rbr1 = _conv_evo_fwd(cx, m.bridge1.conv, m.bridge1.evo, down1, out=cat1[..., :h0])
-        _, _, rbr2 = _conv_evo_fwd(cx, m.bridge2.conv, m.bridge2.evo, down2, out=cat2[..., :h1])
-        _, _, rbr3 = _conv_evo_fwd(cx, m.bridge3.conv, m.bridge3.evo, down3, out=cat3[..., :h2])
+        br1, _, rbr1 = _conv_evo_fwd(cx, m.bridge1.conv, m.bridge1.evo, down1, out=cat1[..., :h0])
+        br2, _, rbr2 = _conv_evo_fwd(cx, m.bridge2.conv, m.bridge2.evo, down2, out=cat2[..., :h1])
+        br3, _, rbr3 = _conv_evo_fwd(cx, m.bridge3.conv, m.bridge3.evo, down3, out=cat3[..., :h2])
         uc3, _, ru3 = _conv_evo_fwd(cx, m.upconv3.conv, m.upconv3.evo, assp)
         ops.upsample(uc3, 2, out=cat3[..., h2:])
+        cat_amax(cat3, br3, uc3)
         up3, rd3 = _block_fwd(cx, m.decoder3, cat3)
         uc2, _, ru2 = _conv_evo_fwd(cx, m.upconv2.conv, m.upconv2.evo, up3)
         ops.upsample(uc2, 2, out=cat2[..., h1:])
+        cat_amax(cat2, br2, uc2)
         up2, rd2 = _block_fwd(cx, m.decoder2, cat2)
         uc1, _, ru1 = _conv_evo_fwd(cx, m.upconv1.conv, m.upconv1.evo, up2)
         ops.upsample(uc1, 2, out=cat1[..., h0:])
+        cat_amax(cat1, br1, uc1)
         up1, rd1 = _block_fwd(cx, m.decoder1, cat1)
         outs = [ops.head(up1, m.out_conv.weight, m.out_conv.bias, 1)]
         heads = [(m.out_conv, up1, 1)]

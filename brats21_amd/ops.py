@@ -459,7 +459,7 @@ def evonorm_finalize(stats, n, c, groups, voxels, eps=1e-5):
     return mean_rstd, chan
 
 
-def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False):
+def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False, amax=None):
     """z = y*sigmoid(y) * rstd_g * gamma + beta; optionally also sum_v z per (n, c) (SE's pooling)."""
     ptr, c, p = _desc(y)
     n, d, h, w, _ = y.shape
@@ -469,11 +469,11 @@ def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False):
     cs = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 1), dtype=torch.float32, device=y.device) if want_chansum else None
     _lib.check(_lib.lib().brats_evonorm_fwd(ptr, p, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), optr, op,
                                             cs.data_ptr() if cs is not None else None, _code(y.dtype), n, d * h * w, c,
-                                            groups, _stream()), "evonorm_fwd")
+                                            groups, _f32(amax), _stream()), "evonorm_fwd")
     return out, (cs[:n * c].view(n, c) if cs is not None else None)
 
 
-def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None):
+def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None, amax=None):
     """Returns (dy, dgamma, dbeta, dconvbias|None); dconvbias = sum_v dy needs the forward's `chan` sums."""
     dzp, c, dzpitch = _desc(dz)
     yp, _, ypitch = _desc(y)
@@ -487,7 +487,7 @@ def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None):
                                             red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                             chan.data_ptr() if chan is not None else None,
                                             dcb.data_ptr() if dcb is not None else None, _code(y.dtype), n,
-                                            d * h * w, c, groups, _stream()), "evonorm_bwd")
+                                            d * h * w, c, groups, _f32(amax), _stream()), "evonorm_bwd")
     return dy, dgamma, dbeta, dcb
 
 
@@ -504,7 +504,7 @@ def channel_dot(a, b=None):
     return out[:n * c].view(n, c)
 
 
-def channel_scale(a, scale, add=None, out=None):
+def channel_scale(a, scale, add=None, out=None, amax=None):
     """out[v][c] = a[v][c] * scale[n][c] (+ add[n][c])."""
     ap, c, apitch = _desc(a)
     n, d, h, w, _ = a.shape
@@ -512,7 +512,7 @@ def channel_scale(a, scale, add=None, out=None):
         out = new_act(n, d, h, w, c, a.dtype, a.device)
     optr, _, op = _desc(out)
     _lib.check(_lib.lib().brats_channel_scale(ap, apitch, _f32(scale.contiguous()), _f32(add.contiguous()) if add is not None else None,
-                                              optr, op, _code(a.dtype), n, d * h * w, c, _stream()), "channel_scale")
+                                              optr, op, _code(a.dtype), n, d * h * w, c, _f32(amax), _stream()), "channel_scale")
     return out
 
 

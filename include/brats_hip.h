@@ -148,19 +148,22 @@ int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int 
                            brats_stream_t s);
 int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma,
                       const float* beta, void* z, int zpitch, float* chansum, int dtype, int N,
-                      int voxels, int C, int groups, brats_stream_t s);
+                      int voxels, int C, int groups,
+                      float* amax /* optional, zero before the call: receives max|z| */, brats_stream_t s);
 /* chan_sums = the f64 [N][C][2] per-channel sums brats_evonorm_finalize left in chan_ws; with it the
  * kernel also emits dconvbias[c] = sum_v dx (bias gradient of the producing conv) at no extra pass. */
 int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
                       const float* gamma, void* dx, int dxpitch, float* red /*[N][C][3]*/,
                       float* dgamma, float* dbeta, const double* chan_sums, float* dconvbias,
-                      int dtype, int N, int voxels, int C, int groups, brats_stream_t s);
+                      int dtype, int N, int voxels, int C, int groups,
+                      float* amax /* optional, zero before the call: receives max|dx| */, brats_stream_t s);
 /* ---- squeeze-excite helpers (MONAI ResidualSELayer, equiunet2021.py:204-205): per-(n,channel)
  * reductions over voxels and per-(n,channel) scale(+add) passes; the two tiny FC layers stay in torch. */
 int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,
                       int dtype, int N, int voxels, int C, brats_stream_t s);
 int brats_channel_scale(const void* a, int apitch, const float* scale /*[N][C]*/, const float* add /*[N][C] or NULL*/,
-                        void* dst, int dpitch, int dtype, int N, int voxels, int C, brats_stream_t s);
+                        void* dst, int dpitch, int dtype, int N, int voxels, int C,
+                        float* amax /* optional, zero before the call: receives max|dst| */, brats_stream_t s);
 /* ---- im2col / col2im for dilations whose halo does not fit LDS (ASPP d = 4, 6, equiunet2021.py:257-259):
  * col [N][D*H*W][27*C] dense; the dilated conv becomes brats_conv3d_fwd(ksize = 1) over 27*C channels. */
 int brats_im2col3(const void* x, int xpitch, void* col, int dtype, int N, int C, int D, int H, int W,
