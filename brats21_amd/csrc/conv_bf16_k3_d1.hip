@@ -2,9 +2,17 @@
 // take the ping-pong persistent kernel of conv_igemm_pp.hpp
 #include <stdlib.h>
 #include "conv_igemm_pp.hpp"
+#include "conv_igemm_vsp.hpp"
 template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream_t st) {
   if (ck == 48) {
     const int rc = conv_try_pp<48>(p, st);
+    if (rc >= 0) return rc;
+  }
+  // Cout = 48 (mod 96) layers with many tiles: the persistent y-split kernel (conv_igemm_vsp.hpp)
+  if (p.rows16 % 3 == 0 && p.rows16 % 6 != 0 && conv_vsplit_enabled()) {
+    int rc = -1;
+    if (ck == 48) rc = conv_try_vsp<48, 1, 3>(p, st);
+    else if (ck == 32) rc = conv_try_vsp<32, 1, 3>(p, st);
     if (rc >= 0) return rc;
   }
   switch (ck) {

@@ -19,6 +19,13 @@ extern "C" int brats_conv3d_set_pingpong(int mode) {
   return old;
 }
 
+int g_conv_persist_mode = -1;
+extern "C" int brats_conv3d_set_persistent(int mode) {
+  const int old = g_conv_persist_mode;
+  g_conv_persist_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  return old;
+}
+
 // ---- chunk selection ---------------------------------------------------------------------------
 extern "C" int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2) {
   (void)ksize; (void)dil;

@@ -88,10 +88,12 @@ constexpr int conv_lds_bytes() {
 // pressure): the weight fragments of step k+1 are requested from L2 before the MFMAs of step k, and the
 // 8 activation fragments are read from LDS in two halves so that 4 ds_read_b128 are always in flight
 // behind 12 MFMAs.
+struct ConvNoHook { template <int K> DEVI void operator()(std::integral_constant<int, K>) const {} };
+
 template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */, int BAR = 0 /* s_barriers embedded at 1/3 and 2/3 (conv_igemm_pp.hpp) */,
-          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */>
+          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */, typename Hook = ConvNoHook>
 DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
-                         int lane, f32x4 (&acc)[NF][NB]) {
+                         int lane, f32x4 (&acc)[NF][NB], Hook&& hook = Hook{} /* called once per macro-step, before its weight loads */) {
   constexpr int YB = NB / 2;
   using G = ConvGeom<T, KS, CK, DIL>;
   constexpr int FOZ = G::HY * G::HX * G::S;  // one z-slice
@@ -127,7 +129,17 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
 #pragma unroll
       for (int i = YB * half; i < YB * half + YB; ++i)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
+        for (int f = 0; f < NF; ++f) {
+          if constexpr (std::is_same<typename std::decay<Hook>::type, ConvNoHook>::value) {
+            acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
+          } else {
+            // persistent kernel: accumulate in place.  With the builtin the allocator gives every MFMA a fresh
+            // destination (92 registers for 48 accumulators), which does not fit beside the prefetch registers.
+            f32x4& c_ = acc[f][i];
+            const bf16x8 a_ = a[k % (WD + 1)][f], b_ = b[i];
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c_) : "v"(a_), "v"(b_));
+          }
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -137,6 +149,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       constexpr int k = k_;
       // sched_barrier(0) pins the issue order: without it hipcc sinks every load to just before its
       // first use (one live B fragment, weights waited for at vmcnt(0)) and the loop runs latency-bound
+      hook(k_);
       if constexpr (k + WD < NSTEP) load_a(std::integral_constant<int, k + WD>{});
       read_b(k_, I1{});
       __builtin_amdgcn_sched_barrier(0);

@@ -70,6 +70,11 @@ int brats_conv3d_split_granule(int cout);
  * faster yet), 0 = one tile per workgroup, -1 = default (0, or the BRATS_CONV_PP environment
  * variable).  Both families compute the same values; returns the previous setting. */
 int brats_conv3d_set_pingpong(int mode);
+/* Kernel selection of the bf16 3x3x3 layers with 48 (mod 96) output channels and >= 2048 tiles: 1 = the persistent
+ * y-split kernel (a workgroup walks a tile list and fetches the next halo tile while the MFMAs of the current one run),
+ * 0 = one tile per workgroup, -1 = default (0, or the BRATS_CONV_PERSIST environment variable; the persistent form is an
+ * experiment that is not faster yet).  Both compute bit-identical results; returns the previous setting. */
+int brats_conv3d_set_persistent(int mode);
 /* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
  * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2
  * as two dense tensors in one launch. */

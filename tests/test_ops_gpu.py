@@ -413,3 +413,32 @@ def test_groupnorm_other_activations_fwd_bwd(dtype, act):
     torch.testing.assert_close(_from_ndhwc(dy), yr.grad, atol=_tol(dtype, 5e-5, 5e-2), rtol=_tol(dtype, 1e-4, 5e-2))
     torch.testing.assert_close(dgamma.cpu(), gr.grad, atol=_tol(dtype, 2e-3, 0.15), rtol=_tol(dtype, 1e-4, 2e-2))
     torch.testing.assert_close(dbeta.cpu(), br.grad, atol=_tol(dtype, 2e-3, 0.15), rtol=_tol(dtype, 1e-4, 2e-2))
+
+
+@pytest.mark.parametrize("cin,cin2,cout,n,size", [
+    (48, 0, 48, 2, (64, 64, 64)),     # 4096 tiles, one chunk
+    (48, 48, 48, 1, (68, 64, 72)),    # two-source (two chunks per tile), ragged tiles in z and x
+    (96, 0, 144, 1, (48, 48, 64)),    # three cout blocks share the tile list, two chunks
+])
+def test_conv3d_persistent_kernel_matches_one_tile_kernel(cin, cin2, cout, n, size):
+    """The persistent y-split kernel (conv_igemm_vsp.hpp) keeps the accumulation and reduction orders of the one-tile
+    kernel: outputs and tile statistics must be bit-identical; the one-tile kernel itself is checked against torch in
+    test_conv3d_fwd_dgrad_wgrad / test_conv3d_full_size_layer_vs_torch."""
+    from brats21_amd import ops, _lib
+    dev = _dev()
+    dt = torch.bfloat16
+    x = _to_ndhwc(_rand((n, cin) + size, 21), dt, dev)
+    x2 = _to_ndhwc(_rand((n, cin2) + size, 22), dt, dev) if cin2 else None
+    w = _rand((cout, cin + cin2, 3, 3, 3), 23, 0.05).to(dev)
+    b = _rand((cout,), 24, 0.1).to(dev)
+    wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
+    lib = _lib.lib()
+    old = lib.brats_conv3d_set_persistent(0)
+    try:
+        y0, s0 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
+        lib.brats_conv3d_set_persistent(1)
+        y1, s1 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
+    finally:
+        lib.brats_conv3d_set_persistent(old)
+    assert torch.equal(y0, y1)
+    assert torch.equal(s0, s1)
