@@ -5,7 +5,7 @@
 //     [128, 256) -- the instruction does not saturate, > 464 becomes NaN, scripts/probes/fp8.hip).  The LDS halo tile
 //     is half the bf16 size (CK bytes per voxel);
 //   * weights are packed as e4m3 with one power-of-two scale per GEMM row (output channel);
-//   * the MMA is v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 per instruction, block scales fixed at 2^0): 2x the bf16
+//   * the MMA is v_mfma_f32_16x16x128_f8f6f4 (the MX instruction with K = 128, block scales 2^0): 2x the bf16
 //     MFMA rate.  Lane (q, v) feeds row/voxel v with K elements 32q..32q+31 = two 16-channel "units" (one
 //     ds_read_b128 each); which (tap, channel) a K element means is free as long as A and B agree;
 //   * epilogue: acc * (2^e * wscale[cout]) + bias, then exactly the bf16 epilogue (statistics, NDHWC store).
@@ -123,7 +123,9 @@ DEVI void conv_f8_mma_chunk(const char* ldsb, int lane_b, int q, __amdgpu_buffer
       __builtin_amdgcn_sched_barrier(0);
       static_for<0, NB>([&](auto i_) {
         constexpr int i = i_;
-        acc[f][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[k % AB][f], b[i], acc[f][i], 0, 0, 0, 127, 0, 127);
+        // constant-zero scale operands select the unscaled v_mfma_f32_16x16x128_f8f6f4 (= block scales 2^0, checked in
+        // scripts/probes/fp8.hip; 32.0 instead of 33.5 cycles per MFMA and no scale VGPR, scripts/probes/mfma_rate.hip)
+        acc[f][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[k % AB][f], b[i], acc[f][i], 0, 0, 0, 0, 0, 0);
         if constexpr (f == NF - 1 && k + 1 < NSTEP) {
           read_b(i_);
           __builtin_amdgcn_sched_barrier(0);

@@ -18,10 +18,11 @@ __global__ void cvt_kernel(const unsigned* src, unsigned* dst, float scale, int 
   r = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(r, v, scale, false);
   dst[i] = __builtin_bit_cast(unsigned, r);
 }
+template <int SCALE>  // 127 = 2^0 block scales in a VGPR; 0 = hipcc selects the unscaled v_mfma_f32_16x16x128_f8f6f4
 __global__ void mfma_kernel(const i32x8* a, const i32x8* b, f32x4* c) {
   int l = threadIdx.x;
   f32x4 acc = {0, 0, 0, 0};
-  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, 0, 0, 0, 127, 0, 127);
+  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[l], b[l], acc, 0, 0, 0, SCALE, 0, SCALE);
   c[l] = acc;
 }
 static float e4m3(unsigned char b) {
@@ -62,7 +63,9 @@ int main() {
   i32x8 *da, *db; f32x4* dc; float hc[64][4];
   hipMalloc(&da, 2048); hipMalloc(&db, 2048); hipMalloc(&dc, 1024);
   hipMemcpy(da, ha, 2048, hipMemcpyHostToDevice); hipMemcpy(db, hb, 2048, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(mfma_kernel, dim3(1), dim3(64), 0, 0, da, db, dc);
+  for (int variant = 0; variant < 2; ++variant) {
+  if (variant == 0) hipLaunchKernelGGL(mfma_kernel<127>, dim3(1), dim3(64), 0, 0, da, db, dc);
+  else hipLaunchKernelGGL(mfma_kernel<0>, dim3(1), dim3(64), 0, 0, da, db, dc);
   hipMemcpy(hc, dc, 1024, hipMemcpyDeviceToHost);
   double maxerr = 0, maxref = 0;
   for (int l = 0; l < 64; ++l) for (int r = 0; r < 4; ++r) {
@@ -71,6 +74,8 @@ int main() {
     for (int k = 0; k < 128; ++k) ref += (double)e4m3(A[row][k]) * e4m3(B[col][k]);
     maxerr = fmax(maxerr, fabs(ref - hc[l][r])); maxref = fmax(maxref, fabs(ref));
   }
-  printf("mfma 16x16x128 e4m3: max |err| %g (max |ref| %g)  [D[row=4q+r][col=v] = sum_k A[row][k] B[col][k]]\n", maxerr, maxref);
+  printf("mfma 16x16x128 e4m3 (%s): max |err| %g (max |ref| %g)  [D[row=4q+r][col=v] = sum_k A[row][k] B[col][k]]\n",
+         variant == 0 ? "scales 127" : "scales 0 -> unscaled instruction", maxerr, maxref);
+  }
   return 0;
 }
