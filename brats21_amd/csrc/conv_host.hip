@@ -114,6 +114,81 @@ extern "C" int brats_conv3d_pack_weights(const float* w, void* packed, int dtype
   return 0;
 }
 
+// ---- multi-tensor packing: one launch for every layer of a network -----------------------------------------------
+static constexpr int PACK_BLOCK = 2048;  // output elements per block (8 per thread)
+template <typename T>
+DEVI void pack_one(const brats_pack_job& J, size_t idx) {
+  constexpr bool BF = std::is_same<T, bf16_t>::value;
+  constexpr int EPL = BF ? 8 : 4;
+  const int e = idx % EPL;
+  size_t t = idx / EPL;
+  const int lane = t % 64; t /= 64;
+  const int ft = t % J.rows16; t /= J.rows16;
+  const int ms = t % J.ms_n;
+  const int chunk = t / J.ms_n;
+  const int q = lane >> 4, row = ft * 16 + (lane & 15);
+  int tap, kc;
+  bool valid;
+  if (BF) {
+    const int upt = J.ck / 8, g = 4 * ms + q;
+    valid = g < J.taps * upt;
+    tap = g / upt;
+    kc = chunk * J.ck + (g % upt) * 8 + e;
+  } else {
+    const int g = 4 * (4 * ms + e) + q;
+    valid = g < J.taps * J.ck;
+    tap = g / J.ck;
+    kc = chunk * J.ck + g % J.ck;
+  }
+  float val = 0.f;
+  if (valid && row < J.rows && kc < J.kdim) {
+    // FWD: K = input channels (zero beyond cin_real); DGRAD: rows = input channels
+    if (J.mode == BRATS_PACK_FWD) { if (J.cin_off + kc < J.cin_real) val = J.w[((size_t)row * J.cin_real + J.cin_off + kc) * J.taps + tap]; }
+    else { if (J.cin_off + row < J.cin_real) val = J.w[((size_t)kc * J.cin_real + J.cin_off + row) * J.taps + (J.taps - 1 - tap)]; }
+  }
+  ((T*)J.out)[idx] = from_f<T>(val);
+}
+__global__ void __launch_bounds__(256) pack_weights_multi_kernel(const brats_pack_job* __restrict__ jobs, const int* __restrict__ blocks) {
+  const brats_pack_job J = jobs[blocks[blockIdx.x * 2]];
+  const size_t base = (size_t)blocks[blockIdx.x * 2 + 1] * PACK_BLOCK + (size_t)threadIdx.x * (PACK_BLOCK / 256);
+  if (base >= J.total) return;
+  if (J.dtype == BRATS_BF16) {
+    // a thread owns one lane's 8 elements of a fragment (= 8 consecutive K channels of one tap): index math once, one
+    // 16-byte store
+    size_t t = base / 8;
+    const int lane = t % 64; t /= 64;
+    const int ft = t % J.rows16; t /= J.rows16;
+    const int ms = t % J.ms_n;
+    const int chunk = t / J.ms_n;
+    const int q = lane >> 4, row = ft * 16 + (lane & 15);
+    const int upt = J.ck / 8, g = 4 * ms + q;
+    const int tap = g / upt, kc0 = chunk * J.ck + (g % upt) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kc = kc0 + e;
+      float val = 0.f;
+      if (g < J.taps * upt && row < J.rows && kc < J.kdim) {
+        if (J.mode == BRATS_PACK_FWD) { if (J.cin_off + kc < J.cin_real) val = J.w[((size_t)row * J.cin_real + J.cin_off + kc) * J.taps + tap]; }
+        else { if (J.cin_off + row < J.cin_real) val = J.w[((size_t)kc * J.cin_real + J.cin_off + row) * J.taps + (J.taps - 1 - tap)]; }
+      }
+      v[e] = val;
+    }
+    Vec<bf16_t, 8>::store((bf16_t*)J.out + base, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PACK_BLOCK / 256; ++i)
+      if (base + i < J.total) pack_one<float>(J, base + i);
+  }
+}
+extern "C" int brats_conv3d_pack_block(void) { return PACK_BLOCK; }
+extern "C" int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* blocks, int nblocks, brats_stream_t s) {
+  if (!jobs || !blocks || nblocks <= 0) BRATS_FAIL(BRATS_E_ARG, "pack_weights_multi: empty job / block table");
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)s, jobs, blocks);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- forward / dgrad ---------------------------------------------------------------------------
 extern "C" int brats_conv3d_split_granule(int cout) { return conv_choose_tile(ceil_div(cout, 16)).nf * 16; }
 

@@ -8,6 +8,8 @@ One autograd node; explicit forward / backward programs over NDHWC activations (
 """
 import warnings
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -204,6 +206,18 @@ def _block_bwd(cx, rec, do, need_dx=True):
 class _AsspFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, dtype, *params):
+        # training: the module packed all layers' weights up front (ops.plan_for); pack_weights() then returns views
+        ctx.plan = ops._PLANS.get(model) if (model.training and model.pack_plan) else None
+        with ops.use_plan(ctx.plan):
+            return _AsspFn._forward(ctx, model, x, dtype, *params)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        with ops.use_plan(ctx.plan):
+            return _AsspFn._backward(ctx, *douts)
+
+    @staticmethod
+    def _forward(ctx, model, x, dtype, *params):
         m = model
         f = m.features
         cx = _Ctx(m, dtype)
@@ -263,7 +277,7 @@ class _AsspFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, *douts):
+    def _backward(ctx, *douts):
         cx, R = ctx.cx, ctx.recs
         m = cx.m
         f = m.features
@@ -327,6 +341,7 @@ class EquiUnetASSPEvo(nn.Module):
         self.features = list(features)
         self.precision = "auto"
         self.conv_fp8 = None  # None | "fwd" | "all": e4m3 kernel for the 3x3x3 convolutions (see EquiUnet.conv_fp8)
+        self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "1") != "0"  # training: one multi-tensor weight-packing launch per step (ops.PackPlan)
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None
         f = self.features
@@ -362,6 +377,8 @@ class EquiUnetASSPEvo(nn.Module):
             raise BratsHipError("brats21_amd.EquiUnetASSPEvo runs on the GPU only (no CPU fallback)")
         if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
             raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
+        if self.training and self.pack_plan and torch.is_grad_enabled():
+            ops.plan_for(self, x.device)  # all layers' weights (forward + dgrad layouts) packed by one launch
         outs = _AsspFn.apply(self, x.float(), self._dtype(), *tuple(self.parameters()))
         if self.deep_supervision:
             return outs[0], list(outs[1:])

@@ -5,8 +5,10 @@ torch.float32; a tensor may be a channel-slice *view* of a wider buffer (pitch =
 is how torch.cat (networks/equiunet2020.py:478-486 of the reference) is removed.  PyTorch is only
 the allocator / stream provider here; every arithmetic op is a HIP kernel of the library.
 """
+import contextlib
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -132,6 +134,108 @@ def conv_chunk(dtype, ksize, dil, c1, c2=0):
 _PACK_CACHE = {}  # inference only: packed weights keyed by (tensor object, layout arguments), validated by version counter
 
 
+_PACK_JOB = np.dtype([("w", "<u8"), ("out", "<u8"), ("dtype", "<i4"), ("mode", "<i4"), ("taps", "<i4"), ("cin_w", "<i4"),
+                      ("cin_real", "<i4"), ("cin_off", "<i4"), ("rows", "<i4"), ("rows16", "<i4"), ("kdim", "<i4"), ("ck", "<i4"),
+                      ("ms_n", "<i4"), ("reserved", "<i4"), ("total", "<u8")])  # == brats_pack_job (include/brats_hip.h)
+
+
+class PackPlan:
+    """Every packed-weight buffer a training step needs (each layer: forward and dgrad layout) as views of ONE allocation,
+    filled by ONE launch per step (brats_conv3d_pack_weights_multi) instead of one ~9 us launch per layer and layout.
+
+    The first step runs the ordinary per-layer path and records what was asked for; ``run()`` (called by the module at the
+    start of a training forward) then builds the tables once and re-packs everything each step.  ``pack_weights`` hands
+    out a view only while the parameter is the same object, at the same address, with the version counter ``run()`` saw;
+    anything else falls back to the per-layer path (and is added to the plan)."""
+
+    def __init__(self):
+        self.recorded = {}   # key -> (weakref(w), args)
+        self.entries = None  # key -> [weakref(w), data_ptr, offset, nbytes, version]
+        self.dirty = True
+
+    def record(self, key, w, args):
+        if isinstance(w, torch.nn.Parameter) and key not in self.recorded:  # (temporaries would never hit again)
+            self.recorded[key] = (weakref.ref(w), args)
+            self.dirty = True
+
+    def _build(self, device):
+        jobs, blocks, entries, off = [], [], {}, 0
+        pb = _lib.lib().brats_conv3d_pack_block()
+        for key, (wref, (dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1)) in self.recorded.items():
+            w = wref()
+            if w is None or w.dtype != torch.float32 or not w.is_contiguous():
+                continue
+            cout_w, cin_real, k = w.shape[0], w.shape[1], w.shape[2]
+            cin_w = cin_pad if cin_pad is not None else cin_real
+            cnt = cin_w - cin_off if cin_cnt is None else cin_cnt
+            kdim, rows = (cnt, cout_w) if mode == PACK_FWD else (cout_w, cnt)
+            ck = conv_chunk(dtype, k, dil, kdim) if (c1 is None or mode != PACK_FWD) else conv_chunk(dtype, k, dil, c1, kdim - c1)
+            code = _code(dtype)
+            nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
+            rows16 = (rows + 15) // 16
+            ms_n = nbytes // ((kdim // ck) * rows16 * 1024)
+            total = nbytes // (2 if code == BF16 else 4)
+            entries[key] = [wref, w.data_ptr(), off, nbytes, -1]
+            jobs.append((w.data_ptr(), off, code, mode, k ** 3, cin_w, cin_real, cin_off, rows, rows16, kdim, ck, ms_n, 0, total))
+            j = len(jobs) - 1
+            blocks.extend((j, b) for b in range((total + pb - 1) // pb))
+            off += (nbytes + 255) // 256 * 256
+        self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=device)
+        rec = np.array(jobs, dtype=_PACK_JOB)
+        rec["out"] += self.buf.data_ptr()
+        self.jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32, device=device).reshape(-1, 2).contiguous()
+        self.entries = entries
+        self.dirty = False
+
+    def run(self, device):
+        if not self.recorded:
+            return
+        if self.entries is not None and not self.dirty:
+            for e in self.entries.values():  # a parameter that was re-allocated (.to(), load with assign) moves: rebuild
+                w = e[0]()
+                if w is None or w.data_ptr() != e[1]:
+                    self.dirty = True
+                    break
+        if self.dirty or self.entries is None:
+            self._build(device)
+        if self.blocks.numel() == 0:
+            return
+        _lib.check(_lib.lib().brats_conv3d_pack_weights_multi(self.jobs.data_ptr(), self.blocks.data_ptr(), self.blocks.shape[0],
+                                                              _stream()), "conv3d_pack_weights_multi")
+        for e in self.entries.values():
+            e[4] = e[0]()._version
+
+    def lookup(self, key, w):
+        e = self.entries.get(key) if self.entries is not None else None
+        if e is not None and e[0]() is w and e[1] == w.data_ptr() and e[4] == w._version:
+            return self.buf[e[2]:e[2] + e[3]]
+        return None
+
+
+ACTIVE_PLAN = None  # set by the network programs around a training forward / backward
+_PLANS = weakref.WeakKeyDictionary()  # module -> PackPlan (kept off the module: deepcopy / state_dict stay plain)
+
+
+@contextlib.contextmanager
+def use_plan(plan):
+    global ACTIVE_PLAN
+    old, ACTIVE_PLAN = ACTIVE_PLAN, plan
+    try:
+        yield
+    finally:
+        ACTIVE_PLAN = old
+
+
+def plan_for(module, device):
+    """Re-pack every recorded weight of `module` (one launch) and return its plan; call at the start of a training forward."""
+    plan = _PLANS.get(module)
+    if plan is None:
+        plan = _PLANS[module] = PackPlan()
+    plan.run(device)
+    return plan
+
+
 def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c1=None):
     """w: torch-layout [Cout, Cin, k, k, k] f32 parameter -> packed MFMA-fragment buffer.
     mode PACK_FWD: GEMM rows = Cout, K = Cin (zero-padded to cin_pad); PACK_DGRAD: rows = Cin slice,
@@ -141,6 +245,12 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c
     packed buffer is cached; the key carries the tensor's version counter, which every in-place update bumps
     (optimizer steps incl. brats21_amd.optim.Ranger2020, load_state_dict, SWA averaging)."""
     key = None
+    if ACTIVE_PLAN is not None:
+        pkey = (id(w), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
+        v = ACTIVE_PLAN.lookup(pkey, w)
+        if v is not None:
+            return v
+        ACTIVE_PLAN.record(pkey, w, (dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1))
     if not torch.is_grad_enabled():
         # keyed by the tensor OBJECT (weak reference: a new tensor that reuses a freed address must not hit) and its
         # version counter

@@ -62,6 +62,20 @@ int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2);
  * [cin_off, cin_off+cin_cnt).  DGRAD: GEMM rows = Cin_w slice, K = Cout_w, taps flipped. */
 int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize,
                               int cout_w, int cin_w, int cin_off, int cin_cnt, int ck, brats_stream_t s);
+/* All weight tensors of a network in ONE launch (a training step re-packs every layer twice, forward and dgrad layout:
+ * 34 launches of ~9 us for EquiUnet).  jobs / blocks are device arrays the caller builds once: job j describes one
+ * brats_conv3d_pack_weights call (cin_real < cin_w: input channels >= cin_real are zero padding that is not present in
+ * w, whose channel pitch is cin_real); blocks[b] = {job, block index inside the job}; a block packs
+ * brats_conv3d_pack_block() consecutive output elements. */
+typedef struct {
+  const float* w;
+  void* out;
+  int dtype, mode, taps, cin_w, cin_real, cin_off, rows, rows16, kdim, ck, ms_n, reserved;
+  unsigned long long total; /* output elements of this job */
+} brats_pack_job;
+int brats_conv3d_pack_block(void);
+int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* blocks /* [nblocks][2] */, int nblocks,
+                                    brats_stream_t s);
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
 /* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
 int brats_conv3d_split_granule(int cout);

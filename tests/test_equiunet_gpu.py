@@ -261,3 +261,50 @@ def test_other_activations_f32_network_vs_oracle(golden_dir, act):
         g = _golden(golden_dir, "equiunet_w8_16_elu.npz")
         assert np.abs(out.detach().cpu().numpy() - g["logits"]).max() < LOGIT_ATOL
         assert abs(loss.item() - float(g["loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
+def test_multi_tensor_weight_packing_is_transparent(name):
+    """ops.PackPlan (one packing launch per training step) must not change a single bit: three optimizer steps with and
+    without it, from the same initial weights; the plan must follow in-place updates (version counters) and survive
+    deepcopy / load_state_dict of the module."""
+    import argparse, contextlib, copy, io
+    from brats21_amd import get_model, synth, ops
+    from brats21_amd.losses import DiceLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ns = argparse.Namespace(model=name, width=16, norm="group", act="relu", num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = get_model(ns).to(dev).train()
+    x = synth.random_image(2, 4, (32, 32, 32), seed=5, device=dev)
+    t = synth.nested_spheres(2, (32, 32, 32), device=dev)
+    crit = DiceLoss().to(dev)
+
+    def run(plan):
+        model = copy.deepcopy(base)
+        model.pack_plan = plan
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out, deep = model(x)
+            loss = crit(out.float(), t) + sum(crit(d.float(), t) for d in deep)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses, [p.detach().clone() for p in model.parameters()], model
+
+    l0, p0, _ = run(False)
+    l1, p1, m1 = run(True)
+    assert l0 == l1
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    plan = ops._PLANS.get(m1)
+    assert plan is not None and plan.entries and all(e[4] >= 0 for e in plan.entries.values())  # the plan was really used
+    # load_state_dict copies in place (same storage, new version): the next step must see the new weights
+    m1.load_state_dict(base.state_dict())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out1, _ = m1(x)
+        base.pack_plan = False
+        out0, _ = base(x)
+    assert torch.equal(out0, out1)
