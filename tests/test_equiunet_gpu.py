@@ -308,3 +308,41 @@ def test_multi_tensor_weight_packing_is_transparent(name):
         base.pack_plan = False
         out0, _ = base(x)
     assert torch.equal(out0, out1)
+
+
+@pytest.mark.parametrize("width", [32, 64])
+def test_equiunet_other_widths_f32_vs_oracle(width):
+    """Widths other than the flagship 48 take other channel chunks / tile roles (32-channel chunks, 2-fragment cout tiles,
+    K-split in f32; BASELINE.json configs[4] names width 64): logits, loss and gradients against the oracle in the
+    exact-f32 mode, and the bf16 mode (y-split / cout-split roles) bounded against it."""
+    from brats21_amd import get_model
+    import contextlib
+    import io
+    torch.manual_seed(2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = get_model(argparse.Namespace(model="equiunet", width=width, norm="group", act="relu", num_classes=3, dropout=0)).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    size = (16, 16, 32)
+    x, t = synth.random_image(1, 4, size, seed=4), synth.nested_spheres(1, size)
+    m.precision = "fp32"
+    out, deeps = m(x.cuda())
+    loss = unet.deep_supervision_loss((out, deeps), t.cuda())
+    loss.backward()
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = unet.equiunet_forward(sd_ref, x)
+    loss_ref = unet.deep_supervision_loss(out_ref, t)
+    loss_ref.backward()
+    assert float((out.detach().cpu() - out_ref[0].detach()).abs().max()) < LOGIT_ATOL
+    assert abs(loss.item() - loss_ref.item()) < 1e-4
+    worst = max(float((p.grad.cpu() - sd_ref[k].grad).norm() / (sd_ref[k].grad.norm() + 1e-12)) for k, p in m.named_parameters())
+    assert worst < 5e-3, worst
+    m.precision = "bf16"
+    m.zero_grad()
+    out16, deeps16 = m(x.cuda())
+    dev = (out16.float().cpu() - out_ref[0].detach()).abs()
+    scale = float(out_ref[0].detach().abs().max())
+    assert float(dev.max()) < 0.15 * scale + 0.3, (float(dev.max()), scale)
+    unet.deep_supervision_loss((out16.float(), [d.float() for d in deeps16]), t.cuda()).backward()
+    g16 = torch.cat([p.grad.flatten().cpu() for p in m.parameters()])
+    gref = torch.cat([sd_ref[k].grad.flatten() for k, _ in m.named_parameters()])
+    assert float(torch.nn.functional.cosine_similarity(g16, gref, dim=0)) > 0.98
