@@ -3,7 +3,9 @@
 #include <stdlib.h>
 #include "conv_igemm_pp.hpp"
 #include "conv_igemm_vsp.hpp"
+#include "conv_igemm_vs8.hpp"
 template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream_t st) {
+  if (ck == 24) return conv_launch_vs8<24, 1, 3>(p, st);  // brats_conv3d_chunk() hands out 24 only for the layers of that kernel
   if (ck == 48) {
     const int rc = conv_try_pp<48>(p, st);
     if (rc >= 0) return rc;

@@ -27,8 +27,25 @@ extern "C" int brats_conv3d_set_persistent(int mode) {
 }
 
 // ---- chunk selection ---------------------------------------------------------------------------
-extern "C" int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2) {
-  (void)ksize; (void)dil;
+int g_conv_vs8_mode = -1;
+extern "C" int brats_conv3d_set_vs8(int mode) {
+  const int old = g_conv_vs8_mode;
+  g_conv_vs8_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  return old;
+}
+static int conv_vs8_enabled() {
+  if (g_conv_vs8_mode >= 0) return g_conv_vs8_mode;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BRATS_CONV_VS8"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+extern "C" int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2, int cout) {
+  // Cout = 48 (mod 96), bf16, 3x3x3 dilation 1: 24-channel chunks for the 4x8x16-tile kernel (conv_igemm_vs8.hpp)
+  if (dtype == BRATS_BF16 && ksize == 3 && dil == 1 && cout > 0 && conv_vs8_enabled() && conv_vsplit_enabled()) {
+    const int rows16 = ceil_div(cout, 16);
+    if (rows16 % 3 == 0 && rows16 % 6 != 0 && c1 % 24 == 0 && (c2 <= 0 || c2 % 24 == 0)) return 24;
+  }
   static int pref16 = -1;  // experiment switch: smaller K chunks -> smaller LDS tile -> more workgroups per CU
   if (pref16 < 0) { const char* e = getenv("BRATS_CONV_CK16"); pref16 = e ? atoi(e) : 0; }
   if (pref16 && dtype == BRATS_BF16 && c1 % 16 == 0 && (c2 <= 0 || c2 % 16 == 0)) return 16;
@@ -213,7 +230,7 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
     if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
       BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
   }
-  const int ck = brats_conv3d_chunk(dtype, ksize, dil, c1, c2);
+  const int ck = brats_conv3d_chunk(dtype, ksize, dil, c1, c2, cout);
   if (!ck) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: no channel chunk divides c1=%d c2=%d", c1, c2);
   ConvParams p;
   p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;

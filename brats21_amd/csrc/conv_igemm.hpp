@@ -28,20 +28,23 @@ struct ConvParams {
 
 constexpr int CONV_TZ = 4, CONV_TY = 4, CONV_TX = 16;  // a voxel fragment = one x-row of 16
 
-template <typename T, int KS, int CK, int DIL>
+template <typename T, int KS, int CK, int DIL, int TY = CONV_TY /* tile rows in y: 8 for conv_igemm_vs8.hpp */>
 struct ConvGeom {
   static constexpr bool BF = std::is_same<T, bf16_t>::value;
   static constexpr int ESZ = sizeof(T);
   static constexpr int EPL = 16 / ESZ;  // elements per 16-byte lane fragment
   static constexpr int R = (KS == 3) ? DIL : 0;
-  static constexpr int HZ = CONV_TZ + 2 * R, HY = CONV_TY + 2 * R, HX = CONV_TX + 2 * R;
+  static constexpr int HZ = CONV_TZ + 2 * R, HY = TY + 2 * R, HX = CONV_TX + 2 * R;
   static constexpr int HVOX = HZ * HY * HX;
   static constexpr int ROWB = CK * ESZ;
   static constexpr int PPV = ROWB / 16;
   // voxel stride in LDS.  bf16: a fragment's 16 voxels are 16 consecutive x, so ds_read_b128 is
   // bank-conflict-free iff (S/16) % 4 == 2 (32, 96, 160 B ...; CK=48 -> 96 B = no padding at all).
   // f32 (ds_read_b32 operands, parity mode): odd number of 16-B slots (2-way at worst).
-  static constexpr int S = BF ? 16 * (PPV + ((2 - PPV % 4) + 4) % 4) : ((PPV % 2 == 0) ? ROWB + 16 : ROWB);
+  // (ds_read_b128 serves 8 lanes per cycle, so any odd number of 16-byte slots is conflict-free as well -- measured
+  // with the 48-byte stride of the e4m3 kernel; only the 24-channel chunks of conv_igemm_vs8.hpp use that here, the
+  // tuned kernels keep their strides)
+  static constexpr int S = (BF && PPV == 3) ? 48 : BF ? 16 * (PPV + ((2 - PPV % 4) + 4) % 4) : ((PPV % 2 == 0) ? ROWB + 16 : ROWB);
   static constexpr int NPIECE = HVOX * PPV;
   static constexpr int NITER = (NPIECE + 255) / 256;
   static constexpr int TAPS = KS * KS * KS;
@@ -91,11 +94,12 @@ constexpr int conv_lds_bytes() {
 struct ConvNoHook { template <int K> DEVI void operator()(std::integral_constant<int, K>) const {} };
 
 template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */, int BAR = 0 /* s_barriers embedded at 1/3 and 2/3 (conv_igemm_pp.hpp) */,
-          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */, typename Hook = ConvNoHook>
+          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */, typename Hook = ConvNoHook,
+          typename GEOM = ConvGeom<T, KS, CK, DIL>>
 DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
                          int lane, f32x4 (&acc)[NF][NB], Hook&& hook = Hook{} /* called once per macro-step, before its weight loads */) {
   constexpr int YB = NB / 2;
-  using G = ConvGeom<T, KS, CK, DIL>;
+  using G = GEOM;
   constexpr int FOZ = G::HY * G::HX * G::S;  // one z-slice
   constexpr int NSTEP = PARITY < 0 ? G::MS : (G::MS - PARITY + 1) / 2;
   if constexpr (G::BF) {

@@ -1,0 +1,229 @@
+// y-split implicit-GEMM kernel on a 4 x 8 x 16 voxel tile (bf16, 3x3x3, dilation 1, Cout = 48 mod 96): twice the
+// voxels of conv_igemm_kernel's tile per workgroup, so that what a tile costs besides its MFMAs -- kernel prologue, the
+// round trip of the halo loads, barriers, the drain of the epilogue's stores: ~40 % of the one-tile kernel by ablation
+// -- is paid half as often, and the halo amplification drops from 2.53x to 2.11x.  To keep two workgroups per CU the
+// K chunk is 24 channels (LDS tile 6 x 10 x 18 voxels x 48 B = 52 KB; 48 B is a conflict-free stride for
+// ds_read_b128).  Roles: all four waves compute the same NF*16 couts over all of K; wave (wm, wn) owns z-slices
+// 2wm, 2wm+1 and y-rows 4wn..4wn+3 = 8 voxel fragments (acc: NF x 8 x 4 registers).  Statistics are written per
+// 4 x 4 x 16 sub-tile (the y-half of a wave pair), i.e. in the layout every consumer already reads.
+#pragma once
+#include "conv_igemm.hpp"
+
+constexpr int VS8_TY = 8;
+
+template <int CK, int DIL, int NF>
+constexpr int conv_vs8_lds_bytes() {
+  using G = ConvGeom<bf16_t, 3, CK, DIL, VS8_TY>;
+  return (G::LDS_TILE + 15) / 16 * 16 + 4 * NF * 16 * 2 * 4;
+}
+
+template <int CK, int DIL, int NF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
+  using T = bf16_t;
+  using G = ConvGeom<T, 3, CK, DIL, VS8_TY>;
+  constexpr int NB = 8, YB = 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int q = lane >> 4, v = lane & 15;
+
+  int bt = blockIdx.x;
+  const int txi = bt % p.tx; bt /= p.tx;
+  const int tyi = bt % p.ty; bt /= p.ty;  // p.ty counts 8-row tiles here
+  const int tzi = bt % p.tz;
+  const int n = bt / p.tz;
+  const int z0 = tzi * CONV_TZ, y0 = tyi * VS8_TY, x0 = txi * CONV_TX;
+  const int ct = blockIdx.y;
+  const int f0 = ct * NF;
+  const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+
+  constexpr int NROWS = G::HZ * G::HY;
+  constexpr int PPR = G::HX * G::PPV;
+  constexpr int IPR = (PPR + 63) / 64;
+  constexpr int RPW = (NROWS + 3) / 4;
+  int lds_off[IPR];
+  int hx_part[IPR];
+#pragma unroll
+  for (int j = 0; j < IPR; ++j) {
+    const int pc = lane + 64 * j;
+    const int hx = pc / G::PPV, part = pc % G::PPV;
+    const int gx = x0 - G::R + hx;
+    const bool ok = pc < PPR && gx >= 0 && gx < p.W;
+    hx_part[j] = ok ? (hx << 16) | part : -1;
+    lds_off[j] = pc < PPR ? wave * (G::HX * G::S) + hx * G::S + part * 16 : -1;
+  }
+
+  f32x4 acc[NF][NB];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lane_b = ((wm * 2) * G::HY * G::HX + wn * YB * G::HX + v) * G::S + q * G::UB;
+  const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;
+
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int c0 = chunk * CK;
+    const T* src;
+    int pitch;
+    if (c0 < p.c1) { src = (const T*)p.x1 + c0; pitch = p.p1; }
+    else { src = (const T*)p.x2 + (c0 - p.c1); pitch = p.p2; }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(src + sample_vox * pitch), (short)0, (int)((size_t)p.D * p.H * p.W * pitch * 2), 0x00020000);
+    const int pb = pitch * 2;
+    int goff[IPR];
+#pragma unroll
+    for (int j = 0; j < IPR; ++j) goff[j] = (hx_part[j] >> 16) * pb + (hx_part[j] & 0xffff) * 16;
+    u32x4 r[RPW][IPR];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int row = wave + 4 * k;
+      const int hz = row / G::HY, hy = row % G::HY;
+      const int gz = z0 - G::R + hz, gy = y0 - G::R + hy;
+      const bool row_ok = row < NROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
+      const int rb = ((gz * p.H + gy) * p.W + (x0 - G::R)) * pb;
+#pragma unroll
+      for (int j = 0; j < IPR; ++j) {
+        const int vo = (row_ok && hx_part[j] >= 0) ? rb + goff[j] : -1;
+        r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+      }
+    }
+    if (chunk > 0) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      if (wave + 4 * k < NROWS) {
+#pragma unroll
+        for (int j = 0; j < IPR; ++j)
+          if (lds_off[j] >= 0) *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = r[k][j];
+      }
+    }
+    __syncthreads();
+    const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
+    conv_mma_chunk<T, 3, CK, DIL, NF, -1, 0, NB, ConvNoHook, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+  }
+
+  // --- epilogue: bias, statistics per 4x4x16 sub-tile, NDHWC store ---
+  constexpr int LDS_MAIN = (G::LDS_TILE + 15) / 16 * 16;
+  float* sred = (float*)(lds + LDS_MAIN);  // [4 (wm + 2 wn)][NF*16][2]
+  {
+    const bool x_ok = x0 + v < p.W;
+    const bool second = p.y2 != nullptr && f0 * 16 >= p.ysplit;
+    T* const ydst = second ? (T*)p.y2 : (T*)p.y;
+    const int ypit = second ? p.y2pitch : p.ypitch;
+    const int csub = second ? p.ysplit : 0;
+    const int lane_o = (x0 + v) * ypit + 4 * q - csub;
+    float bias[NF][4], s1[NF][4], s2[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int cbase = (f0 + f) * 16 + 4 * q;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        bias[f][rr] = (p.bias && cbase < p.cout) ? p.bias[cbase + rr] : 0.f;
+        s1[f][rr] = 0.f;
+        s2[f][rr] = 0.f;
+      }
+    }
+    const bool full = z0 + CONV_TZ <= p.D && y0 + VS8_TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * NF * 16 <= p.cout;
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
+        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          float o[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            o[rr] = acc[f][i][rr] + bias[f][rr];
+            s1[f][rr] += o[rr];
+            s2[f][rr] += o[rr] * o[rr];
+          }
+          Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
+        const bool ok = z < p.D && y < p.H && x_ok;
+        const float mk = ok ? 1.f : 0.f;
+        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bool cok = (f0 + f) * 16 + 4 * q < p.cout;
+          const float mf = cok ? mk : 0.f;
+          float o[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            o[rr] = acc[f][i][rr] + bias[f][rr];
+            const float om = o[rr] * mf;
+            s1[f][rr] += om;
+            s2[f][rr] += om * o[rr];
+          }
+          if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
+        }
+      }
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          s1[f][rr] = row16_sum(s1[f][rr]);
+          s2[f][rr] = row16_sum(s2[f][rr]);
+        }
+        if (v == 0) {
+          const int cl = f * 16 + 4 * q;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 0] = s1[f][rr];
+            sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 1] = s2[f][rr];
+          }
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    if (tid < 2 * NF * 16) {  // one 4x4x16 statistics entry per y-half (wn)
+      const int half = tid / (NF * 16), cl = tid % (NF * 16);
+      const int c = ct * NF * 16 + cl;
+      const int ty_i = tyi * 2 + half;
+      if (c < p.cout && ty_i < ty4) {
+        const size_t tps = (size_t)p.tz * ty4 * p.tx;
+        const size_t tile = ((size_t)tzi * ty4 + ty_i) * p.tx + txi;
+        float* dst = p.stats + (((size_t)n * tps + tile) * p.cout + c) * 2;
+        dst[0] = sred[((2 * half) * NF * 16 + cl) * 2] + sred[((2 * half + 1) * NF * 16 + cl) * 2];
+        dst[1] = sred[((2 * half) * NF * 16 + cl) * 2 + 1] + sred[((2 * half + 1) * NF * 16 + cl) * 2 + 1];
+      }
+    }
+  }
+}
+
+extern int g_conv_vs8_mode;  // conv_host.hip: -1 = BRATS_CONV_VS8 (default on), 0 / 1 = brats_conv3d_set_vs8
+static inline int conv_vs8_mode() {
+  if (g_conv_vs8_mode >= 0) return g_conv_vs8_mode;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BRATS_CONV_VS8"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+template <int CK, int DIL, int NF>
+int conv_launch_vs8(const ConvParams& p0, hipStream_t st) {
+  constexpr int lds = conv_vs8_lds_bytes<CK, DIL, NF>();
+  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    attr_done = true;
+  }
+  ConvParams p = p0;
+  const int ty4 = p.ty;
+  p.ty = ceil_div(p.H, VS8_TY);
+  dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / NF));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, ty4);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}

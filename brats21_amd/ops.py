@@ -124,8 +124,9 @@ def ndhwc_to_ncdhw(x):
 
 
 # ------------------------------------------------------------------------------------------ conv
-def conv_chunk(dtype, ksize, dil, c1, c2=0):
-    ck = _lib.lib().brats_conv3d_chunk(_code(dtype), ksize, dil, c1, c2)
+def conv_chunk(dtype, ksize, dil, c1, c2=0, cout=0):
+    """K chunk of the kernel that will run a layer with c1 (+c2) input channels and `cout` GEMM rows."""
+    ck = _lib.lib().brats_conv3d_chunk(_code(dtype), ksize, dil, c1, c2, cout)
     if ck <= 0:
         raise _lib.BratsHipError(f"conv3d: no channel chunk for c1={c1} c2={c2} dtype={dtype}")
     return ck
@@ -169,7 +170,7 @@ class PackPlan:
             cin_w = cin_pad if cin_pad is not None else cin_real
             cnt = cin_w - cin_off if cin_cnt is None else cin_cnt
             kdim, rows = (cnt, cout_w) if mode == PACK_FWD else (cout_w, cnt)
-            ck = conv_chunk(dtype, k, dil, kdim) if (c1 is None or mode != PACK_FWD) else conv_chunk(dtype, k, dil, c1, kdim - c1)
+            ck = conv_chunk(dtype, k, dil, kdim, 0, rows) if (c1 is None or mode != PACK_FWD) else conv_chunk(dtype, k, dil, c1, kdim - c1, rows)
             code = _code(dtype)
             nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
             rows16 = (rows + 15) // 16
@@ -281,7 +282,7 @@ def _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1):
     else:
         kdim, rows = cout_w, cin_cnt
     # the K chunk must be the one the kernel will pick for the (possibly two-source) input it reads
-    ck = conv_chunk(dtype, k, dil, kdim) if (c1 is None or mode != PACK_FWD) else conv_chunk(dtype, k, dil, c1, kdim - c1)
+    ck = conv_chunk(dtype, k, dil, kdim, 0, rows) if (c1 is None or mode != PACK_FWD) else conv_chunk(dtype, k, dil, c1, kdim - c1, rows)
     nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
     packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     _lib.check(_lib.lib().brats_conv3d_pack_weights(w.data_ptr(), packed.data_ptr(), code, mode, k, cout_w, cin_w,

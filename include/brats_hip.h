@@ -56,8 +56,9 @@ int brats_ndhwc_to_ncdhw(const void* src, int src_pitch, float* dst, int dtype, 
 enum { BRATS_PACK_FWD = 0, BRATS_PACK_DGRAD = 1 };
 /* bytes of the packed-weight buffer for a conv with `cin` (GEMM-K) and `cout` (GEMM-M) channels */
 size_t brats_conv3d_packed_bytes(int dtype, int ksize, int cin, int cout, int ck);
-/* channel chunk the kernel will use for an input made of c1 (+c2) channels; 0 = unsupported */
-int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2);
+/* channel chunk the kernel will use for an input made of c1 (+c2) channels and `cout` GEMM rows (output channels; for
+ * the dgrad layout the input channels of the layer); 0 = unsupported */
+int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2, int cout);
 /* w: [Cout_w][Cin_w][k][k][k] f32 (torch layout).  FWD: GEMM rows = Cout_w, K = Cin_w slice
  * [cin_off, cin_off+cin_cnt).  DGRAD: GEMM rows = Cin_w slice, K = Cout_w, taps flipped. */
 int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize,
@@ -89,6 +90,11 @@ int brats_conv3d_set_pingpong(int mode);
  * 0 = one tile per workgroup, -1 = default (0, or the BRATS_CONV_PERSIST environment variable; the persistent form is an
  * experiment that is not faster yet).  Both compute bit-identical results; returns the previous setting. */
 int brats_conv3d_set_persistent(int mode);
+/* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
+ * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (1, or BRATS_CONV_VS8).  The setting
+ * changes brats_conv3d_chunk(), i.e. the packed-weight layout: weights must be packed under the same setting they are
+ * used with.  Returns the previous setting. */
+int brats_conv3d_set_vs8(int mode);
 /* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
  * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2
  * as two dense tensors in one launch. */

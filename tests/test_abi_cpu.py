@@ -21,13 +21,19 @@ def test_library_exports_every_declared_symbol():
 def test_host_side_queries_and_argument_errors():
     l = _lib.lib()
     # chunk selection: width-48 layers use 48-channel chunks in bf16, 16 in f32; first layer 8 / 4
-    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 48, 0) == 48
-    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 96, 0) == 48
-    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 8, 0) == 8
-    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 64, 0) == 32
-    assert l.brats_conv3d_chunk(_lib.F32, 3, 1, 48, 0) == 16
-    assert l.brats_conv3d_chunk(_lib.F32, 3, 1, 4, 0) == 4
-    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 12, 0) == 0
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 48, 0, 0) == 48
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 96, 0, 96) == 48
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 8, 0, 48) == 8
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 64, 0, 64) == 32
+    assert l.brats_conv3d_chunk(_lib.F32, 3, 1, 48, 0, 48) == 16
+    assert l.brats_conv3d_chunk(_lib.F32, 3, 1, 4, 0, 48) == 4
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 12, 0, 0) == 0
+    # layers with 48 (mod 96) output channels: 24-channel chunks for the 4x8x16-tile kernel, unless switched off
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 48, 48, 48) == 24
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 2, 48, 0, 48) == 48
+    old = l.brats_conv3d_set_vs8(0)
+    assert l.brats_conv3d_chunk(_lib.BF16, 3, 1, 48, 48, 48) == 48
+    l.brats_conv3d_set_vs8(old)
     assert l.brats_conv3d_tiles_per_sample(128, 128, 128) == 32 * 16 * 16
     assert l.brats_conv3d_tiles_per_sample(4, 4, 4) == 1
     # packed size: chunks * macro-steps * cout16 * 64 lanes * 16 B

@@ -263,17 +263,21 @@ def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, sp
     x2 = torch.randn((n, *size, cin2), generator=g).to(dev).to(dt) if cin2 else None
     w = torch.randn((cout, cin + cin2, 3, 3, 3), generator=g) * (2.0 / ((cin + cin2) * 27)) ** 0.5
     bias = torch.randn(cout, generator=g).to(dev)
-    wpk = ops.pack_weights(w.to(dev), dt, ops.PACK_FWD, c1=cin if cin2 else None)
     lib = _lib.lib()
+    old8 = lib.brats_conv3d_set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
     res = {}
-    for mode in (0, 1):
-        old = lib.brats_conv3d_set_pingpong(mode)
-        try:
-            y, st = ops.conv3d(x, wpk, cout, 3, 1, bias=bias, want_stats=True, x2=x2, split=split)
-            torch.cuda.synchronize()
-        finally:
-            lib.brats_conv3d_set_pingpong(old)
-        res[mode] = (y, st)
+    try:
+        wpk = ops.pack_weights(w.to(dev), dt, ops.PACK_FWD, c1=cin if cin2 else None)
+        for mode in (0, 1):
+            old = lib.brats_conv3d_set_pingpong(mode)
+            try:
+                y, st = ops.conv3d(x, wpk, cout, 3, 1, bias=bias, want_stats=True, x2=x2, split=split)
+                torch.cuda.synchronize()
+            finally:
+                lib.brats_conv3d_set_pingpong(old)
+            res[mode] = (y, st)
+    finally:
+        lib.brats_conv3d_set_vs8(old8)
     ya, yb = res[0][0], res[1][0]
     # cout 96 / 192: both kernels run the same MFMA order -> bit-identical.  cout 48: the tile kernel accumulates all of
     # K in one chain (y-split roles), the ping-pong kernel adds two K-parity partial sums -> equal up to one bf16 ulp.
@@ -431,14 +435,50 @@ def test_conv3d_persistent_kernel_matches_one_tile_kernel(cin, cin2, cout, n, si
     x2 = _to_ndhwc(_rand((n, cin2) + size, 22), dt, dev) if cin2 else None
     w = _rand((cout, cin + cin2, 3, 3, 3), 23, 0.05).to(dev)
     b = _rand((cout,), 24, 0.1).to(dev)
-    wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
     lib = _lib.lib()
+    old8 = lib.brats_conv3d_set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
     old = lib.brats_conv3d_set_persistent(0)
     try:
+        wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
         y0, s0 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
         lib.brats_conv3d_set_persistent(1)
         y1, s1 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
     finally:
         lib.brats_conv3d_set_persistent(old)
+        lib.brats_conv3d_set_vs8(old8)
     assert torch.equal(y0, y1)
     assert torch.equal(s0, s1)
+
+
+@pytest.mark.parametrize("cin,cin2,cout,n,size", [
+    (48, 0, 48, 2, (32, 32, 32)),     # interior tiles
+    (48, 48, 48, 1, (12, 20, 40)),    # two-source input, ragged tiles in z, y (20 = 2.5 tiles of 8 rows) and x
+    (96, 0, 144, 1, (8, 12, 16)),     # three cout blocks, four 24-channel chunks, y = 1.5 tiles
+])
+def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size):
+    """The 4x8x16-tile kernel (24-channel chunks, conv_igemm_vs8.hpp) against the 4x4x16-tile kernel (48-channel chunks):
+    same products in f32, a different summation order over K, so the bf16 outputs differ by at most one rounding step
+    of the result; the tile statistics (f32, taken before that rounding) agree to 1e-5 relative."""
+    from brats21_amd import ops, _lib
+    dev = _dev()
+    dt = torch.bfloat16
+    x = _to_ndhwc(_rand((n, cin) + size, 31), dt, dev)
+    x2 = _to_ndhwc(_rand((n, cin2) + size, 32), dt, dev) if cin2 else None
+    w = _rand((cout, cin + cin2, 3, 3, 3), 33, 0.05).to(dev)
+    b = _rand((cout,), 34, 0.1).to(dev)
+    lib = _lib.lib()
+    old = lib.brats_conv3d_set_vs8(0)
+    try:
+        wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
+        y0, s0 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
+        lib.brats_conv3d_set_vs8(1)
+        wpk8 = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
+        assert wpk8.numel() != wpk.numel() or not torch.equal(wpk8, wpk)  # really the other layout
+        y1, s1 = ops.conv3d(x, wpk8, cout, 3, 1, bias=b, want_stats=True, x2=x2)
+    finally:
+        lib.brats_conv3d_set_vs8(old)
+    err = (y0.float() - y1.float()).abs().max().item()
+    assert err <= y0.float().abs().max().item() * 2 ** -7, err
+    t0, t1 = s0.sum(1), s1.sum(1)   # [n, cout, 2]: per-tile entries may be dealt differently only at ragged edges
+    assert torch.allclose(t0, t1, rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-3)  # and each 4x4x16 entry holds the same voxels
