@@ -2,10 +2,14 @@
 // voxels of conv_igemm_kernel's tile per workgroup, so that what a tile costs besides its MFMAs -- kernel prologue, the
 // round trip of the halo loads, barriers, the drain of the epilogue's stores: ~40 % of the one-tile kernel by ablation
 // -- is paid half as often, and the halo amplification drops from 2.53x to 2.11x.  To keep two workgroups per CU the
-// K chunk is 24 channels (LDS tile 6 x 10 x 18 voxels x 48 B = 52 KB; 48 B is a conflict-free stride for
-// ds_read_b128).  Roles: all four waves compute the same NF*16 couts over all of K; wave (wm, wn) owns z-slices
+// K chunk is 24 channels (LDS tile 6 x 10 x 18 voxels x 48 B = 52 KB; the 48-byte voxel stride costs LDS bank
+// conflicts -- SQ_LDS_BANK_CONFLICT ratio 0.45 against 0.01 at 96 B -- which the kernel can afford: it is not LDS-bound).  Roles: all four waves compute the same NF*16 couts over all of K; wave (wm, wn) owns z-slices
 // 2wm, 2wm+1 and y-rows 4wn..4wn+3 = 8 voxel fragments (acc: NF x 8 x 4 registers).  Statistics are written per
 // 4 x 4 x 16 sub-tile (the y-half of a wave pair), i.e. in the layout every consumer already reads.
+// Tried on top, not kept: touching the next chunk's half of the voxel rows early (L2 prefetch by inline-asm loads into a
+// scratch register quad): -0.4 % once correct.  A first version let the compiler reuse the scratch registers while the
+// loads were still in flight -- the data landed in live registers, the network produced NaNs, and NaN-filled tensors
+// made every kernel of the step faster (a fake 8 % "speed-up"): compare loss values, not only times, in an A/B.
 #pragma once
 #include "conv_igemm.hpp"
 
@@ -17,7 +21,7 @@ constexpr int conv_vs8_lds_bytes() {
   return (G::LDS_TILE + 15) / 16 * 16 + 4 * NF * 16 * 2 * 4;
 }
 
-template <int CK, int DIL, int NF, bool PREFETCH = true>
+template <int CK, int DIL, int NF>
 __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
   using T = bf16_t;
   using G = ConvGeom<T, 3, CK, DIL, VS8_TY>;
@@ -87,28 +91,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
       for (int j = 0; j < IPR; ++j) {
         const int vo = (row_ok && hx_part[j] >= 0) ? rb + goff[j] : -1;
         r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
-      }
-    }
-    // L2 prefetch of the NEXT chunk's half of the same 96-byte voxel rows: with 24-channel chunks the two halves of a
-    // 128-byte line are wanted ~1 us apart, and by then the line had often left the XCD's L2 (HBM fetch 1.8 GB per
-    // launch instead of 0.9, L2 hit 0.67).  Loads into one scratch register quad by inline asm: the compiler's vmcnt
-    // bookkeeping does not see them, which can only make its waits more conservative; nothing reads the register.
-    if (PREFETCH && c0 + CK < (c0 < p.c1 ? p.c1 : p.c1 + p.c2)) {
-      const uintptr_t base = (uintptr_t)(src + sample_vox * pitch);
-      const u32x4 desc = {(uint32_t)base, (uint32_t)(base >> 32) & 0xffffu, (uint32_t)((size_t)p.D * p.H * p.W * pitch * 2), 0x00020000u};
-      u32x4 scratch;
-#pragma unroll
-      for (int k = 0; k < RPW; ++k) {
-        const int row = wave + 4 * k;
-        const int hz = row / G::HY, hy = row % G::HY;
-        const int gz = z0 - G::R + hz, gy = y0 - G::R + hy;
-        const bool row_ok = row < NROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
-        const int rb = ((gz * p.H + gy) * p.W + (x0 - G::R)) * pb + CK * 2;
-#pragma unroll
-        for (int j = 0; j < IPR; ++j) {
-          const int vo = (row_ok && hx_part[j] >= 0) ? rb + goff[j] : -1;
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(scratch) : "v"(vo), "s"(desc));
-        }
       }
     }
     if (chunk > 0) __syncthreads();
