@@ -119,7 +119,7 @@ extern "C" int brats_head_fwd(const void* x, int xpitch, const float* w, const f
 
 // dx[v][c] = sum_k dlow[k][v]*w[k][c];  dw[k][c] += sum_v dlow[k][v]*x[v][c];  db[k] += sum_v dlow[k][v]
 template <typename T>
-__global__ void head_bwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ dlow,
+__global__ void __launch_bounds__(256) head_bwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ dlow,
                                 T* __restrict__ dx, int dxpitch, float* __restrict__ dw /* per-block partials */, int C, int K,
                                 size_t voxels) {
   constexpr int VW = 16 / sizeof(T);
@@ -139,24 +139,54 @@ __global__ void head_bwd_kernel(const T* __restrict__ x, int xpitch, const float
     for (int j = 0; j < VW; ++j) aw[k][j] = 0.f;
   }
   if (myvl < vl_n) {
-    const T* xb = x + (size_t)n * voxels * xpitch;
-    T* dxb = dx ? dx + (size_t)n * voxels * dxpitch : nullptr;
-    for (size_t v = (size_t)blockIdx.x * vl_n + myvl; v < voxels; v += (size_t)gridDim.x * vl_n) {
-      float a[VW], o[VW], g[HEAD_KMAX];
-      Vec<T, VW>::load(xb + v * xpitch + c0, a);
+    const T* xb = x + (size_t)n * voxels * xpitch + c0;
+    T* dxb = dx ? dx + (size_t)n * voxels * dxpitch + c0 : nullptr;
+    // the thread's channel vector is fixed: its K x VW weights live in registers (read from LDS per element the pass was
+    // LDS-bound), two voxels are in flight per iteration
+    float wr[HEAD_KMAX][VW];
+#pragma unroll
+    for (int k = 0; k < HEAD_KMAX; ++k)
+#pragma unroll
+      for (int j = 0; j < VW; ++j) wr[k][j] = k < K ? ws[k * C + c0 + j] : 0.f;
+    const float* dl = dlow + (size_t)n * K * voxels;
+    auto body = [&](const float* a, const float* g, float* o) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) o[j] = 0.f;
 #pragma unroll
       for (int k = 0; k < HEAD_KMAX; ++k) {
-        g[k] = k < K ? dlow[((size_t)n * K + k) * voxels + v] : 0.f;
         ab[k] += g[k];
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
           aw[k][j] += g[k] * a[j];
-          if (k < K) o[j] += g[k] * ws[k * C + c0 + j];
+          o[j] += g[k] * wr[k][j];
         }
       }
-      if (dxb) Vec<T, VW>::store(dxb + v * dxpitch + c0, o);
+    };
+    const size_t stride = (size_t)gridDim.x * vl_n;
+    size_t v = (size_t)blockIdx.x * vl_n + myvl;
+    for (; v + stride < voxels; v += 2 * stride) {
+      float a0[VW], a1[VW], o0[VW], o1[VW], g0[HEAD_KMAX], g1[HEAD_KMAX];
+      Vec<T, VW>::load(xb + v * xpitch, a0);
+      Vec<T, VW>::load(xb + (v + stride) * xpitch, a1);
+#pragma unroll
+      for (int k = 0; k < HEAD_KMAX; ++k) {
+        g0[k] = k < K ? dl[(size_t)k * voxels + v] : 0.f;
+        g1[k] = k < K ? dl[(size_t)k * voxels + v + stride] : 0.f;
+      }
+      body(a0, g0, o0);
+      body(a1, g1, o1);
+      if (dxb) {
+        Vec<T, VW>::store(dxb + v * dxpitch, o0);
+        Vec<T, VW>::store(dxb + (v + stride) * dxpitch, o1);
+      }
+    }
+    if (v < voxels) {
+      float a0[VW], o0[VW], g0[HEAD_KMAX];
+      Vec<T, VW>::load(xb + v * xpitch, a0);
+#pragma unroll
+      for (int k = 0; k < HEAD_KMAX; ++k) g0[k] = k < K ? dl[(size_t)k * voxels + v] : 0.f;
+      body(a0, g0, o0);
+      if (dxb) Vec<T, VW>::store(dxb + v * dxpitch, o0);
     }
   }
   float* scr = sm + K * C;  // [vl_n][K][C] + [vl_n][K]
