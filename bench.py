@@ -216,13 +216,13 @@ def main():
     # timed run), so `traffic` stays null; the committed summary of those passes is quoted beside it with its source
     if roofline is not None and roofline["kernel"].startswith("conv_igemm cin=48 cout=48"):
         try:
-            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_conv.txt")
-            line = next(l for l in open(src) if "conv_igemm_kernel<unsigned short, 3, 48, 1, 3, false, true>" in l)
+            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_dominant.txt")
+            line = next(l for l in open(src) if "conv_igemm_vs8_kernel<24, 1, 3>" in l)
             import re
             fetch = float(re.search(r"fetchMB\(x2\)=\s*([0-9.]+)", line).group(1))
             write = float(re.search(r"writeMB=\s*([0-9.]+)", line).group(1))
             roofline["traffic_profiled"] = {"fetch_MB": fetch, "write_MB": write, "algorithmic_MB": round(2 * (n * d * h * w * cout * 2) / 1e6, 1),
-                                            "source": "profiles/r01_final_pmc_conv.txt (rocprofv3 --pmc, separate passes, per launch)"}
+                                            "source": "profiles/r01_final_pmc_dominant.txt (rocprofv3 --pmc, separate passes over this kernel and shape, per launch)"}
         except Exception:
             pass
     if args.kernel_table:

@@ -8,6 +8,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 be
 cp $out/stats/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 bash scripts/pmc.sh final/pmc scripts/prof_conv.py all > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc > $out/pmc_conv.txt
+bash scripts/pmc.sh final/pmc_dom scripts/prof_conv.py dom > /dev/null 2>&1
+python3 scripts/pmc_report.py final/pmc_dom > $out/pmc_dominant.txt
 python3 bench.py --steps 10 --warmup 3 --fp8 all --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_fp8.json
 python3 bench.py --steps 10 --warmup 3 --fp8 all --graph --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_fp8_graph.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_fp8 -- python3 bench.py --steps 10 --warmup 3 --fp8 all --no-infer --no-cpu-baseline > /dev/null 2>&1
