@@ -213,7 +213,8 @@ def main():
                   "families": {f: {"ms_per_step": round(v[0] / args.steps, 3), "TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                                for f, v in fam.items()}}
     # HBM traffic of the dominant kernel comes from separate --pmc passes (scripts/pmc.sh; never collected inside this
-    # timed run), so `traffic` stays null; the committed summary of those passes is quoted beside it with its source
+    # timed run): `traffic` is the committed per-launch figure of those passes for exactly this kernel and shape (null
+    # when the dominant kernel is another one), with its source beside it
     if roofline is not None and roofline["kernel"].startswith("conv_igemm cin=48 cout=48"):
         try:
             src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_dominant.txt")
@@ -221,6 +222,7 @@ def main():
             import re
             fetch = float(re.search(r"fetchMB\(x2\)=\s*([0-9.]+)", line).group(1))
             write = float(re.search(r"writeMB=\s*([0-9.]+)", line).group(1))
+            roofline["traffic"] = int((fetch + write) * 1024 * 1024)  # bytes per launch (the report prints MiB), from the committed passes
             roofline["traffic_profiled"] = {"fetch_MB": fetch, "write_MB": write, "algorithmic_MB": round(2 * (n * d * h * w * cout * 2) / 1e6, 1),
                                             "source": "profiles/r01_final_pmc_dominant.txt (rocprofv3 --pmc, separate passes over this kernel and shape, per launch)"}
         except Exception:
