@@ -6,7 +6,8 @@
 // conflicts -- SQ_LDS_BANK_CONFLICT ratio 0.45 against 0.01 at 96 B -- which the kernel can afford: it is not LDS-bound).  Roles: all four waves compute the same NF*16 couts over all of K; wave (wm, wn) owns z-slices
 // 2wm, 2wm+1 and y-rows 4wn..4wn+3 = 8 voxel fragments (acc: NF x 8 x 4 registers).  Statistics are written per
 // 4 x 4 x 16 sub-tile (the y-half of a wave pair), i.e. in the layout every consumer already reads.
-// 16-channel chunks (32-byte stride, conflict-free, three chunks per 48 channels) are slower: 0.443 vs 0.417 ms.
+// 16-channel chunks (32-byte stride, conflict-free, three chunks per 48 channels) are slower: 0.443 vs 0.417 ms; so is
+// a unit-plane layout of the 24-channel chunk ([unit][voxel][16 B], planes 80 B out of phase): 0.461 ms.
 // Tried on top, not kept: touching the next chunk's half of the voxel rows early (L2 prefetch by inline-asm loads into a
 // scratch register quad): -0.4 % once correct.  A first version let the compiler reuse the scratch registers while the
 // loads were still in flight -- the data landed in live registers, the network produced NaNs, and NaN-filled tensors
