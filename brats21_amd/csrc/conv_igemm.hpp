@@ -13,6 +13,8 @@
 // the layer has too few couts (KSPLIT), the parity of the K macro-steps (reduced through LDS).
 // Per Cin chunk (CK channels) the halo tile is staged once and all taps read it (27x reuse from
 // LDS; HBM/L2 sees only the ~2x halo amplification).  2 workgroups/CU overlap staging with MFMA.
+// Relatives: conv_igemm_vs8.hpp (y-split roles on a 4x8x16 tile, the default for bf16 layers with 48 mod 96 couts),
+// conv_igemm_f8.hpp (e4m3 operands), conv_igemm_pp.hpp / conv_igemm_vsp.hpp (persistent experiments, off by default).
 #pragma once
 #include <stdlib.h>
 #include "common.hpp"
