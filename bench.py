@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--optimizer", default="ranger", choices=["ranger", "adam"],
                     help="ranger = the reference's default (--optimizer ranger, src/arguments_train.py:120), fused HIP step")
     ap.add_argument("--use-gc", action="store_true", help="Ranger gradient centralisation (reference default: off)")
-    ap.add_argument("--sw-batch", type=int, default=3, help="sliding-window windows per forward in the inference leg")
+    ap.add_argument("--sw-batch", type=int, default=4, help="sliding-window windows per forward in the inference leg")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one hipGraph (single GPU; no per-kernel timers, so roofline is null)")
     ap.add_argument("--fp8", default=None, choices=["fwd", "all"],

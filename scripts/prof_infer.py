@@ -9,5 +9,5 @@ torch.manual_seed(0)
 ns = argparse.Namespace(model="equiunet", width=48, norm="group", act="relu", num_classes=3, dropout=0)
 with contextlib.redirect_stdout(io.StringIO()):
     model = get_model(ns).to(dev)
-args = argparse.Namespace(sw_batch=3, precision="bf16", model="equiunet")
+args = argparse.Namespace(sw_batch=4, precision="bf16", model="equiunet")
 print(bench.inference_bench(model, dev, args)["value"], "volumes/s")
