@@ -290,6 +290,17 @@ def _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1):
     return packed
 
 
+def set_vs8(mode):
+    """brats_conv3d_set_vs8 + invalidation of everything packed under the old setting (the switch changes the K chunk, i.e.
+    the packed-weight layout of the layers it applies to).  Returns the previous setting."""
+    old = _lib.lib().brats_conv3d_set_vs8(mode)
+    _PACK_CACHE.clear()
+    for plan in list(_PLANS.values()):
+        plan.dirty = True
+        plan.entries = None
+    return old
+
+
 def split_granule(cout):
     return _lib.lib().brats_conv3d_split_granule(cout)
 

@@ -93,7 +93,7 @@ int brats_conv3d_set_persistent(int mode);
 /* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
  * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (1, or BRATS_CONV_VS8).  The setting
  * changes brats_conv3d_chunk(), i.e. the packed-weight layout: weights must be packed under the same setting they are
- * used with.  Returns the previous setting. */
+ * used with (the Python side offers ops.set_vs8(), which also drops its packed-weight caches).  Returns the previous setting. */
 int brats_conv3d_set_vs8(int mode);
 /* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
  * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2

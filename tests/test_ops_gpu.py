@@ -264,7 +264,7 @@ def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, sp
     w = torch.randn((cout, cin + cin2, 3, 3, 3), generator=g) * (2.0 / ((cin + cin2) * 27)) ** 0.5
     bias = torch.randn(cout, generator=g).to(dev)
     lib = _lib.lib()
-    old8 = lib.brats_conv3d_set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
+    old8 = ops.set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
     res = {}
     try:
         wpk = ops.pack_weights(w.to(dev), dt, ops.PACK_FWD, c1=cin if cin2 else None)
@@ -277,7 +277,7 @@ def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, sp
                 lib.brats_conv3d_set_pingpong(old)
             res[mode] = (y, st)
     finally:
-        lib.brats_conv3d_set_vs8(old8)
+        ops.set_vs8(old8)
     ya, yb = res[0][0], res[1][0]
     # cout 96 / 192: both kernels run the same MFMA order -> bit-identical.  cout 48: the tile kernel accumulates all of
     # K in one chain (y-split roles), the ping-pong kernel adds two K-parity partial sums -> equal up to one bf16 ulp.
@@ -436,7 +436,7 @@ def test_conv3d_persistent_kernel_matches_one_tile_kernel(cin, cin2, cout, n, si
     w = _rand((cout, cin + cin2, 3, 3, 3), 23, 0.05).to(dev)
     b = _rand((cout,), 24, 0.1).to(dev)
     lib = _lib.lib()
-    old8 = lib.brats_conv3d_set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
+    old8 = ops.set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
     old = lib.brats_conv3d_set_persistent(0)
     try:
         wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
@@ -445,7 +445,7 @@ def test_conv3d_persistent_kernel_matches_one_tile_kernel(cin, cin2, cout, n, si
         y1, s1 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
     finally:
         lib.brats_conv3d_set_persistent(old)
-        lib.brats_conv3d_set_vs8(old8)
+        ops.set_vs8(old8)
     assert torch.equal(y0, y1)
     assert torch.equal(s0, s1)
 
@@ -467,16 +467,16 @@ def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size):
     w = _rand((cout, cin + cin2, 3, 3, 3), 33, 0.05).to(dev)
     b = _rand((cout,), 34, 0.1).to(dev)
     lib = _lib.lib()
-    old = lib.brats_conv3d_set_vs8(0)
+    old = ops.set_vs8(0)
     try:
         wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
         y0, s0 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
-        lib.brats_conv3d_set_vs8(1)
+        ops.set_vs8(1)
         wpk8 = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
         assert wpk8.numel() != wpk.numel() or not torch.equal(wpk8, wpk)  # really the other layout
         y1, s1 = ops.conv3d(x, wpk8, cout, 3, 1, bias=b, want_stats=True, x2=x2)
     finally:
-        lib.brats_conv3d_set_vs8(old)
+        ops.set_vs8(old)
     err = (y0.float() - y1.float()).abs().max().item()
     assert err <= y0.float().abs().max().item() * 2 ** -7, err
     t0, t1 = s0.sum(1), s1.sum(1)   # [n, cout, 2]: per-tile entries may be dealt differently only at ragged edges
