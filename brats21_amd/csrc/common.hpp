@@ -81,3 +81,4 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // out[i] = sum_{b < nb} part[b * total + i] in a fixed order (bitwise reproducible reductions without float atomics);
 // implemented in dice.hip
 int brats_ordered_sum(const float* part, float* out, int nb, int total, hipStream_t st);
+int brats_ordered_sum2(const float* part, float* out1, int n1, float* out2, int nb, int total, hipStream_t st);

@@ -46,7 +46,8 @@ __global__ void dice_stats_kernel(const float* __restrict__ x, const float* __re
 }
 
 // out[i] = sum over nb partial vectors, 8 entries x 32 slices per block, slices added in order
-__global__ void __launch_bounds__(256) ordered_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, int total) {
+__global__ void __launch_bounds__(256) ordered_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, int total,
+                                                          float* __restrict__ out2 /* entries >= n1 go here (may be NULL) */, int n1) {
   const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
   const int i = blockIdx.x * 8 + e;
   float s = 0.f;
@@ -60,12 +61,18 @@ __global__ void __launch_bounds__(256) ordered_sum_kernel(const float* __restric
   if (g == 0 && i < total) {
 #pragma unroll
     for (int k = 1; k < 32; ++k) s += sm[k][e];
-    out[i] = s;
+    if (out2 && i >= n1) out2[i - n1] = s;
+    else out[i] = s;
   }
 }
 
 int brats_ordered_sum(const float* part, float* out, int nb, int total, hipStream_t st) {
-  hipLaunchKernelGGL(ordered_sum_kernel, dim3((total + 7) / 8), dim3(256), 0, st, part, out, nb, total);
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3((total + 7) / 8), dim3(256), 0, st, part, out, nb, total, (float*)nullptr, 0);
+  return 0;
+}
+// the first n1 totals to out1, the rest to out2 (two result tensors, one launch, no copies)
+int brats_ordered_sum2(const float* part, float* out1, int n1, float* out2, int nb, int total, hipStream_t st) {
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3((total + 7) / 8), dim3(256), 0, st, part, out1, nb, total, out2, n1);
   return 0;
 }
 

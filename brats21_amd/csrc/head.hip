@@ -258,10 +258,8 @@ extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const f
   else
     hipLaunchKernelGGL(head_bwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, w, dlow, (float*)dx, dxpitch,
                        part, C, K, vox);
-  brats_ordered_sum(part, tot, N * (int)grid.x, K * C + K, st);
-  hipError_t e = hipMemcpyAsync(dw, tot, (size_t)K * C * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(db, tot + (size_t)K * C, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "head_bwd: copy: %s", hipGetErrorString(e));
+  (void)tot;
+  brats_ordered_sum2(part, dw, K * C, db, N * (int)grid.x, K * C + K, st);  // totals straight into dw [K][C] and db [K]
   BRATS_CHECK_LAUNCH();
   return 0;
 }
