@@ -30,31 +30,65 @@ def conv_flops(cin, cout, k, n, d, h, w):
 
 
 def cpu_baseline(width, cores):
-    """The CPU oracle (plain torch fp32 restatement of the reference's CPU path, oracle/unet.py) on a
-    bounded sample: ONE 4x64^3 patch (1/8 of the voxels of a 4x128^3 patch), forward + Dice loss +
-    backward, 1 warm-up + 5 timed repetitions, median.  Reported in the metric's unit (128^3-patches/s).
-    Threads: torch/mkldnn 3D convolutions scale to ~16 threads on this host and get SLOWER beyond
-    (measured on the GPU box, scripts/cpu_threads.py: 8 thr 0.14 s, 16 thr 0.10 s, 32 thr 0.15 s,
-    64 thr 0.43 s, 128 thr 2.1 s per 32^3 patch), so the baseline uses min(16, cores) threads."""
+    """The CPU oracle (plain torch fp32 restatement of the reference's CPU path, oracle/unet.py) timed on the GPU box's
+    host cores on a bounded sample of the bench workload: ONE real 4x128^3 patch of the width-48 network, forward + Dice
+    loss + backward (1 warm-up + 2 timed repetitions, the faster one), after 3 warm-ups + 5 timed repetitions of a 4x64^3
+    patch (1/8 of the voxels; its figure is kept beside the 128^3 one).  Reported in the metric's unit (128^3-patches/s).
+    Threads: torch/mkldnn 3D convolutions scale to ~16 threads on this host and get SLOWER beyond (measured on the GPU
+    box, scripts/cpu_threads.py: 8 thr 0.14 s, 16 thr 0.10 s, 32 thr 0.15 s, 64 thr 0.43 s, 128 thr 2.1 s per 32^3
+    patch), so the baseline uses min(16, cores) threads."""
     from oracle import synth as osynth, unet
     threads = min(16, cores)
     torch.set_num_threads(threads)
-    size = (64, 64, 64)
     sd = {k: v.requires_grad_(True) for k, v in osynth.fill_state_dict(unet.equiunet_state_shapes(width)).items()}
-    x, t = osynth.random_image(1, 4, size), osynth.nested_spheres(1, size)
-    times = []
-    for it in range(6):
-        t0 = time.perf_counter()
-        loss = unet.deep_supervision_loss(unet.equiunet_forward(sd, x), t)
-        loss.backward()
-        for v in sd.values():
-            v.grad = None
-        if it:
-            times.append(time.perf_counter() - t0)
-    sec = sorted(times)[len(times) // 2]
-    return {"value": round((1.0 / 8.0) / sec, 5), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"1 patch of 4x64^3 (=1/8 of a 4x128^3 patch), fwd+Dice+bwd fp32 torch CPU, median of 5: {sec:.2f} s; "
-                      f"host has {cores} cores, {threads} threads used (fastest setting)"}
+
+    def run(size, warm, timed):
+        x, t = osynth.random_image(1, 4, size), osynth.nested_spheres(1, size)
+        times = []
+        for it in range(warm + timed):
+            t0 = time.perf_counter()
+            loss = unet.deep_supervision_loss(unet.equiunet_forward(sd, x), t)
+            loss.backward()
+            for v in sd.values():
+                v.grad = None
+            if it >= warm:
+                times.append(time.perf_counter() - t0)
+        return times
+
+    t64 = sorted(run((64, 64, 64), 3, 5))[2]
+    t128 = min(run((128, 128, 128), 1, 2))
+    return {"value": round(1.0 / t128, 5), "unit": "patches/s", "cores": threads, "kind": "port",
+            "sample": f"1 patch of 4x128^3, fwd+Dice+bwd fp32 torch CPU (oracle/unet.py), 1 warm-up + best of 2: {t128:.2f} s; "
+                      f"beside it 1 patch of 4x64^3 (3 warm-ups, median of 5): {t64:.2f} s = {(1.0 / 8.0) / t64:.4f} patches/s "
+                      f"extrapolated; host has {cores} cores, {threads} threads used (fastest setting)"}
+
+
+def kernel_source_sha():
+    """Identity of the convolution kernels' source (what a committed PMC profile must have been taken with)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "brats21_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.startswith("conv_") or name == "common.hpp":
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(kernel_label):
+    """HBM traffic of the dominant kernel from the committed, separately collected rocprofv3 --pmc passes
+    (scripts/pmc.sh + scripts/pmc_report.py --json): used only when the record names this kernel / shape AND was
+    taken with the very kernel sources that are running now -- otherwise the figure would be stale and stays null."""
+    import glob
+    sha = kernel_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_dominant.json")), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("kernel_label") == kernel_label and rec.get("source_sha16") == sha:
+            return rec, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def inference_bench(model, dev, args):
@@ -217,21 +251,17 @@ def main():
                   "sampled_steps": sampled,
                   "families": {f: {"ms_per_step": round(v[0] / sampled, 3), "TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
                                for f, v in fam.items()}}
-    # HBM traffic of the dominant kernel comes from separate --pmc passes (scripts/pmc.sh; never collected inside this
-    # timed run): `traffic` is the committed per-launch figure of those passes for exactly this kernel and shape (null
-    # when the dominant kernel is another one), with its source beside it
-    if roofline is not None and roofline["kernel"].startswith("conv_igemm cin=48 cout=48"):
-        try:
-            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc_dominant.txt")
-            line = next(l for l in open(src) if "conv_igemm_vs8_kernel<24, 1, 3>" in l)
-            import re
-            fetch = float(re.search(r"fetchMB\(x2\)=\s*([0-9.]+)", line).group(1))
-            write = float(re.search(r"writeMB=\s*([0-9.]+)", line).group(1))
-            roofline["traffic"] = int((fetch + write) * 1024 * 1024)  # bytes per launch (the report prints MiB), from the committed passes
-            roofline["traffic_profiled"] = {"fetch_MB": fetch, "write_MB": write, "algorithmic_MB": round(2 * (n * d * h * w * cout * 2) / 1e6, 1),
-                                            "source": "profiles/r01_final_pmc_dominant.txt (rocprofv3 --pmc, separate passes over this kernel and shape, per launch)"}
-        except Exception:
-            pass
+    # HBM traffic of the dominant kernel comes from separate --pmc passes (never collected inside this timed run):
+    # `traffic` is the committed per-launch figure of those passes, null unless it was taken on this kernel, this shape
+    # and these kernel sources (profiled_traffic)
+    if roofline is not None:
+        rec, src = profiled_traffic(roofline["kernel"])
+        if rec is not None:
+            roofline["traffic"] = int((rec["fetch_MB"] + rec["write_MB"]) * 1024 * 1024)  # bytes per launch (the report prints MiB)
+            roofline["traffic_profiled"] = {"fetch_MB": rec["fetch_MB"], "write_MB": rec["write_MB"],
+                                            "algorithmic_MB": round(2 * (n * d * h * w * cout * 2) / 1e6, 1),
+                                            "source": src + " (rocprofv3 --pmc, separate passes over this kernel and shape, per launch; "
+                                                            "FETCH_SIZE doubled per MI355X_MICROARCH.md)"}
     if args.kernel_table:
         for key in sorted(table, key=lambda k: -table[k][2]):
             c, a, tt = table[key]

@@ -1,8 +1,5 @@
-// explicit instantiation unit: bf16, 3x3x3, dilation 1 (see conv_igemm.hpp); large layers with 48-channel chunks
-// take the ping-pong persistent kernel of conv_igemm_pp.hpp
+// explicit instantiation unit: bf16, 3x3x3, dilation 1 (see conv_igemm.hpp)
 #include <stdlib.h>
-#include "conv_igemm_pp.hpp"
-#include "conv_igemm_vsp.hpp"
 #include "conv_igemm_vs8.hpp"
 template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream_t st) {
   if (ck == 24) return conv_launch_vs8<24, 1, 3>(p, st);  // brats_conv3d_chunk() hands out 24 only for the layers of that kernel
@@ -10,17 +7,6 @@ template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream
   if (ck == 8 && p.nchunks == 1 && p.rows16 % 3 == 0 && p.rows16 % 6 != 0 && conv_vsplit_enabled() && conv_vs8_mode() &&
       (long)p.N * p.tz * p.ty * p.tx >= 2048)
     return conv_launch_vs8<8, 1, 3>(p, st);
-  if (ck == 48) {
-    const int rc = conv_try_pp<48>(p, st);
-    if (rc >= 0) return rc;
-  }
-  // Cout = 48 (mod 96) layers with many tiles: the persistent y-split kernel (conv_igemm_vsp.hpp)
-  if (p.rows16 % 3 == 0 && p.rows16 % 6 != 0 && conv_vsplit_enabled()) {
-    int rc = -1;
-    if (ck == 48) rc = conv_try_vsp<48, 1, 3>(p, st);
-    else if (ck == 32) rc = conv_try_vsp<32, 1, 3>(p, st);
-    if (rc >= 0) return rc;
-  }
   switch (ck) {
     case 48: return conv_launch_ck<bf16_t, 3, 48, 1>(p, st);
     case 32: return conv_launch_ck<bf16_t, 3, 32, 1>(p, st);

@@ -164,7 +164,6 @@ extern "C" int brats_conv3d_f8_fwd(const void* x1, int c1, int pitch1, const flo
   p.N = N; p.D = D; p.H = H; p.W = W; p.cout = cout;
   p.nchunks = (c1 + c2) / ck;
   p.tz = ceil_div(D, CONV_TZ); p.ty = ceil_div(H, CONV_TY); p.tx = ceil_div(W, CONV_TX);
-  p.debug = 0;
   pp.amax1 = amax1; pp.amax2 = c2 ? amax2 : nullptr; pp.xscale = xscale;
   if (dil == 1) return conv_f8_launch<1>(pp, ck, (hipStream_t)s);
   if (dil == 2) return conv_f8_launch<2>(pp, ck, (hipStream_t)s);

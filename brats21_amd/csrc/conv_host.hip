@@ -12,19 +12,6 @@ void brats_set_error(const char* fmt, ...) {
 }
 extern "C" const char* brats_last_error(void) { return g_err; }
 extern "C" int brats_abi_version(void) { return 1; }
-int g_conv_pp_mode = -1;
-extern "C" int brats_conv3d_set_pingpong(int mode) {
-  const int old = g_conv_pp_mode;
-  g_conv_pp_mode = mode < 0 ? -1 : (mode ? 1 : 0);
-  return old;
-}
-
-int g_conv_persist_mode = -1;
-extern "C" int brats_conv3d_set_persistent(int mode) {
-  const int old = g_conv_persist_mode;
-  g_conv_persist_mode = mode < 0 ? -1 : (mode ? 1 : 0);
-  return old;
-}
 
 // ---- chunk selection ---------------------------------------------------------------------------
 int g_conv_vs8_mode = -1;
@@ -244,7 +231,6 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
   p.N = N; p.D = D; p.H = H; p.W = W; p.cout = cout; p.rows16 = ceil_div(cout, 16);
   p.nchunks = (c1 + c2) / ck;
   p.tz = ceil_div(D, CONV_TZ); p.ty = ceil_div(H, CONV_TY); p.tx = ceil_div(W, CONV_TX);
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("BRATS_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   hipStream_t st = (hipStream_t)s;
   if (ksize == 1) dil = 1;
 #define GO(T) \

@@ -14,7 +14,7 @@
 // Per Cin chunk (CK channels) the halo tile is staged once and all taps read it (27x reuse from
 // LDS; HBM/L2 sees only the ~2x halo amplification).  2 workgroups/CU overlap staging with MFMA.
 // Relatives: conv_igemm_vs8.hpp (y-split roles on a 4x8x16 tile, the default for bf16 layers with 48 mod 96 couts),
-// conv_igemm_f8.hpp (e4m3 operands), conv_igemm_pp.hpp / conv_igemm_vsp.hpp (persistent experiments, off by default).
+// conv_igemm_f8.hpp (e4m3 operands).  (Two persistent experiments that did not pay live in scripts/probes/experiments/.)
 #pragma once
 #include <stdlib.h>
 #include "common.hpp"
@@ -25,7 +25,6 @@ struct ConvParams {
   void* y2; int y2pitch; int ysplit;  // optional second destination for output channels >= ysplit (dgrad of a concat input)
   int N, D, H, W, cout, rows16, nchunks;
   int tz, ty, tx;
-  int debug;  // ablation bits for conv_igemm_pp.hpp (BRATS_CONV_DEBUG): 1 no LDS-DMA, 2 no MFMA, 4 no epilogue
 };
 
 constexpr int CONV_TZ = 4, CONV_TY = 4, CONV_TX = 16;  // a voxel fragment = one x-row of 16
@@ -93,13 +92,11 @@ constexpr int conv_lds_bytes() {
 // pressure): the weight fragments of step k+1 are requested from L2 before the MFMAs of step k, and the
 // 8 activation fragments are read from LDS in two halves so that 4 ds_read_b128 are always in flight
 // behind 12 MFMAs.
-struct ConvNoHook { template <int K> DEVI void operator()(std::integral_constant<int, K>) const {} };
-
-template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */, int BAR = 0 /* s_barriers embedded at 1/3 and 2/3 (conv_igemm_pp.hpp) */,
-          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */, typename Hook = ConvNoHook,
+template <typename T, int KS, int CK, int DIL, int NF, int PARITY /* -1: all steps */,
+          int NB = 8 /* voxel fragments per wave: NB/2 y-rows in each of 2 z-slices */,
           typename GEOM = ConvGeom<T, KS, CK, DIL>>
 DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0,
-                         int lane, f32x4 (&acc)[NF][NB], Hook&& hook = Hook{} /* called once per macro-step, before its weight loads */) {
+                         int lane, f32x4 (&acc)[NF][NB]) {
   constexpr int YB = NB / 2;
   using G = GEOM;
   constexpr int FOZ = G::HY * G::HX * G::S;  // one z-slice
@@ -135,17 +132,8 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
 #pragma unroll
       for (int i = YB * half; i < YB * half + YB; ++i)
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          if constexpr (std::is_same<typename std::decay<Hook>::type, ConvNoHook>::value) {
-            acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
-          } else {
-            // persistent kernel: accumulate in place.  With the builtin the allocator gives every MFMA a fresh
-            // destination (92 registers for 48 accumulators), which does not fit beside the prefetch registers.
-            f32x4& c_ = acc[f][i];
-            const bf16x8 a_ = a[k % (WD + 1)][f], b_ = b[i];
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c_) : "v"(a_), "v"(b_));
-          }
-        }
+        for (int f = 0; f < NF; ++f)
+          acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -155,7 +143,6 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       constexpr int k = k_;
       // sched_barrier(0) pins the issue order: without it hipcc sinks every load to just before its
       // first use (one live B fragment, weights waited for at vmcnt(0)) and the loop runs latency-bound
-      hook(k_);
       if constexpr (k + WD < NSTEP) load_a(std::integral_constant<int, k + WD>{});
       read_b(k_, I1{});
       __builtin_amdgcn_sched_barrier(0);
@@ -165,10 +152,6 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       __builtin_amdgcn_sched_barrier(0);
       mma(k_, I1{});
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BAR == 2 && (k == NSTEP / 3 || k == (2 * NSTEP) / 3)) {
-        __builtin_amdgcn_s_barrier();  // the other team's epilogue rounds (no memory of this wave is involved)
-        __builtin_amdgcn_sched_barrier(0);
-      }
     });
   } else {
     static_for<0, NSTEP>([&](auto k_) {
@@ -297,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       if (wn == 0) conv_mma_chunk<T, KS, CK, DIL, NF, 0>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
       else conv_mma_chunk<T, KS, CK, DIL, NF, 1>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     } else {
-      conv_mma_chunk<T, KS, CK, DIL, NF, -1, 0, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+      conv_mma_chunk<T, KS, CK, DIL, NF, -1, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     }
   }
 

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
     }
     __syncthreads();
     const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
-    conv_mma_chunk<T, 3, CK, DIL, NF, -1, 0, NB, ConvNoHook, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    conv_mma_chunk<T, 3, CK, DIL, NF, -1, NB, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
   }
 
   // --- epilogue: bias, statistics per 4x4x16 sub-tile, NDHWC store ---

@@ -22,8 +22,6 @@ struct WgradParams {
   int N, D, H, W, cin, cout;
   int tz, ty, tx, ntiles, nsplit;
   int nlane;  // tile ranges (8 = one per XCD; fewer for small volumes so that fewer split-K slabs are written)
-  int debug;  // ablation bits (BRATS_WGRAD_DEBUG): 1 loads dropped by the range check, 2 skip MMA, 4 no tiles,
-              // 8 skip LDS writes + barriers, 16 no load instructions
 };
 
 constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // tile = 16 x-rows of 16 voxels
@@ -145,19 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   // a workgroup's own load -> LDS -> MFMA chain is otherwise serial and sets the throughput (load latency under a
   // chip-wide burst is as long as the MFMA phase).
   u32x4 rx[G::XRPW][G::XIPR], ry[G::YRPW][G::YIPR];
-  const unsigned live = (p.debug & 1) ? 0u : 1u;  // ablation: zero records = every load dropped by the range check
   auto issue_loads = [&](int tile) {
-    if (p.debug & 16) {  // ablation: no load instructions at all
-#pragma unroll
-      for (int k = 0; k < G::XRPW; ++k)
-#pragma unroll
-        for (int j = 0; j < G::XIPR; ++j) rx[k][j] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int k = 0; k < G::YRPW; ++k)
-#pragma unroll
-        for (int j = 0; j < G::YIPR; ++j) ry[k][j] = u32x4{0u, 0u, 0u, 0u};
-      return;
-    }
     int bt = tile;
     const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
     const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
@@ -166,9 +152,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int gz0 = z0 + (tzg - 1) * DIL;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0,
-                                                                          (int)(xsample_bytes * live), 0x00020000);
+                                                                          (int)xsample_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0),
-                                                                          (short)0, (int)(ysample_bytes * live), 0x00020000);
+                                                                          (short)0, (int)ysample_bytes, 0x00020000);
     const int xorg = ((gz0 * p.H + (y0 - DIL)) * p.W + (x0 - DIL)) * xpitch * G::ESZ;  // may be negative at the low faces
     const int yorg = ((z0 * p.H + y0) * p.W + x0) * p.dyp * G::ESZ;
     bool xok[G::XIPR], yok[G::YIPR];
@@ -200,11 +186,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   };
   // (the dilated 48x48 tile has no registers left to keep a second tile in flight: it would spill)
   constexpr bool PREFETCH = !(G::BF && DIL == 2 && COF * CIF == 9);
-  const int tile_first = (p.debug & 4) ? tile_end : lane8 * tpx + gsub;  // ablation bit 4: no tiles (prologue + epilogue only)
+  const int tile_first = lane8 * tpx + gsub;
   if (PREFETCH && tile_first < tile_end) issue_loads(tile_first);
   for (int tile = tile_first; tile < tile_end; tile += g8) {
     if (!PREFETCH) issue_loads(tile);
-    if (!(p.debug & 8)) {
     __syncthreads();  // previous tile's LDS reads are done
 #pragma unroll
     for (int k = 0; k < G::XRPW; ++k) {
@@ -221,12 +206,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         if (ylo[j] >= 0) *(u32x4*)(ldy + ylo[j] + k * 4 * (WG_TX * G::SY)) = ry[k][j];
     }
     __syncthreads();
-    } else { asm volatile("" :: "v"(rx[0][0][0]), "v"(ry[0][0][0])); }
     if (PREFETCH && tile + g8 < tile_end) issue_loads(tile + g8);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMA phase
 
     // ---- MFMA over the 256 voxels of the tile ----
-    if (p.debug & 2) continue;
     if constexpr (G::BF) {
       // k-step s = the two x-rows 2s, 2s+1 of the tile (row = z*4 + y).  MFMA k = 8q + e: e = 0..3 from the
       // first transposing read (row 2s, x = 4q + e), e = 4..7 from the second (row 2s+1, same x); lane
@@ -375,7 +358,6 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     for (int m = 0; m < 3; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 rx[G::XI], ry[G::YI];
-  const unsigned live = (p.debug & 1) ? 0u : 1u;
   auto issue_loads = [&](int tile) {
     int bt = tile;
     const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
@@ -384,9 +366,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     const int n = bt / p.tz;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0,
-                                                                          (int)(xsample_bytes * live), 0x00020000);
+                                                                          (int)xsample_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0),
-                                                                          (short)0, (int)(ysample_bytes * live), 0x00020000);
+                                                                          (short)0, (int)ysample_bytes, 0x00020000);
     unsigned zm = 0, ym = 0, xm = 0, zy = 0, yy = 0, xy = 0;
 #pragma unroll
     for (int h = 0; h < G::HZ; ++h) zm |= ((unsigned)(z0 - 1 + h) < (unsigned)p.D ? 1u : 0u) << h;
@@ -418,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     }
   };
 
-  const int tile_first = (p.debug & 4) ? tile_end : lane8 * tpx + gsub;
+  const int tile_first = lane8 * tpx + gsub;
   if (tile_first < tile_end) issue_loads(tile_first);
   for (int tile = tile_first; tile < tile_end; tile += g8) {
     __syncthreads();  // previous tile's LDS reads are done
@@ -430,7 +412,6 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     __syncthreads();
     if (tile + g8 < tile_end) issue_loads(tile + g8);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMA phase
-    if (p.debug & 2) continue;
     // k-step s = x-rows 2s, 2s+1 of the tile (row = z*4 + y); see the tap-plane kernel for the fragment layout
     const int qq = v >> 2, pp = v & 3;
     const int ybase = (4 * q + qq) * G::SY + pp * 8;
@@ -649,7 +630,6 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   const int cit = ceil_div(c1, 16 * cif) + (c2 > 0 ? ceil_div(c2, 16 * cif) : 0);
   p.nsplit = wgrad_nsplit(p.ntiles, cot, cit);
   p.nlane = wgrad_nlane(p.ntiles);
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("BRATS_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; } p.debug = dbg; }
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
   hipStream_t st = (hipStream_t)s;

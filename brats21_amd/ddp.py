@@ -14,6 +14,7 @@ backward program itself pushes every finished gradient into ``GradientBuckets.pu
 ``_grad_sink`` attribute of the module).  Statically unused parameters (EvoNorm ``v``, SURVEY.md
 Appendix B) never get a gradient and are simply not part of any bucket.
 """
+import contextlib
 import os
 
 import torch
@@ -66,6 +67,8 @@ class GradientBuckets:
         self._pending = None
         self._handles = []
         self._filled = None
+        self._late = None          # buckets that must be gathered from p.grad in finish() (gradient accumulation)
+        self._sync = True
         if hasattr(model, "_grad_sink"):
             model._grad_sink = self.push
 
@@ -108,6 +111,18 @@ class GradientBuckets:
     def _start(self):
         self._filled = [0] * len(self._plan)
         self._handles = [None] * len(self._plan)
+        self._late = set()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (the reference's --gradient_accumulation_iter, learning/engine.py:119-130): backward
+        passes inside the block only accumulate into p.grad locally; the first backward outside it averages the
+        accumulated total (like torch DDP's no_sync)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
 
     def _launch(self, b):
         if self.world > 1:
@@ -116,21 +131,33 @@ class GradientBuckets:
     # -- producer side ----------------------------------------------------------------------------
     def push(self, param_index, grad):
         """Called by the backward program as soon as parameter #param_index's gradient exists."""
+        if not self._sync:
+            return
         if self._plan is None:
             self._order.append(param_index)  # first step: learn the production order, reduce in finish()
             return
         if self._filled is None:
             self._start()
         b, off = self._where[param_index]
+        if self.params[param_index].grad is not None:
+            # an older gradient is still there (micro-batch accumulation, or zero_grad(set_to_none=False)): autograd will
+            # ADD this step's gradient to it after the backward program returns, so what has to be averaged is p.grad
+            # as it stands in finish(), not `grad` -- this bucket is gathered and reduced there (no overlap, but right)
+            self._late.add(b)
+            return
         self._flat[b][off:off + grad.numel()].copy_(grad.reshape(-1))
         self._filled[b] += 1
-        if self._filled[b] == len(self._plan[b]):
+        if self._filled[b] == len(self._plan[b]) and b not in self._late:
             self._launch(b)
 
     # -- consumer side ----------------------------------------------------------------------------
     def finish(self):
-        """After loss.backward(): make every p.grad the average over ranks."""
+        """After loss.backward(): make every p.grad the average over ranks (of the accumulated total when gradients
+        were accumulated over several backward passes)."""
+        if not self._sync:
+            return
         if self._plan is None:
+            self._order = list(dict.fromkeys(self._order))  # (accumulated micro-batches push every index repeatedly)
             seen = set(self._order)
             order = self._order + [i for i, p in enumerate(self.params) if i not in seen and p.grad is not None]
             if not order:
@@ -141,9 +168,14 @@ class GradientBuckets:
         if self._filled is None:
             self._start()
         for b, bucket in enumerate(self._plan):
-            if self._filled[b] != len(bucket):  # not produced through push(): gather from p.grad now
+            if self._filled[b] != len(bucket) or b in self._late:  # not (only) produced through push(): gather from p.grad
+                if self._handles[b] is not None:  # an earlier micro-batch already sent this bucket off: let it land first
+                    self._handles[b].wait()
                 for idx, off, n in bucket:
-                    self._flat[b][off:off + n].copy_(self.params[idx].grad.reshape(-1))
+                    g = self.params[idx].grad
+                    dst = self._flat[b][off:off + n]
+                    if g.data_ptr() != dst.data_ptr():  # (p.grad may still be last step's view of this very bucket)
+                        dst.copy_(g.reshape(-1))
                 self._launch(b)
         for h in self._handles:
             if h is not None:

@@ -4,6 +4,7 @@ with every tensor resident on the GPU.  Logging, meters, checkpoints and data lo
 own and out of scope here."""
 import torch
 
+from . import ops
 from .evaluate import Evaluator  # noqa: F401  (re-export: the evaluate-step driver)
 from .losses import DiceLoss, deep_supervision_loss, fused_deep_supervision_dice
 
@@ -83,4 +84,5 @@ class GraphedTrainStep:
             if target.data_ptr() != self.static_target.data_ptr():
                 self.static_target.copy_(target, non_blocking=True)
         self.graph.replay()
+        ops.invalidate_packed_weights()  # the replayed optimizer kernels changed the weights behind autograd's back
         return self.static_loss

@@ -117,15 +117,23 @@ def hard_dice_metric(pred, target):
 class Evaluator:
     """The per-case body of Engine.evaluate (learning/engine.py:205-285) for one or several models:
     pad to k -> [TTA x] (sliding window | whole volume) -> on-GPU mean of sigmoid -> threshold ->
-    background removal -> (labels) -> crop.  The fixed-shape patch step of each model is captured into a
-    hipGraph once and replayed."""
+    background removal -> (labels) -> crop.
+
+    ``use_graph`` (default: only with a sliding window, whose patch shape is fixed): the patch step of each model is
+    captured into a hipGraph once and replayed; the graphs follow the models' weights (GraphedPredictor re-captures when
+    a parameter's address / version or ops' packed-weight generation changed).  Whole-volume evaluation
+    (sliding_window_size=None, the reference's default path) sees a different padded shape for almost every case, so
+    it runs eagerly unless use_graph=True is passed explicitly (then at most ``max_graphs`` shapes stay captured)."""
 
     def __init__(self, models, tta_transforms=None, sliding_window_size=None, sw_batch_size=1, overlap=0.25,
-                 k_divisible=8, thresh=0.5, amp=True, use_graph=True):
+                 k_divisible=8, thresh=0.5, amp=True, use_graph=None, max_graphs=4):
         self.models = list(models) if isinstance(models, (list, tuple)) else [models]
         self.tta, self.roi, self.swb, self.overlap = tta_transforms, sliding_window_size, sw_batch_size, overlap
         self.k, self.thresh, self.amp = k_divisible, thresh, amp
-        self.predictors = [GraphedPredictor(self._amp(m)) if use_graph else self._amp(m) for m in self.models]
+        if use_graph is None:
+            use_graph = sliding_window_size is not None
+        self.predictors = [GraphedPredictor(self._amp(m), modules=m, max_graphs=max_graphs) if use_graph else self._amp(m)
+                           for m in self.models]
 
     def _amp(self, model):
         def run(x):

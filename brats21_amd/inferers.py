@@ -7,6 +7,7 @@ result to the CPU and stitches there, learning/engine.py:305-307).
 Host-side index logic (scan interval, window origins, importance map) restates MONAI 0.6.0's
 dense_patch_slices / compute_importance_map as used by the reference.
 """
+import collections
 import itertools
 import math
 
@@ -44,7 +45,22 @@ def dense_window_starts(image_size, roi_size, interval):
     return list(itertools.product(*per_dim))
 
 
+def _gaussian_taps(sigma, truncated=4.0):
+    """MONAI 0.6.0 gaussian_1d(sigma, truncated=4.0, approx="erf"): the Gaussian integrated over each unit cell,
+    round(truncated * sigma) taps either side, float32."""
+    sigma = torch.as_tensor(float(sigma), dtype=torch.float32)
+    tail = int(max(float(sigma) * truncated, 0.5) + 0.5)
+    x = torch.arange(-tail, tail + 1, dtype=torch.float32)
+    t = 0.70710678 / torch.abs(sigma)
+    return (0.5 * (torch.erf(t * (x + 0.5)) - torch.erf(t * (x - 0.5)))).clamp(min=0)
+
+
 def importance_map(patch, mode="constant", sigma_scale=0.125, device=None):
+    """MONAI 0.6.0 compute_importance_map as the reference calls it (utils/inferers.py:119-121).  ``gaussian`` is
+    GaussianFilter(sigma_scale * patch) applied to a unit delta at patch // 2 (erf-integrated taps, truncated at 4
+    sigma, zero padding), divided by its maximum, zeros replaced by the smallest non-zero weight.  The filter of a delta
+    is the outer product of the (shifted, cut) tap vectors, multiplied axis 0 first in float32 like the separable
+    convolutions do."""
     mode = getattr(mode, "value", mode)
     if mode == "constant":
         return torch.ones(tuple(patch), dtype=torch.float32, device=device)
@@ -52,9 +68,12 @@ def importance_map(patch, mode="constant", sigma_scale=0.125, device=None):
         raise ValueError(f"unsupported blend mode {mode}")
     if isinstance(sigma_scale, (int, float)):
         sigma_scale = (sigma_scale,) * len(patch)
-    m = torch.ones(tuple(patch), dtype=torch.float64)
+    m = torch.ones((), dtype=torch.float32)
     for ax, (p, s) in enumerate(zip(patch, sigma_scale)):
-        g = torch.exp(-0.5 * ((torch.arange(p, dtype=torch.float64) - p // 2) / (s * p)) ** 2)
+        taps = _gaussian_taps(p * s)
+        tail = (taps.numel() - 1) // 2
+        d = (torch.arange(p) - p // 2).abs()
+        g = torch.where(d <= tail, taps[(tail + d).clamp(max=2 * tail)], torch.zeros((), dtype=torch.float32))
         shape = [1] * len(patch)
         shape[ax] = p
         m = m * g.view(shape)
@@ -72,28 +91,67 @@ def _first(out):
 # --------------------------------------------------------------------------------------- hipGraph patch step
 class GraphedPredictor:
     """Captures ``predictor(window_batch)`` for one fixed input shape into a hipGraph (torch.cuda.CUDAGraph
-    is hipGraph on ROCm) and replays it: one graph launch instead of ~100 kernel launches per patch."""
+    is hipGraph on ROCm) and replays it: one graph launch instead of ~100 kernel launches per patch.
 
-    def __init__(self, predictor):
+    A captured graph bakes in the addresses of the packed-weight buffers the warm-up produced, so it is only valid
+    for the weights it was captured with.  Pass the model(s) as ``modules``: every call compares their parameters'
+    (object, address, version counter) and ops' packed-weight generation with what the graph saw and re-captures on a
+    mismatch (optimizer steps, load_state_dict, SWA, train()/eval() switches); ``reset()`` drops all graphs by hand.
+    Each graph keeps its packed buffers alive.  At most ``max_graphs`` shapes stay captured (least recently used
+    evicted): every graph owns a private memory pool the size of a forward."""
+
+    def __init__(self, predictor, modules=None, max_graphs=4):
         self.predictor = predictor
-        self.graphs = {}
+        self.modules = [] if modules is None else (list(modules) if isinstance(modules, (list, tuple)) else [modules])
+        self.max_graphs = max_graphs
+        self.graphs = collections.OrderedDict()
+        self.captures = 0
 
-    def __call__(self, x):
-        key = (tuple(x.shape), x.dtype)
-        if key not in self.graphs:
-            static_in = torch.empty_like(x)
-            static_in.copy_(x)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+    def reset(self):
+        self.graphs.clear()
+
+    def _signature(self):
+        from . import ops
+        sig = [ops.pack_generation()]
+        for m in self.modules:
+            sig.append(m.training)
+            for p in m.parameters():
+                sig.append((id(p), p.data_ptr(), p._version))
+        return tuple(sig)
+
+    def _capture(self, x):
+        from . import ops
+        keep = []
+        static_in = torch.empty_like(x)
+        static_in.copy_(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with ops.keep_packed(keep):
             with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(2):  # warm-up outside capture (lazy allocations, attribute setup)
+                for _ in range(2):  # warm-up outside capture (lazy allocations, attribute setup, packed weights)
                     _first(self.predictor(static_in))
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
                 static_out = _first(self.predictor(static_in))
-            self.graphs[key] = (g, static_in, static_out)
-        g, static_in, static_out = self.graphs[key]
+        self.captures += 1
+        return g, static_in, static_out, keep
+
+    def __call__(self, x):
+        key = (tuple(x.shape), x.dtype)
+        sig = self._signature()
+        hit = self.graphs.get(key)
+        if hit is not None and hit[4] != sig:
+            del self.graphs[key]  # weights changed since the capture
+            hit = None
+        if hit is None:
+            while len(self.graphs) >= self.max_graphs:
+                self.graphs.popitem(last=False)
+            g, static_in, static_out, keep = self._capture(x)
+            hit = self.graphs[key] = (g, static_in, static_out, keep, self._signature())
+        else:
+            self.graphs.move_to_end(key)
+        g, static_in, static_out = hit[:3]
         static_in.copy_(x)
         g.replay()
         return static_out

@@ -70,6 +70,21 @@ def _head(cin, k):
     return nn.ModuleList([_ConvParams(cin, k, 1, bias=True)])  # key "<name>.0.weight" like nn.Sequential
 
 
+class _PackedWeightsModule(nn.Module):
+    """Keeps ops' no_grad packed-weight cache honest: the cache is dropped on every train() / eval() transition and on
+    every grad-enabled forward, so weights changed without a version bump (``p.data.copy_`` of the reference's
+    Ranger2020, learning/optimizer.py:243,253) are never served stale to a later evaluation."""
+
+    def train(self, mode=True):
+        if mode != self.training:
+            ops.invalidate_packed_weights()
+        return super().train(mode)
+
+    def _weights_may_have_changed(self):
+        if torch.is_grad_enabled():
+            ops.invalidate_packed_weights()
+
+
 # ------------------------------------------------------------------------------------------ programs
 class _AmaxSlots:
     """Zero-initialised device scalars for the |max| side outputs of the producer kernels (one fill per pass)."""
@@ -281,7 +296,7 @@ class _EquiUnetFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ module
-class EquiUnet(nn.Module):
+class EquiUnet(_PackedWeightsModule):
     """Constructor signature of networks/equiunet2020.py:413-414."""
     name = "EquiUnet"
 
@@ -349,6 +364,7 @@ class EquiUnet(nn.Module):
         if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
             raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
         params = tuple(self.parameters())
+        self._weights_may_have_changed()
         if self.training and self.pack_plan and torch.is_grad_enabled():
             ops.plan_for(self, x.device)  # all layers' weights (forward + dgrad layouts) packed by one launch
         outs = _EquiUnetFn.apply(self, x.float(), self._dtype(), *params)

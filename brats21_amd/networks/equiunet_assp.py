@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .._lib import PACK_DGRAD, PACK_FWD, BratsHipError
-from .equiunet import _AmaxSlots, _ConvParams, _inherit_amax
+from .equiunet import _AmaxSlots, _ConvParams, _PackedWeightsModule, _inherit_amax
 
 
 # ------------------------------------------------------------------------------------------ parameter holders
@@ -321,7 +321,7 @@ class _AsspFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ module
-class EquiUnetASSPEvo(nn.Module):
+class EquiUnetASSPEvo(_PackedWeightsModule):
     """Constructor signature of networks/equiunet2021.py:230-231."""
     name = "EquiUnetASSPEvo"
 
@@ -377,6 +377,7 @@ class EquiUnetASSPEvo(nn.Module):
             raise BratsHipError("brats21_amd.EquiUnetASSPEvo runs on the GPU only (no CPU fallback)")
         if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
             raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
+        self._weights_may_have_changed()
         if self.training and self.pack_plan and torch.is_grad_enabled():
             ops.plan_for(self, x.device)  # all layers' weights (forward + dgrad layouts) packed by one launch
         outs = _AsspFn.apply(self, x.float(), self._dtype(), *tuple(self.parameters()))

@@ -132,7 +132,53 @@ def conv_chunk(dtype, ksize, dil, c1, c2=0, cout=0):
     return ck
 
 
-_PACK_CACHE = {}  # inference only: packed weights keyed by (tensor object, layout arguments), validated by version counter
+_PACK_CACHE = {}  # inference only: packed weights keyed by (tensor object, layout arguments); validated by the version
+# counter, the address AND the generation below (writes through ``p.data`` -- the reference's Ranger2020 updates its
+# weights with ``p.data.copy_``, learning/optimizer.py:243,253 -- do not bump a parameter's version counter)
+_PACK_GEN = 0
+_PACK_KEEP = None  # list collecting every packed buffer handed out while a hipGraph of the forward is being built
+
+
+def invalidate_packed_weights():
+    """Drop every cached packed-weight buffer.  Called by the network modules whenever their weights may have changed
+    without a version bump: on every grad-enabled (training) forward and on every train() / eval() transition.  Call it
+    yourself after writing weights through ``p.data`` between two no_grad forwards of an eval-mode model."""
+    global _PACK_GEN
+    _PACK_GEN += 1
+    _PACK_CACHE.clear()
+
+
+def pack_generation():
+    return _PACK_GEN
+
+
+@contextlib.contextmanager
+def keep_packed(sink):
+    """Every buffer pack_weights() / pack_weights_f8() returns inside the block is appended to ``sink``: a captured
+    hipGraph bakes the buffers' addresses in, so its owner must keep them alive (inferers.GraphedPredictor)."""
+    global _PACK_KEEP
+    old, _PACK_KEEP = _PACK_KEEP, sink
+    try:
+        yield sink
+    finally:
+        _PACK_KEEP = old
+
+
+def _cache_get(key, w):
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr() and hit[4] == _PACK_GEN:
+        if _PACK_KEEP is not None:
+            _PACK_KEEP.append(hit[3])
+        return hit[3]
+    return None
+
+
+def _cache_put(key, w, packed):
+    if len(_PACK_CACHE) >= 1024:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (weakref.ref(w), w._version, w.data_ptr(), packed, _PACK_GEN)
+    if _PACK_KEEP is not None:
+        _PACK_KEEP.append(packed)
 
 
 _PACK_JOB = np.dtype([("w", "<u8"), ("out", "<u8"), ("dtype", "<i4"), ("mode", "<i4"), ("taps", "<i4"), ("cin_w", "<i4"),
@@ -243,8 +289,10 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c
     K = Cout, taps flipped.
 
     Under ``torch.no_grad()`` (sliding-window / TTA inference: 144 forwards of the same weights per volume) the
-    packed buffer is cached; the key carries the tensor's version counter, which every in-place update bumps
-    (optimizer steps incl. brats21_amd.optim.Ranger2020, load_state_dict, SWA averaging)."""
+    packed buffer is cached.  A hit needs the same tensor object, address, version counter (bumped by in-place updates:
+    torch optimizers, brats21_amd.optim.Ranger2020, load_state_dict, SWA averaging) and cache generation
+    (``invalidate_packed_weights``: every training forward and train()/eval() switch of the modules -- that covers
+    optimizers that write through ``p.data``, like the reference's Ranger2020)."""
     key = None
     if ACTIVE_PLAN is not None:
         pkey = (id(w), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
@@ -256,14 +304,12 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c
         # keyed by the tensor OBJECT (weak reference: a new tensor that reuses a freed address must not hit) and its
         # version counter
         key = (id(w), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
-        hit = _PACK_CACHE.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
-            return hit[3]
+        hit = _cache_get(key, w)
+        if hit is not None:
+            return hit
     packed = _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1)
     if key is not None:
-        if len(_PACK_CACHE) >= 1024:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (weakref.ref(w), w._version, w.data_ptr(), packed)
+        _cache_put(key, w, packed)
     return packed
 
 
@@ -294,7 +340,7 @@ def set_vs8(mode):
     """brats_conv3d_set_vs8 + invalidation of everything packed under the old setting (the switch changes the K chunk, i.e.
     the packed-weight layout of the layers it applies to).  Returns the previous setting."""
     old = _lib.lib().brats_conv3d_set_vs8(mode)
-    _PACK_CACHE.clear()
+    invalidate_packed_weights()
     for plan in list(_PLANS.values()):
         plan.dirty = True
         plan.entries = None
@@ -360,9 +406,9 @@ def pack_weights_f8(w, mode, cin_pad=None, cin_off=0, cin_cnt=None, c1=None):
     key = None
     if not torch.is_grad_enabled():
         key = (id(w), "f8", mode, cin_pad, cin_off, cin_cnt, 0, c1)
-        hit = _PACK_CACHE.get(key)
-        if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
-            return hit[3]
+        hit = _cache_get(key, w)
+        if hit is not None:
+            return hit
     w0 = w
     cout_w, cin_w, k = w.shape[0], w.shape[1], w.shape[2]
     if k != 3:
@@ -383,9 +429,7 @@ def pack_weights_f8(w, mode, cin_pad=None, cin_off=0, cin_cnt=None, c1=None):
     _lib.check(_lib.lib().brats_conv3d_f8_pack_weights(w.data_ptr(), packed.data_ptr(), mode, cout_w, cin_w, cin_off,
                                                        cin_cnt, ck, _stream()), "conv3d_f8_pack_weights")
     if key is not None:
-        if len(_PACK_CACHE) >= 1024:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (weakref.ref(w0), w0._version, w0.data_ptr(), packed)
+        _cache_put(key, w0, packed)
     return packed
 
 

@@ -109,6 +109,16 @@ class Ranger2020(Optimizer):
         (cached); per step only the gradient pointers and the step-dependent scalars are rewritten -- the reference's
         Python loop over parameters (learning/optimizer.py:145-253) must not come back as host time here."""
         rec = plan.get("rec")
+        if rec is not None:
+            # the cached records hold raw addresses: parameters or state tensors re-allocated since (model.to() / .half()
+            # / .float() round trips, load_state_dict(assign=True), p.data = ..., a state replaced by hand) must not be
+            # written through the old ones
+            ptrs = plan["ptrs"]
+            for t, p in enumerate(active):
+                st = self.state[p]
+                if (p.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), st['slow_buffer'].data_ptr()) != ptrs[t]:
+                    rec = None
+                    break
         if rec is None:
             rec = np.zeros(len(active), _REC)
             for t, p in enumerate(active):
@@ -130,6 +140,7 @@ class Ranger2020(Optimizer):
                           state['slow_buffer'].data_ptr(), p.numel(), plan["rowlen"][t], plan["rowbase"][t], 0.0, 0.0, 0, 0)
             plan["rec"] = rec
             plan["states"] = [self.state[p] for p in active]
+            plan["ptrs"] = [(int(r["param"]), int(r["exp_avg"]), int(r["exp_avg_sq"]), int(r["slow"])) for r in rec]
             # pinned staging ring: the H2D copy of the table is asynchronous, a slot is reused only after its copy ran
             plan["pinned"] = [torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
             plan["pinned_capture"] = torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory()  # see step(): capture mode

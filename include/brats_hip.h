@@ -80,16 +80,6 @@ int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* block
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
 /* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
 int brats_conv3d_split_granule(int cout);
-/* Tuning / test knob: selects the kernel family of the large bf16 3x3x3 layers.  1 = the persistent
- * "ping-pong" kernel (LDS-DMA double buffering, two wave teams in anti-phase; experimental, not
- * faster yet), 0 = one tile per workgroup, -1 = default (0, or the BRATS_CONV_PP environment
- * variable).  Both families compute the same values; returns the previous setting. */
-int brats_conv3d_set_pingpong(int mode);
-/* Kernel selection of the bf16 3x3x3 layers with 48 (mod 96) output channels and >= 2048 tiles: 1 = the persistent
- * y-split kernel (a workgroup walks a tile list and fetches the next halo tile while the MFMAs of the current one run),
- * 0 = one tile per workgroup, -1 = default (0, or the BRATS_CONV_PERSIST environment variable; the persistent form is an
- * experiment that is not faster yet).  Both compute bit-identical results; returns the previous setting. */
-int brats_conv3d_set_persistent(int mode);
 /* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
  * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (1, or BRATS_CONV_VS8).  The setting
  * changes brats_conv3d_chunk(), i.e. the packed-weight layout: weights must be packed under the same setting they are

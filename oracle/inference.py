@@ -37,18 +37,10 @@ def window_starts(image_size, roi_size, interval):
 
 
 def importance_map(patch, mode="constant", sigma_scale=0.125):
-    """MONAI compute_importance_map (utils/inferers.py:119-121)."""
-    if mode == "constant":
-        return torch.ones(patch, dtype=torch.float32)
-    m = np.ones(patch, dtype=np.float64)
-    for ax, p in enumerate(patch):
-        g = np.exp(-0.5 * ((np.arange(p, dtype=np.float64) - p // 2) / (sigma_scale * p)) ** 2)
-        shp = [1] * len(patch)
-        shp[ax] = p
-        m = m * g.reshape(shp)
-    m = (m / m.max()).astype(np.float32)
-    m[m == 0] = m[m != 0].min()
-    return torch.from_numpy(m)
+    """MONAI 0.6.0 compute_importance_map (utils/inferers.py:119-121); the restatement lives in oracle/refshim.py (the
+    stub the reference itself is imported with when the golden vectors are generated)."""
+    from .refshim import _compute_importance_map
+    return _compute_importance_map(tuple(patch), mode, sigma_scale)
 
 
 def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.25, mode="constant",

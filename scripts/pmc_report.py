@@ -1,6 +1,9 @@
 """Summarises the per-kernel PMC counters collected by scripts/pmc.sh (clock, MFMA-busy fraction, LDS conflicts, L2 hit, traffic)."""
-import csv, glob, sys, collections
+import csv, glob, json, os, sys, collections
 tag = sys.argv[1]
+# --json "<bench.py roofline.kernel label>" "<kernel name substring>": one record for bench.py's roofline.traffic
+want_json = sys.argv[3:5] if len(sys.argv) >= 5 and sys.argv[2] == "--json" else None
+records = []
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(f"gpurun_out/{tag}/p*/*/*counter_collection.csv")):
     disp = collections.OrderedDict()
@@ -29,4 +32,18 @@ for k, d in agg.items():
         # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs; MFMA busy cycles are summed over all 1024 SIMDs
         clk = m['GRBM_GUI_ACTIVE'] / 8 / dur  # GHz (dur in ns)
         line += f" clk={clk:.2f}GHz mfma_util={m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}"
-    print(line)
+    records.append((k[0], m, dur))
+    if not want_json:
+        print(line)
+if want_json:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    label, sub = want_json
+    name, m, dur = next(r for r in records if sub in r[0])
+    rec = {"kernel_label": label, "kernel_name": name, "source_sha16": bench.kernel_source_sha(),
+           "fetch_MB": round(2 * m['FETCH_SIZE'] / 1024, 1), "write_MB": round(m['WRITE_SIZE'] / 1024, 1), "dur_us": round(dur / 1e3, 1),
+           "L2hit": round(m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']), 3),
+           "mfma_util": round(m['SQ_VALU_MFMA_BUSY_CYCLES'] / (m['GRBM_GUI_ACTIVE'] / 8 * 1024), 3),
+           "clk_GHz": round(m['GRBM_GUI_ACTIVE'] / 8 / dur, 3),
+           "note": "rocprofv3 --pmc, separate passes (scripts/pmc.sh); FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md); MiB per launch"}
+    print(json.dumps(rec))

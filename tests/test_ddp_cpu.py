@@ -67,6 +67,75 @@ def _worker(rank, world, port, use_push, q):
     q.put((rank, out))
 
 
+def _accum_worker(rank, world, port, mode, q):
+    """Gradient accumulation (the reference's --gradient_accumulation_iter, learning/engine.py:119-130: no zero_grad
+    between micro-batches) through push(): the averaged result must be the mean over ranks of the SUM over micro-batches."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _Net()
+    torch.manual_seed(200 + rank)
+    buckets = GradientBuckets(net, bucket_bytes=64)
+    params = list(net.parameters())
+
+    def backward_with_push(x):
+        """what the accelerated models do: the backward program pushes each finished gradient, THEN autograd
+        accumulates it into p.grad"""
+        loss = net(x).pow(2).mean()
+        grads = torch.autograd.grad(loss, [p for p in params if p is not net.unused])
+        it = iter(grads)
+        local = [None if p is net.unused else next(it) for p in params]
+        for idx in reversed(range(len(local))):
+            if local[idx] is not None:
+                net._grad_sink(idx, local[idx])
+        for p, g in zip(params, local):
+            if g is not None:
+                p.grad = g.clone() if p.grad is None else p.grad.add_(g)
+        return local
+
+    for outer in range(3):  # outer step 0 learns the bucket order, 1 and 2 use the push path
+        net.zero_grad(set_to_none=(mode != "zero_in_place"))
+        total = [None] * len(params)
+        micro = 1 if mode == "zero_in_place" else 3
+        for mb in range(micro):
+            x = torch.randn(4, 6)
+            if mode == "no_sync" and mb < micro - 1:
+                with buckets.no_sync():
+                    local = backward_with_push(x)
+                    buckets.finish()  # a no-op inside no_sync
+            else:
+                local = backward_with_push(x)
+                if mode == "finish_each":
+                    buckets.finish()
+            for i, g in enumerate(local):
+                if g is not None:
+                    total[i] = g.clone() if total[i] is None else total[i] + g
+        if mode != "finish_each":
+            buckets.finish()
+        for p, g in zip(params, total):
+            if g is None:
+                assert p.grad is None
+                continue
+            dist.all_reduce(g)
+            torch.testing.assert_close(p.grad, g / world, atol=1e-6, rtol=1e-5)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+@pytest.mark.parametrize("mode", ["finish_once", "finish_each", "no_sync", "zero_in_place"])
+def test_gradient_accumulation_gloo_world2(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_accum_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 @pytest.mark.parametrize("use_push", [False, True])
 def test_gradient_buckets_gloo_world2(use_push):
     ctx = mp.get_context("spawn")

@@ -64,3 +64,29 @@ def test_signed_perm_algebra_against_torch_ops():
     a, b = ax.aug(axe="xyz"), rot.aug(angle=90)
     torch.testing.assert_close(_perm_torch(a.then(b), x), _perm_torch(b, _perm_torch(a, x).contiguous()))
     assert SignedPerm().is_identity and a.out_shape(x.shape) == (2, 3, 5, 6, 4)
+
+
+def test_gaussian_importance_map_is_monai_gaussian_filter_of_a_delta():
+    """MONAI 0.6.0 compute_importance_map(gaussian) (utils/inferers.py:119-121): GaussianFilter (erf-integrated taps,
+    4 sigma) over a unit delta, / max, zeros -> smallest non-zero.  Known-answer check of the closed form, and the
+    product's outer-product construction against the oracle's convolution construction (bit for bit)."""
+    import math
+    from brats21_amd.inferers import importance_map
+    from oracle.refshim import _compute_importance_map
+    m = importance_map((16, 16, 16), "gaussian", 0.125)
+    sig = 2.0
+
+    def tap(d):
+        t = 1.0 / (math.sqrt(2.0) * sig)
+        return 0.5 * (math.erf(t * (d + 0.5)) - math.erf(t * (d - 0.5)))
+
+    assert float(m[8, 8, 8]) == 1.0
+    for i in range(16):
+        assert abs(float(m[i, 8, 8]) - tap(abs(i - 8)) / tap(0)) < 1e-6
+    assert abs(float(m[0, 0, 0]) - (tap(8) / tap(0)) ** 3) < 1e-12
+    for patch in ((16, 16, 16), (12, 20, 9), (5, 3, 7), (32, 32, 32)):
+        a, b = importance_map(patch, "gaussian", 0.125), _compute_importance_map(patch, "gaussian", 0.125)
+        assert torch.equal(a, b) and float(a.min()) > 0
+    # sigma so small that the 4-sigma cut leaves cells untouched: they get the smallest non-zero weight, never 0
+    a, b = importance_map((16, 16, 16), "gaussian", 0.03), _compute_importance_map((16, 16, 16), "gaussian", 0.03)
+    assert torch.equal(a, b) and float(a.min()) > 0 and float(a[0, 0, 0]) == float(a.min())

@@ -246,55 +246,6 @@ def test_fused_dice_matches_torch_dice(jaccard):
         torch.testing.assert_close(a, b, atol=1e-9, rtol=1e-4)
 
 
-@pytest.mark.parametrize("cin,cin2,cout,n,size,split", [
-    (48, 0, 48, 2, (32, 64, 64), None),     # K-split tile (cout 48), one chunk
-    (48, 48, 48, 3, (34, 62, 66), None),    # two sources, ragged in z / y / x
-    (48, 0, 96, 2, (32, 64, 64), 48),       # no-split tile (cout 96), dual destination
-    (96, 0, 192, 2, (32, 32, 64), None),    # two cout tiles per voxel tile, two chunks
-])
-def test_conv3d_pingpong_kernel_matches_tile_kernel(cin, cin2, cout, n, size, split):
-    """The persistent LDS-DMA kernel of the large bf16 layers against the one-tile-per-workgroup kernel on the same
-    inputs and against torch on sample 0."""
-    from brats21_amd import _lib, ops
-    dev = _dev()
-    dt = torch.bfloat16
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn((n, *size, cin), generator=g).to(dev).to(dt)
-    x2 = torch.randn((n, *size, cin2), generator=g).to(dev).to(dt) if cin2 else None
-    w = torch.randn((cout, cin + cin2, 3, 3, 3), generator=g) * (2.0 / ((cin + cin2) * 27)) ** 0.5
-    bias = torch.randn(cout, generator=g).to(dev)
-    lib = _lib.lib()
-    old8 = ops.set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
-    res = {}
-    try:
-        wpk = ops.pack_weights(w.to(dev), dt, ops.PACK_FWD, c1=cin if cin2 else None)
-        for mode in (0, 1):
-            old = lib.brats_conv3d_set_pingpong(mode)
-            try:
-                y, st = ops.conv3d(x, wpk, cout, 3, 1, bias=bias, want_stats=True, x2=x2, split=split)
-                torch.cuda.synchronize()
-            finally:
-                lib.brats_conv3d_set_pingpong(old)
-            res[mode] = (y, st)
-    finally:
-        ops.set_vs8(old8)
-    ya, yb = res[0][0], res[1][0]
-    # cout 96 / 192: both kernels run the same MFMA order -> bit-identical.  cout 48: the tile kernel accumulates all of
-    # K in one chain (y-split roles), the ping-pong kernel adds two K-parity partial sums -> equal up to one bf16 ulp.
-    same = (lambda a, b: torch.equal(a, b)) if cout % 96 == 0 else (
-        lambda a, b: bool(((a.float() - b.float()).abs() <= 2e-2 * b.float().abs() + 2e-2).all()))
-    if split is not None:
-        assert same(ya[0], yb[0]) and same(ya[1], yb[1])
-        yb = torch.cat([yb[0], yb[1]], -1)
-    else:
-        assert same(ya, yb)
-    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-5, atol=1e-3)
-    # torch reference on sample 0 (zero padding at every face included)
-    xin = x[:1].float().cpu() if x2 is None else torch.cat([x[:1], x2[:1]], -1).float().cpu()
-    ref = F.conv3d(xin.permute(0, 4, 1, 2, 3), w.to(dt).float(), bias.cpu(), 1, 1)
-    torch.testing.assert_close(_from_ndhwc(yb[:1]), ref, atol=3e-2, rtol=2e-2)
-
-
 @pytest.mark.parametrize("cin,cin2,cout,n,size", [
     (48, 0, 48, 2, (32, 64, 64)),
     (48, 48, 48, 3, (34, 62, 66)),     # two sources, ragged in z / y / x
@@ -417,37 +368,6 @@ def test_groupnorm_other_activations_fwd_bwd(dtype, act):
     torch.testing.assert_close(_from_ndhwc(dy), yr.grad, atol=_tol(dtype, 5e-5, 5e-2), rtol=_tol(dtype, 1e-4, 5e-2))
     torch.testing.assert_close(dgamma.cpu(), gr.grad, atol=_tol(dtype, 2e-3, 0.15), rtol=_tol(dtype, 1e-4, 2e-2))
     torch.testing.assert_close(dbeta.cpu(), br.grad, atol=_tol(dtype, 2e-3, 0.15), rtol=_tol(dtype, 1e-4, 2e-2))
-
-
-@pytest.mark.parametrize("cin,cin2,cout,n,size", [
-    (48, 0, 48, 2, (64, 64, 64)),     # 4096 tiles, one chunk
-    (48, 48, 48, 1, (68, 64, 72)),    # two-source (two chunks per tile), ragged tiles in z and x
-    (96, 0, 144, 1, (48, 48, 64)),    # three cout blocks share the tile list, two chunks
-])
-def test_conv3d_persistent_kernel_matches_one_tile_kernel(cin, cin2, cout, n, size):
-    """The persistent y-split kernel (conv_igemm_vsp.hpp) keeps the accumulation and reduction orders of the one-tile
-    kernel: outputs and tile statistics must be bit-identical; the one-tile kernel itself is checked against torch in
-    test_conv3d_fwd_dgrad_wgrad / test_conv3d_full_size_layer_vs_torch."""
-    from brats21_amd import ops, _lib
-    dev = _dev()
-    dt = torch.bfloat16
-    x = _to_ndhwc(_rand((n, cin) + size, 21), dt, dev)
-    x2 = _to_ndhwc(_rand((n, cin2) + size, 22), dt, dev) if cin2 else None
-    w = _rand((cout, cin + cin2, 3, 3, 3), 23, 0.05).to(dev)
-    b = _rand((cout,), 24, 0.1).to(dev)
-    lib = _lib.lib()
-    old8 = ops.set_vs8(0)  # both kernels of this test work on 48-channel chunks / 4x4x16 tiles
-    old = lib.brats_conv3d_set_persistent(0)
-    try:
-        wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
-        y0, s0 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
-        lib.brats_conv3d_set_persistent(1)
-        y1, s1 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
-    finally:
-        lib.brats_conv3d_set_persistent(old)
-        ops.set_vs8(old8)
-    assert torch.equal(y0, y1)
-    assert torch.equal(s0, s1)
 
 
 @pytest.mark.parametrize("cin,cin2,cout,n,size", [
