@@ -22,6 +22,7 @@ struct WgradParams {
   int N, D, H, W, cin, cout;
   int tz, ty, tx, ntiles, nsplit;
   int nlane;  // tile ranges (8 = one per XCD; fewer for small volumes so that fewer split-K slabs are written)
+  int ntaps, dil;  // KS = 1 form only: 1 tap (a 1x1x1 convolution) or 27 shifted taps (3x3x3 at any dilation)
 };
 
 constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // tile = 16 x-rows of 16 voxels
@@ -30,12 +31,18 @@ constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // tile = 16 x-ro
 // (4 x (4+2d) x (16+2d) voxels), X + dY tiles fit twice per CU, and two workgroups per CU overlap each
 // other's staging and MFMA phases.  The three tzg workgroups of a tile group sit on the same XCD
 // (block ids b, b+8, b+16) so the shared dY / X lines come from that XCD's L2.
-template <typename T, int DIL, int COF, int CIF>
+// KS = 1 ("shifted-tap" form): no halo at all.  A workgroup owns ONE tap; its X tile is the dY tile's box shifted by
+// dil * off(tap) (voxels outside the volume read zeros).  With ntaps = 1 that is the weight gradient of a 1x1x1
+// convolution (ConvEvo / bridge / upconv / ASPP k1, networks/equiunet2021.py:212-222: a GEMM over the voxels, HBM-bound);
+// with ntaps = 27 it is the weight gradient of a 3x3x3 convolution at ANY dilation -- used for the ASPP branches with
+// dilation 4 and 6 (:121-189), whose halo does not fit LDS and whose 16^3 input sits in L2 anyway.
+template <typename T, int DIL, int COF, int CIF, int KS = 3>
 struct WgGeom {
   static constexpr bool BF = std::is_same<T, bf16_t>::value;
   static constexpr int ESZ = sizeof(T);
   static constexpr int EPL = 16 / ESZ;
-  static constexpr int HY = WG_TY + 2 * DIL, HX = WG_TX + 2 * DIL;
+  static constexpr int R = KS == 3 ? DIL : 0;
+  static constexpr int HY = WG_TY + 2 * R, HX = WG_TX + 2 * R;
   static constexpr int HVOX = WG_TZ * HY * HX;
   static constexpr int CI_T = 16 * CIF, CO_T = 16 * COF;
   static constexpr int XROWB = CI_T * ESZ, YROWB = CO_T * ESZ;
@@ -48,7 +55,7 @@ struct WgGeom {
   static constexpr int YPPR = WG_TX * YPPV, YIPR = (YPPR + 63) / 64, YROWS = WG_TZ * WG_TY, YRPW = YROWS / 4;
   static constexpr int LDS_X = HVOX * SX, LDS_Y = WG_VOX * SY;
   static constexpr int LDS = LDS_X + LDS_Y;
-  static constexpr int PAIRS = 9 * CIF;          // (tap-in-plane, ci fragment) pairs
+  static constexpr int PAIRS = (KS == 3 ? 9 : 1) * CIF;  // (tap-in-plane, ci fragment) pairs
   static constexpr int PPW = (PAIRS + 3) / 4;    // pairs per wave (wave w: w, w+4, ...)
   static constexpr int NB = BF ? 32 : 64;        // bytes between consecutive ci / co fragments in a voxel row
 };
@@ -61,18 +68,23 @@ DEVI bf16x8 tr_pair(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename T, int DIL, int COF, int CIF>
+template <typename T, int DIL, int COF, int CIF, int KS = 3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p) {
-  using G = WgGeom<T, DIL, COF, CIF>;
+  using G = WgGeom<T, DIL, COF, CIF, KS>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldx = lds;
   char* ldy = lds + G::LDS_X;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = lane >> 4, v = lane & 15;
-  // ---- schedule: blockIdx.x = lane8 + 8*r, r = 3*gsub + tzg ----
+  // ---- schedule: blockIdx.x = lane8 + 8*r, r = NP*gsub + tzg (NP = 3 tap planes, or the taps of the KS = 1 form) ----
+  const int NP = KS == 3 ? 3 : p.ntaps;
   const int lane8 = blockIdx.x % p.nlane, rr = blockIdx.x / p.nlane;
-  const int tzg = rr % 3, gsub = rr / 3, g8 = gridDim.x / (3 * p.nlane);
+  const int tzg = rr % NP, gsub = rr / NP, g8 = gridDim.x / (NP * p.nlane);
+  // KS = 1: the tap's shift in voxels (0 for a 1x1x1 convolution)
+  const int shz = (KS == 3 || p.ntaps == 1) ? 0 : (tzg / 9 - 1) * p.dil;
+  const int shy = (KS == 3 || p.ntaps == 1) ? 0 : ((tzg / 3) % 3 - 1) * p.dil;
+  const int shx = (KS == 3 || p.ntaps == 1) ? 0 : (tzg % 3 - 1) * p.dil;
   const int split = lane8 + p.nlane * gsub;
   const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
   const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
   for (int jj = 0; jj < G::PPW; ++jj) {
     const int pid = wave + 4 * jj;
     const int t9 = pid / CIF, nn = pid % CIF;
-    poff[jj] = pid < G::PAIRS ? (((t9 / 3) * DIL) * G::HX + (t9 % 3) * DIL) * G::SX + nn * G::NB : 0;
+    poff[jj] = pid < G::PAIRS ? (((t9 / 3) * G::R) * G::HX + (t9 % 3) * G::R) * G::SX + nn * G::NB : 0;
   }
   f32x4 acc[G::PPW][COF];
 #pragma unroll
@@ -149,23 +161,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
     const int z0 = (bt % p.tz) * WG_TZ;
     const int n = bt / p.tz;
-    const int gz0 = z0 + (tzg - 1) * DIL;
+    const int gz0 = KS == 3 ? z0 + (tzg - 1) * DIL : z0 + shz;
+    const int gy0 = KS == 3 ? y0 - DIL : y0 + shy, gx0 = KS == 3 ? x0 - DIL : x0 + shx;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0,
                                                                           (int)xsample_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0),
                                                                           (short)0, (int)ysample_bytes, 0x00020000);
-    const int xorg = ((gz0 * p.H + (y0 - DIL)) * p.W + (x0 - DIL)) * xpitch * G::ESZ;  // may be negative at the low faces
+    const int xorg = ((gz0 * p.H + gy0) * p.W + gx0) * xpitch * G::ESZ;  // may be negative at the low faces
     const int yorg = ((z0 * p.H + y0) * p.W + x0) * p.dyp * G::ESZ;
     bool xok[G::XIPR], yok[G::YIPR];
 #pragma unroll
-    for (int j = 0; j < G::XIPR; ++j) xok[j] = (unsigned)(x0 - DIL + xhx[j]) < (unsigned)p.W;
+    for (int j = 0; j < G::XIPR; ++j) xok[j] = (unsigned)(gx0 + xhx[j]) < (unsigned)p.W;
 #pragma unroll
     for (int j = 0; j < G::YIPR; ++j) yok[j] = x0 + yvx[j] < p.W;
 #pragma unroll
     for (int k = 0; k < G::XRPW; ++k) {
       const int row = wave + 4 * k;
-      const int gz = gz0 + row / G::HY, gy = y0 - DIL + row % G::HY;
+      const int gz = gz0 + row / G::HY, gy = gy0 + row % G::HY;
       const bool row_ok = row < G::XROWS && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H;  // scalar
 #pragma unroll
       for (int j = 0; j < G::XIPR; ++j) {
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
   };
   // (the dilated 48x48 tile has no registers left to keep a second tile in flight: it would spill)
-  constexpr bool PREFETCH = !(G::BF && DIL == 2 && COF * CIF == 9);
+  constexpr bool PREFETCH = !(G::BF && KS == 3 && DIL == 2 && COF * CIF == 9);
   const int tile_first = lane8 * tpx + gsub;
   if (PREFETCH && tile_first < tile_end) issue_loads(tile_first);
   for (int tile = tile_first; tile < tile_end; tile += g8) {
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     const int pid = wave + 4 * jj;
     if (pid < G::PAIRS) {
       const int t9 = pid / CIF, nn = pid % CIF;
-      float* base = p.ws + ((size_t)split * 27 + tzg * 9 + t9) * p.cout * p.cin;
+      float* base = p.ws + (KS == 3 ? (size_t)split * 27 + tzg * 9 + t9 : (size_t)split * p.ntaps + tzg) * p.cout * p.cin;
       const int ci = ci0 + nn * 16 + v;
 #pragma unroll
       for (int m = 0; m < COF; ++m)
@@ -469,8 +482,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
 // sums are combined in group order through LDS (one thread per element deep the kernel had 61 workgroups, each
 // lane walking all ~256 slabs serially).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                           int cout, int cin) {
-  const size_t per = (size_t)27 * cout * cin;
+                                                           int cout, int cin, int taps) {
+  const size_t per = (size_t)taps * cout * cin;
   const size_t per4 = per / 4;  // cin % 4 == 0
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
   const size_t i4 = (size_t)blockIdx.x * 32 + e;
@@ -488,7 +501,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     const int co = (i / cin) % cout;
     const int tap = (int)(i / ((size_t)cin * cout));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dw[((size_t)co * cin + ci + j) * 27 + tap] = s[j];
+    for (int j = 0; j < 4; ++j) dw[((size_t)co * cin + ci + j) * taps + tap] = s[j];
   }
 }
 
@@ -577,10 +590,10 @@ extern "C" size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D
   return (size_t)ns * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
 }
 
-template <typename T, int DIL, int COF, int CIF>
+template <typename T, int DIL, int COF, int CIF, int KS = 3>
 static int wgrad_launch(const WgradParams& p, dim3 grid, hipStream_t st) {
-  using G = WgGeom<T, DIL, COF, CIF>;
-  auto kern = conv_wgrad_kernel<T, DIL, COF, CIF>;
+  using G = WgGeom<T, DIL, COF, CIF, KS>;
+  auto kern = conv_wgrad_kernel<T, DIL, COF, CIF, KS>;
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
@@ -592,9 +605,9 @@ static int wgrad_launch(const WgradParams& p, dim3 grid, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int DIL>
+template <typename T, int DIL, int KS = 3>
 static int wgrad_dispatch(const WgradParams& p, int cof, int cif, dim3 grid, hipStream_t st) {
-#define WG_CASE(A, B) if (cof == A && cif == B) return wgrad_launch<T, DIL, A, B>(p, grid, st);
+#define WG_CASE(A, B) if (cof == A && cif == B) return wgrad_launch<T, DIL, A, B, KS>(p, grid, st);
   WG_CASE(3, 1) WG_CASE(2, 1) WG_CASE(1, 1)
   if constexpr (std::is_same<T, bf16_t>::value) {
     WG_CASE(3, 3) WG_CASE(3, 2) WG_CASE(2, 3) WG_CASE(2, 2) WG_CASE(1, 3) WG_CASE(1, 2)
@@ -663,7 +676,74 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   if (rc) return rc;
   const size_t per = (size_t)27 * cout * p.cin;
   const size_t blocks = (per / 4 + 31) / 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, p.cin);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, p.cin, 27);
+  if (dbias) {
+    const size_t vox = (size_t)N * D * H * W;
+    if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
+    else hipLaunchKernelGGL(dbias_kernel<float>, dim3(cout), dim3(256), 0, st, (const float*)dy, dypitch, dbias, vox, cout);
+  }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- shifted-tap form: 1x1x1 convolutions, and 3x3x3 convolutions at any dilation (ASPP d = 4, 6) ------------------
+static int wgrad_shift_geometry(int dtype, int ksize, int N, int D, int H, int W, int cin, int cout, WgradParams* p, int* cof,
+                                int* cif, int* cot, int* cit) {
+  wgrad_tiles(dtype, cin, 0, cout, cof, cif);
+  p->N = N; p->D = D; p->H = H; p->W = W; p->cin = cin; p->cout = cout;
+  p->tz = ceil_div(D, WG_TZ); p->ty = ceil_div(H, WG_TY); p->tx = ceil_div(W, WG_TX);
+  p->ntiles = N * p->tz * p->ty * p->tx;
+  p->ntaps = ksize == 3 ? 27 : 1;
+  *cot = ceil_div(cout, 16 * *cof);
+  *cit = ceil_div(cin, 16 * *cif);
+  p->nlane = wgrad_nlane(p->ntiles);
+  int g8 = ceil_div(512, p->ntaps * p->nlane * *cot * *cit);
+  const int cap = ceil_div(p->ntiles, p->nlane);
+  if (g8 > cap) g8 = cap;
+  if (g8 < 1) g8 = 1;
+  p->nsplit = p->nlane * g8;
+  return 0;
+}
+
+extern "C" size_t brats_conv3d_wgrad_shift_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int cin, int cout) {
+  if (ksize != 1 && ksize != 3) return 0;
+  WgradParams p;
+  int cof, cif, cot, cit;
+  wgrad_shift_geometry(dtype, ksize, N, D, H, W, cin, cout, &p, &cof, &cif, &cot, &cit);
+  return (size_t)p.nsplit * p.ntaps * cout * cin * sizeof(float);
+}
+
+extern "C" int brats_conv3d_wgrad_shift(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
+                                        float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
+                                        brats_stream_t s) {
+  if (!x || !dy || !ws || !dw || cin <= 0 || cout <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0)
+    BRATS_FAIL(BRATS_E_ARG, "wgrad_shift: null pointer / bad size");
+  if ((ksize != 1 && ksize != 3) || dil < 1) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: ksize=%d dil=%d unsupported", ksize, dil);
+  if (dtype != BRATS_BF16 && dtype != BRATS_F32) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: dtype %d", dtype);
+  const int epl = dtype == BRATS_BF16 ? 8 : 4;
+  if (xpitch % epl || dypitch % epl || cin % epl || cout % epl)
+    BRATS_FAIL(BRATS_E_ARG, "wgrad_shift: channel counts / pitches must be multiples of %d", epl);
+  {
+    const int mp = xpitch > dypitch ? xpitch : dypitch;
+    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
+  }
+  WgradParams p;
+  int cof, cif, cot, cit;
+  wgrad_shift_geometry(dtype, ksize, N, D, H, W, cin, cout, &p, &cof, &cif, &cot, &cit);
+  p.x1 = x; p.x2 = nullptr; p.c1 = cin; p.c2 = 0; p.p1 = xpitch; p.p2 = 0;
+  p.dy = dy; p.dyp = dypitch; p.ws = ws; p.dil = dil;
+  hipStream_t st = (hipStream_t)s;
+  if (cin % 16 || cout % 16) {  // slab entries of padded ci / co lanes are never written
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * p.ntaps * cout * cin * sizeof(float), st);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad_shift: memset: %s", hipGetErrorString(e));
+  }
+  dim3 grid(p.ntaps * p.nsplit, cot, cit);
+  const int rc = dtype == BRATS_BF16 ? wgrad_dispatch<bf16_t, 1, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 1, 1>(p, cof, cif, grid, st);
+  if (rc) return rc;
+  const size_t per = (size_t)p.ntaps * cout * cin;
+  const size_t blocks = (per / 4 + 31) / 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, cin, p.ntaps);
   if (dbias) {
     const size_t vox = (size_t)N * D * H * W;
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);

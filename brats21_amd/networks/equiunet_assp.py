@@ -101,42 +101,28 @@ class _Ctx:
 
 
 def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
-    """conv (3x3x3 any dilation or 1x1x1) + bias.  Returns (y, stats, saved) with what backward needs."""
+    """conv (3x3x3 with dilation 1 | 2, or 1x1x1) + bias.  Returns (y, stats, saved) with what backward needs."""
     w = conv.weight
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-    if k == 3 and dil > 2:  # halo too large for LDS: im2col + 1x1 implicit GEMM over 27*C channels
-        col = ops.im2col3(x, dil)
-        w1 = w.detach().permute(0, 2, 3, 4, 1).reshape(cout, 27 * cin, 1, 1, 1)
-        wpk = ops.pack_weights(w1, cx.dtype, PACK_FWD)
-        y, stats = ops.conv3d(col, wpk, cout, 1, 1, bias=_flat(conv.bias), out=out, want_stats=want_stats)
-        return y, stats, ("col", col, dil)
     if cx.fp8 and k == 3 and ops.conv_f8_chunk(x.shape[-1]) > 0:
         wpk = ops.pack_weights_f8(w, PACK_FWD, cin_pad=x.shape[-1])
         y, stats = ops.conv3d_f8(x, wpk, cout, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats,
                                  amax=getattr(x, "_amax", None))
-        return y, stats, ("direct", x, dil)
+        return y, stats, (x, dil)
     wpk = ops.pack_weights(w, cx.dtype, PACK_FWD, cin_pad=x.shape[-1], dil=dil)
     y, stats = ops.conv3d(x, wpk, cout, k, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
-    return y, stats, ("direct", x, dil)
+    return y, stats, (x, dil)
 
 
 def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
-    kind, xin, dil = saved
+    xin, dil = saved
     w = conv.weight
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
     if db is None:
         db = ops.channel_dot(dy).sum(0)
-    if kind == "col":
-        dw1 = ops.wgrad_1x1(xin, dy)  # [cout, 27*cin] in (tap, ci) order
-        cx.put(conv.weight, dw1.view(cout, 3, 3, 3, cin).permute(0, 4, 1, 2, 3).contiguous())
-        cx.put(conv.bias, db)
-        if not need_dx:
-            return None
-        w1 = w.detach().permute(0, 2, 3, 4, 1).reshape(cout, 27 * cin, 1, 1, 1)
-        dcol, _ = ops.conv3d(dy, ops.pack_weights(w1, cx.dtype, PACK_DGRAD), 27 * cin, 1, 1)
-        return ops.col2im3(dcol, cin, dil)
     if k == 1:
-        cx.put(conv.weight, ops.wgrad_1x1(xin, dy))
+        dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1)  # a GEMM over the voxels: the shifted-tap weight-gradient kernel, 1 tap
+        cx.put(conv.weight, dw)
     else:
         dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil)
         cx.put(conv.weight, dw[:, :cin].contiguous() if dw.shape[1] != cin else dw)
@@ -147,6 +133,49 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
         dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil, amax=getattr(dy, "_amax", None))
         return dx
     dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil)
+    return dx
+
+
+def _aspp_fwd(cx, aspp, x, acat):
+    """SimpleASPPEVO's parallel branches (networks/equiunet2021.py:179-187): ONE launch of the direct (gather) convolution,
+    each branch writing its channel slice of the concat buffer `acat` (no torch.cat, no im2col buffer)."""
+    n, d, h, w, _ = x.shape
+    q = aspp.convs[0].weight.shape[0]
+    jobs = []
+    for i, (k, dl) in enumerate(zip(aspp.kernel_sizes, aspp.dilations)):
+        conv = aspp.convs[i]
+        wpk = ops.pack_weights_direct(conv.weight, cx.dtype, PACK_FWD)
+        jobs.append(([(x, wpk, k, dl)], _flat(conv.bias), acat[..., i * q:(i + 1) * q]))
+    for j0 in range(0, len(jobs), 4):
+        ops.dconv_run(jobs[j0:j0 + 4], n, d, h, w, cx.dtype)
+    return x
+
+
+def _aspp_bwd(cx, aspp, x, d_acat):
+    """Weight / bias gradients of the branches (shifted-tap weight-gradient kernel: 1 tap for k = 1, 27 shifted taps for
+    the dilated ones) and the input gradient as ONE launch whose accumulators sum the four branches."""
+    n, d, h, w, _ = x.shape
+    q = aspp.convs[0].weight.shape[0]
+    db_all = ops.channel_dot(d_acat).sum(0)
+    terms = []
+    for i, (k, dl) in enumerate(zip(aspp.kernel_sizes, aspp.dilations)):
+        conv = aspp.convs[i]
+        dyi = d_acat[..., i * q:(i + 1) * q]
+        dw, _ = ops.conv3d_wgrad_shift(x, dyi, k, dl)
+        cx.put(conv.weight, dw)
+        cx.put(conv.bias, db_all[i * q:(i + 1) * q])
+        terms.append((dyi, ops.pack_weights_direct(conv.weight, cx.dtype, PACK_DGRAD), k, dl))
+    dx = ops.new_act(n, d, h, w, x.shape[-1], cx.dtype, x.device)
+    if len(terms) <= 4:
+        ops.dconv_run([(terms, None, dx)], n, d, h, w, cx.dtype)
+    else:  # (more than four branches: the reference's constructor allows any number)
+        parts = []
+        for j0 in range(0, len(terms), 4):
+            part = dx if j0 == 0 else torch.empty_like(dx)
+            ops.dconv_run([(terms[j0:j0 + 4], None, part)], n, d, h, w, cx.dtype)
+            parts.append(part)
+        for part in parts[1:]:
+            dx += part
     return dx
 
 
@@ -238,12 +267,8 @@ class _AsspFn(torch.autograd.Function):
         down3, rb3 = _block_fwd(cx, m.encoder3, pool(down2))
         down4, rb4 = _block_fwd(cx, m.encoder4, pool(down3))
         # ASPP (:299, :187-189): the four branches write into channel slices of one buffer
-        q4 = f[3] // 4
         acat = ops.new_act(n, d // 8, h // 8, w // 8, f[3], dtype, dev)
-        ra = []
-        for i, (k, dl) in enumerate(zip(m.aspp.kernel_sizes, m.aspp.dilations)):
-            _, _, sv = _conv_any_fwd(cx, m.aspp.convs[i], down4, dl, False, out=acat[..., i * q4:(i + 1) * q4])
-            ra.append(sv)
+        ra = _aspp_fwd(cx, m.aspp, down4, acat)
         assp, _, rk1 = _conv_evo_fwd(cx, m.aspp.conv_k1.conv, m.aspp.conv_k1.evo, acat)
         # bridges (:302-304) and decoder (:306-320): bridge / up-sample outputs land in concat buffers
         cat1 = ops.new_act(n, d, h, w, 2 * h0, dtype, dev)
@@ -303,11 +328,7 @@ class _AsspFn(torch.autograd.Function):
         dcat3 = _block_bwd(cx, R["rd3"], d_up3)
         d_assp = _conv_evo_bwd(cx, R["ru3"], ops.upsample_bwd(dcat3[..., h2:], 2))
         d_acat = _conv_evo_bwd(cx, R["rk1"], d_assp)
-        q4 = f[3] // 4
-        d_down4 = None
-        for i in range(len(m.aspp.convs)):
-            dxi = _conv_any_bwd(cx, m.aspp.convs[i], R["ra"][i], d_acat[..., i * q4:(i + 1) * q4])
-            d_down4 = dxi if d_down4 is None else d_down4 + dxi
+        d_down4 = _aspp_bwd(cx, m.aspp, R["ra"], d_acat)
         d_p3 = _block_bwd(cx, R["rb4"], d_down4)
         d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=_conv_evo_bwd(cx, R["rbr3"], dcat3[..., :h2]), with_avg=True)
         d_p2 = _block_bwd(cx, R["rb3"], d_down3)

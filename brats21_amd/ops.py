@@ -682,35 +682,73 @@ def channel_scale(a, scale, add=None, out=None, amax=None):
     return out
 
 
-def im2col3(x, dil):
+_DCONV_JOB = np.dtype([("term", [("x", "<u8"), ("w", "<u8"), ("xpitch", "<i4"), ("cin", "<i4"), ("ksize", "<i4"), ("dil", "<i4")], (4,)),
+                       ("nterms", "<i4"), ("rows", "<i4"), ("bias", "<u8"), ("y", "<u8"), ("ypitch", "<i4"), ("reserved", "<i4")])
+# == brats_dconv_job (include/brats_hip.h)
+
+
+def pack_weights_direct(w, dtype, mode, cin_off=0, cin_cnt=None):
+    """w [Cout, Cin, k, k, k] f32 -> the fragment order of the direct (gather) convolution, dconv_run().  Cached under
+    torch.no_grad() exactly like pack_weights()."""
+    key = None
+    if not torch.is_grad_enabled():
+        key = (id(w), "direct", str(dtype), mode, cin_off, cin_cnt)
+        hit = _cache_get(key, w)
+        if hit is not None:
+            return hit
+    cout_w, cin_w, k = w.shape[0], w.shape[1], w.shape[2]
+    cnt = cin_w - cin_off if cin_cnt is None else cin_cnt
+    kdim, rows = (cnt, cout_w) if mode == PACK_FWD else (cout_w, cnt)
+    code = _code(dtype)
+    nbytes = _lib.lib().brats_dconv_packed_bytes(code, k, kdim, rows)
+    if nbytes == 0:
+        raise _lib.BratsHipError(f"pack_weights_direct: K channels {kdim} must be a multiple of {16 if code == BF16 else 8}")
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        wd = wd.contiguous().float()
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(_lib.lib().brats_dconv_pack_weights(wd.data_ptr(), packed.data_ptr(), code, mode, k, cout_w, cin_w, cin_off, cnt,
+                                                   _stream()), "dconv_pack_weights")
+    if key is not None:
+        _cache_put(key, w, packed)
+    return packed
+
+
+def dconv_run(jobs, n, d, h, w, dtype):
+    """One launch of the direct (gather) convolution.  jobs: up to 4 of (terms, bias | None, out) with terms = up to 4 of
+    (x, packed_w, ksize, dil); out[..., :] = bias + sum over the terms of conv(x, w).  x / out: NDHWC tensors or
+    channel-slice views of [n, d, h, w, *]."""
+    rec = np.zeros(len(jobs), _DCONV_JOB)
+    keep = []
+    for j, (terms, bias, out) in enumerate(jobs):
+        optr, rows, opitch = _desc(out)
+        if out.dtype != dtype or tuple(out.shape[:4]) != (n, d, h, w):
+            raise _lib.BratsHipError("dconv_run: bad output tensor")
+        rec[j]["nterms"], rec[j]["rows"], rec[j]["y"], rec[j]["ypitch"] = len(terms), rows, optr, opitch
+        rec[j]["bias"] = _f32(bias) or 0
+        for t, (x, wpk, ksize, dil) in enumerate(terms):
+            xptr, cin, xpitch = _desc(x)
+            if x.dtype != dtype or tuple(x.shape[:4]) != (n, d, h, w):
+                raise _lib.BratsHipError("dconv_run: bad input tensor")
+            rec[j]["term"][t] = (xptr, wpk.data_ptr(), xpitch, cin, ksize, dil)
+            keep.append(wpk)
+    buf = rec.tobytes()
+    _lib.check(_lib.lib().brats_dconv_run(buf, len(jobs), _code(dtype), n, d, h, w, _stream()), "dconv_run")
+
+
+def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False):
+    """dW [cout, cin, k, k, k] f32 (and dbias) of a 1x1x1 convolution, or of a 3x3x3 convolution at any dilation
+    (shifted-tap form of the weight-gradient kernel: the ASPP branches with dilation 4 / 6)."""
     ptr, c, p = _desc(x)
+    dptr, cout, dp = _desc(dy)
     n, d, h, w, _ = x.shape
-    col = new_act(n, d, h, w, 27 * c, x.dtype, x.device)
-    _lib.check(_lib.lib().brats_im2col3(ptr, p, col.data_ptr(), _code(x.dtype), n, c, d, h, w, dil, _stream()), "im2col3")
-    return col
-
-
-def col2im3(dcol, c, dil):
-    n, d, h, w, _ = dcol.shape
-    dx = new_act(n, d, h, w, c, dcol.dtype, dcol.device)
-    _lib.check(_lib.lib().brats_col2im3(dcol.data_ptr(), dx.data_ptr(), c, _code(dcol.dtype), n, c, d, h, w, dil, _stream()),
-               "col2im3")
-    return dx
-
-
-def wgrad_1x1(x, dy):
-    """dW [cout, cin] f32 of a 1x1x1 conv: a plain GEMM dy^T @ x over the voxels -> library GEMM
-    (rocBLAS through torch.matmul; the design rules reserve hand-written MFMA for the fused hot ops)."""
-    c, co = x.shape[-1], dy.shape[-1]
-    x2 = x.reshape(-1, c) if x.is_contiguous() else x.contiguous().reshape(-1, c)
-    d2 = dy.reshape(-1, co) if dy.is_contiguous() else dy.contiguous().reshape(-1, co)
-    if x2.dtype == torch.float32:
-        return torch.matmul(d2.t(), x2)
-    # bf16: split the voxel axis so each GEMM output (rounded to bf16 by the library) sums few voxels,
-    # then add the slabs in f32
-    v = x2.shape[0]
-    s = 64
-    while v % s:
-        s //= 2
-    part = torch.bmm(d2.view(s, v // s, co).transpose(1, 2), x2.view(s, v // s, c))
-    return part.float().sum(0)
+    code = _code(x.dtype)
+    nbytes = _lib.lib().brats_conv3d_wgrad_shift_ws_bytes(code, ksize, n, d, h, w, c, cout)
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, c, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
+    with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_wgrad_shift(ptr, c, p, dptr, dp, ws.data_ptr(), dw.data_ptr(),
+                                                       db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
+                                                       cout, _stream()), "conv3d_wgrad_shift")
+    return dw, db

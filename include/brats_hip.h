@@ -123,6 +123,15 @@ int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c
                        const void* dy, int dypitch, float* ws, float* dw, float* dbias,
                        int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                        brats_stream_t s);
+/* Weight gradient in the "shifted-tap" form: ksize = 1 (ConvEvo / bridge / upconv / ASPP k1 convolutions,
+ * networks/equiunet2021.py:212-222 -- a GEMM over the voxels) and ksize = 3 at ANY dilation >= 1 (the ASPP branches with
+ * dilation 4 and 6, :121-189, whose halo does not fit LDS): one workgroup per (tap, channel block, voxel range), its X tile
+ * is the dY tile's box shifted by the tap.  Same split-K slabs + fixed-order reduction as brats_conv3d_wgrad.
+ * dw = [cout][cin][ksize^3] f32, overwritten; dbias (may be NULL) = sum_v dy. */
+size_t brats_conv3d_wgrad_shift_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int cin, int cout);
+int brats_conv3d_wgrad_shift(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
+                             float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
+                             brats_stream_t s);
 
 /* ---- GroupNorm(8) + activation (nn.GroupNorm networks/factory.py:179-182, get_act :195-200) ---
  * finalize: per-(n,channel) tile partials -> per-(n,group) mean / rstd (biased var, eps) and the
@@ -179,12 +188,23 @@ int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, 
 int brats_channel_scale(const void* a, int apitch, const float* scale /*[N][C]*/, const float* add /*[N][C] or NULL*/,
                         void* dst, int dpitch, int dtype, int N, int voxels, int C,
                         float* amax /* optional, zero before the call: receives max|dst| */, brats_stream_t s);
-/* ---- im2col / col2im for dilations whose halo does not fit LDS (ASPP d = 4, 6, equiunet2021.py:257-259):
- * col [N][D*H*W][27*C] dense; the dilated conv becomes brats_conv3d_fwd(ksize = 1) over 27*C channels. */
-int brats_im2col3(const void* x, int xpitch, void* col, int dtype, int N, int C, int D, int H, int W,
-                  int dil, brats_stream_t s);
-int brats_col2im3(const void* dcol, void* dx, int dxpitch, int dtype, int N, int C, int D, int H, int W,
-                  int dil, brats_stream_t s);
+/* ---- direct (gather) convolution of the ASPP head (SimpleASPPEVO, networks/equiunet2021.py:121-189: four parallel
+ * nn.Conv3d 384 -> 96 with kernel 1 / 3, dilation 1 / 2 / 4 / 6, "same" padding, bias; torch.cat at :187; and their input
+ * gradients).  The halo of dilation 4 / 6 does not fit LDS (it is larger than the 16^3 volume), but the volume lives in L2:
+ * the MFMA B operand is gathered straight from global memory, taps outside the volume read zeros through the buffer
+ * range check.  One launch = up to 4 jobs; a job's output [N*D*H*W][rows] (channel pitch ypitch, may be a channel slice
+ * of a wider buffer) is bias + the sum of up to 4 terms, term = conv(x (cin channels at pitch xpitch), w) with
+ * w = brats_dconv_pack_weights() output.  Forward of the ASPP head: 4 jobs x 1 term, each writing its slice of the concat
+ * buffer; input gradient: 1 job x 4 terms (mode = BRATS_PACK_DGRAD weights), the four branch gradients summed in the
+ * accumulators.  cin must be a multiple of 16 (bf16) / 8 (f32), rows a multiple of 4.  `jobs` is a HOST array. */
+typedef struct { const void* x; const void* w; int xpitch, cin, ksize, dil; } brats_dconv_term;
+typedef struct { brats_dconv_term term[4]; int nterms, rows; const float* bias; void* y; int ypitch, reserved; } brats_dconv_job;
+size_t brats_dconv_packed_bytes(int dtype, int ksize, int kdim, int rows);
+/* w: [Cout_w][Cin_w][k][k][k] f32 (torch layout); FWD: rows = Cout_w, K = the Cin_w slice [cin_off, cin_off + cin_cnt);
+ * DGRAD: rows = the Cin_w slice, K = Cout_w, taps flipped (as brats_conv3d_pack_weights). */
+int brats_dconv_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize, int cout_w, int cin_w,
+                             int cin_off, int cin_cnt, brats_stream_t s);
+int brats_dconv_run(const brats_dconv_job* jobs, int njobs, int dtype, int N, int D, int H, int W, brats_stream_t s);
 
 /* ---- pooling (nn.MaxPool3d(2,2) equiunet2020.py:433; MONAI MaxAvgPool equiunet2021.py:261) ---- */
 int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C,

@@ -56,36 +56,70 @@ def test_evonorm_fwd_bwd_matches_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_dilated_im2col_conv_and_1x1(dtype):
-    """ASPP branches: dilation 4 / 6 via im2col + 1x1 implicit GEMM, and the native 1x1 kernel, vs F.conv3d."""
+@pytest.mark.parametrize("size,cin,q", [((8, 8, 8), 32, 16), ((16, 16, 16), 96, 32), ((5, 6, 7), 32, 48)])
+def test_aspp_direct_kernels_vs_torch(dtype, size, cin, q):
+    """SimpleASPPEVO's branches (networks/equiunet2021.py:179-187; kernel 1 / 3, dilation 1 / 2 / 4 / 6) on the direct
+    (gather) convolution -- forward as ONE launch writing four channel slices, input gradient as ONE launch summing
+    four terms -- and their weight gradients on the shifted-tap kernel, against F.conv3d / autograd.  The ragged
+    5x6x7 volume exercises taps that leave the volume in every direction and partial voxel fragments."""
     from brats21_amd import ops
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 32, 8, 8, 8, generator=g).to(dtype).float()
-    for k, dil in ((3, 4), (3, 6), (1, 1)):
-        w = (torch.randn(16, 32, k, k, k, generator=g) * 0.05).to(dtype).float()
-        b = torch.randn(16, generator=g) * 0.1
-        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
-        y_ref = F.conv3d(xr, wr, b, 1, (k - 1) // 2 * dil, dil)
-        dy = torch.randn(y_ref.shape, generator=g).to(dtype).float()
-        y_ref.backward(dy)
-        xd, dyd = _to_ndhwc(x, dtype), _to_ndhwc(dy, dtype)
-        if k == 3:
-            col = ops.im2col3(xd, dil)
-            w1 = w.permute(0, 2, 3, 4, 1).reshape(16, 27 * 32, 1, 1, 1).to(DEV)
-        else:
-            col, w1 = xd, w.to(DEV)
-        y, _ = ops.conv3d(col, ops.pack_weights(w1, dtype, ops.PACK_FWD), 16, 1, 1, bias=b.to(DEV))
-        tol = dict(atol=3e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=4e-2, rtol=2e-2)
-        torch.testing.assert_close(_from_ndhwc(y), y_ref.detach(), **tol)
-        dcol, _ = ops.conv3d(dyd, ops.pack_weights(w1, dtype, ops.PACK_DGRAD), w1.shape[1], 1, 1)
-        dx = ops.col2im3(dcol, 32, dil) if k == 3 else dcol
-        tol = dict(atol=5e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=6e-2, rtol=3e-2)
-        torch.testing.assert_close(_from_ndhwc(dx), xr.grad, **tol)
-        dw = ops.wgrad_1x1(col, dyd).cpu()
-        dw = dw.view(16, 3, 3, 3, 32).permute(0, 4, 1, 2, 3) if k == 3 else dw.view(16, 32, 1, 1, 1)
-        tol = dict(atol=2e-4, rtol=1e-4) if dtype == torch.float32 else dict(atol=0.15, rtol=3e-2)
-        torch.testing.assert_close(dw, wr.grad, **tol)
+    n = 2
+    branches = ((1, 1), (3, 2), (3, 4), (3, 6))
+    x = torch.randn(n, cin, *size, generator=g).to(dtype).float()
+    ws = [(torch.randn(q, cin, k, k, k, generator=g) * (1.0 / (cin * k ** 3)) ** 0.5).to(dtype).float() for k, _ in branches]
+    bs = [torch.randn(q, generator=g) * 0.1 for _ in branches]
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    y_ref = torch.cat([F.conv3d(xr, w, b, 1, (k - 1) // 2 * dl, dl) for w, b, (k, dl) in zip(wr, bs, branches)], 1)
+    dy = torch.randn(y_ref.shape, generator=g).to(dtype).float()
+    y_ref.backward(dy)
+    xd, dyd = _to_ndhwc(x, dtype), _to_ndhwc(dy, dtype)
+    wd = [w.to(DEV) for w in ws]
+    # forward: four jobs, one launch, channel slices of one buffer
+    acat = torch.full((n, *size, 4 * q), float("nan"), dtype=dtype, device=DEV)
+    jobs = [([(xd, ops.pack_weights_direct(w, dtype, ops.PACK_FWD), k, dl)], b.to(DEV), acat[..., i * q:(i + 1) * q])
+            for i, (w, b, (k, dl)) in enumerate(zip(wd, bs, branches))]
+    ops.dconv_run(jobs, n, *size, dtype)
+    tol = dict(atol=3e-5, rtol=1e-5) if dtype == torch.float32 else dict(atol=4e-2, rtol=2e-2)
+    torch.testing.assert_close(_from_ndhwc(acat), y_ref.detach(), **tol)
+    # input gradient: one job, four terms summed in the accumulators
+    dx = torch.full((n, *size, cin), float("nan"), dtype=dtype, device=DEV)
+    terms = [(dyd[..., i * q:(i + 1) * q], ops.pack_weights_direct(w, dtype, ops.PACK_DGRAD), k, dl)
+             for i, (w, (k, dl)) in enumerate(zip(wd, branches))]
+    ops.dconv_run([(terms, None, dx)], n, *size, dtype)
+    tol = dict(atol=1e-4, rtol=1e-5) if dtype == torch.float32 else dict(atol=8e-2, rtol=3e-2)
+    torch.testing.assert_close(_from_ndhwc(dx), xr.grad, **tol)
+    # weight gradients: shifted-tap kernel (1 tap / 27 taps at any dilation), + bias gradient
+    for i, (k, dl) in enumerate(branches):
+        dw, db = ops.conv3d_wgrad_shift(xd, dyd[..., i * q:(i + 1) * q], k, dl, want_dbias=True)
+        scale = float(wr[i].grad.abs().max())
+        tol = dict(atol=2e-5 * scale + 1e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2 * scale, rtol=3e-2)
+        torch.testing.assert_close(dw.cpu(), wr[i].grad, **tol)
+        torch.testing.assert_close(db.cpu(), dy[:, i * q:(i + 1) * q].sum((0, 2, 3, 4)), atol=1e-3 if dtype == torch.float32 else 0.5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,size", [(48, 24, (16, 16, 32)), (96, 48, (12, 9, 20)), (384, 96, (4, 4, 4)), (16, 8, (8, 8, 8))])
+def test_wgrad_1x1_native_vs_torch(dtype, cin, cout, size):
+    """Weight gradient of the 1x1x1 convolutions (ConvEvo: bridge / upconv / ASPP conv_k1, networks/equiunet2021.py:
+    212-222) on the shifted-tap MFMA kernel (no library GEMM), incl. a channel-slice dy view and ragged tiles."""
+    from brats21_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n = 2
+    x = torch.randn(n, cin, *size, generator=g).to(dtype).float()
+    dyw = torch.randn(n, cout + 8, *size, generator=g).to(dtype).float()
+    xd, dywd = _to_ndhwc(x, dtype), _to_ndhwc(dyw, dtype)
+    dyd = dywd[..., 8:]  # a channel-slice view (pitch cout + 8)
+    dw, db = ops.conv3d_wgrad_shift(xd, dyd, 1, want_dbias=True)
+    ref = torch.einsum("ncdhw,nkdhw->kc", x.double(), dyw[:, 8:].double())
+    scale = float(ref.abs().max())
+    tol = dict(atol=2e-6 * scale + 1e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=1e-2 * scale, rtol=2e-2)
+    torch.testing.assert_close(dw.cpu().double().view(cout, cin), ref, **tol)
+    torch.testing.assert_close(db.cpu().double(), dyw[:, 8:].double().sum((0, 2, 3, 4)), atol=1e-3 if dtype == torch.float32 else 0.5, rtol=1e-3)
+    dw2, _ = ops.conv3d_wgrad_shift(xd, dyd, 1)
+    assert torch.equal(dw, dw2)  # fixed-order split-K reduction: bitwise reproducible
 
 
 def test_assp_f32_matches_reference_golden(golden_dir):
