@@ -183,7 +183,7 @@ def main():
                              weight_decay=1e-5, use_gc=args.use_gc, capturable=args.graph)
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
-    buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None
+    buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None  # BRATS_DDP_BF16=1: bf16 transport
     size = (args.patch,) * 3
     x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
     t = synth.nested_spheres(args.batch, size, device=dev)
@@ -211,12 +211,30 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ops.TIMER = timer if (timer is not None and i % stride == 0) else None
+        if buckets is not None:
+            buckets.measure = i % stride == 0  # two HIP events around the collective waits of the sampled steps
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    ddp_info = None
+    if buckets is not None:
+        # data-parallel accounting: per-rank step time, the collectives' stand-alone cost, and how much of it the overlap
+        # with the backward kernels hid (exposed = GPU time finish() waited for them in the sampled steps)
+        mine = torch.tensor([elapsed / args.steps * 1e3, buckets.exposed_ms() or 0.0], device=dev, dtype=torch.float64)
+        if world > 1:
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+        else:
+            both = [mine]
+        ar = buckets.allreduce_ms()
+        exposed = max(float(b[1]) for b in both)
+        ddp_info = {"ms_per_step_by_rank": [round(float(b[0]), 3) for b in both], "buckets": len(buckets._plan),
+                    "payload_MB": round(buckets.payload_bytes() / 1e6, 1), "comm_dtype": str(buckets.comm_dtype).replace("torch.", ""),
+                    "allreduce_ms": round(ar, 3), "exposed_ms": round(exposed, 3),
+                    "overlap_frac": round(max(0.0, 1.0 - exposed / ar), 3) if ar > 0 else None}
     if world > 1:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -280,6 +298,8 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
         "roofline": roofline,
     }
+    if ddp_info is not None:
+        res["ddp"] = ddp_info
     if world == 1 and not args.no_infer:
         res["inference"] = inference_bench(model, dev, args)
     if world == 1 and not args.no_cpu_baseline:

@@ -54,7 +54,14 @@ def shard_indices(n_items, rank, world, epoch=0, shuffle=True, seed=0):
 class GradientBuckets:
     """Bucketed, asynchronous gradient averaging for one model replica."""
 
-    def __init__(self, model, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, model, bucket_bytes=32 << 20, process_group=None, comm_dtype=None):
+        """comm_dtype=torch.bfloat16 (or BRATS_DDP_BF16=1): gradients travel as bf16 (half the xGMI payload: 33 MB instead
+        of 66.5 MB for EquiUnetASSPEvo-48) and are summed in bf16 by the collective; p.grad stays f32.  Default: f32."""
+        if comm_dtype is None and os.environ.get("BRATS_DDP_BF16", "0") != "0":
+            comm_dtype = torch.bfloat16
+        self.comm_dtype = comm_dtype or torch.float32
+        self.measure = False       # bench.py: record how long finish() has to wait for the collectives (GPU time)
+        self.exposed = []          # [(event before the waits, event after them)]
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -107,6 +114,8 @@ class GradientBuckets:
         self._where = {idx: (b, off) for b, bucket in enumerate(plan) for idx, off, _ in bucket}
         dev = self.params[0].device
         self._flat = [torch.zeros(sum(n for _, _, n in bucket), dtype=torch.float32, device=dev) for bucket in plan]
+        # reduced-precision transport: the collective runs on a bf16 image of the bucket
+        self._wire = [torch.zeros_like(f, dtype=self.comm_dtype) for f in self._flat] if self.comm_dtype != torch.float32 else None
 
     def _start(self):
         self._filled = [0] * len(self._plan)
@@ -126,7 +135,11 @@ class GradientBuckets:
 
     def _launch(self, b):
         if self.world > 1:
-            self._handles[b] = dist.all_reduce(self._flat[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            buf = self._flat[b]
+            if self._wire is not None:
+                buf = self._wire[b]
+                buf.copy_(self._flat[b])
+            self._handles[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- producer side ----------------------------------------------------------------------------
     def push(self, param_index, grad):
@@ -177,10 +190,20 @@ class GradientBuckets:
                     if g.data_ptr() != dst.data_ptr():  # (p.grad may still be last step's view of this very bucket)
                         dst.copy_(g.reshape(-1))
                 self._launch(b)
+        ev = None
+        if self.measure and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for h in self._handles:
             if h is not None:
                 h.wait()
+        if ev is not None:
+            ev[1].record()
+            self.exposed.append(ev)
         if self.world > 1:
+            if self._wire is not None:
+                for f, w in zip(self._flat, self._wire):
+                    f.copy_(w)
             torch._foreach_mul_(self._flat, 1.0 / self.world)  # one multi-tensor launch instead of one mul per parameter
         for b, bucket in enumerate(self._plan):
             for idx, off, n in bucket:
@@ -191,4 +214,34 @@ class GradientBuckets:
         self._handles = []
 
     def payload_bytes(self):
-        return sum(f.numel() for f in self._flat) * 4 if self._flat else 0
+        """Bytes every rank contributes to the all-reduces of one step."""
+        esz = 4 if self.comm_dtype == torch.float32 else 2
+        return sum(f.numel() for f in self._flat) * esz if self._flat else 0
+
+    def exposed_ms(self):
+        """Mean GPU time per measured step that finish() spent waiting for collectives (what the overlap did NOT hide)."""
+        if not self.exposed:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.exposed) / len(self.exposed)
+
+    def allreduce_ms(self, reps=5):
+        """Blocking time of one step's collectives on scratch copies of the buckets (no compute beside them): the cost
+        that overlap has to hide.  Call outside the timed region; every rank must call it."""
+        if self.world <= 1 or not self._flat:
+            return 0.0
+        scratch = [torch.zeros_like(w) for w in (self._wire or self._flat)]
+        on_gpu = scratch[0].is_cuda
+        for s in scratch:
+            dist.all_reduce(s, group=self.group)  # warm-up (connection set-up)
+        if on_gpu:
+            torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hs = [dist.all_reduce(s, group=self.group, async_op=True) for s in scratch]
+            for h in hs:
+                h.wait()
+        if on_gpu:
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3

@@ -151,6 +151,50 @@ def test_gradient_buckets_gloo_world2(use_push):
     assert got[0][0] == 0 and got[1][0] == 1 and got[0][1] != got[1][1]  # different shards -> different losses
 
 
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _Net()
+    torch.manual_seed(300 + rank)
+    buckets = GradientBuckets(net, bucket_bytes=64, comm_dtype=torch.bfloat16)
+    for step in range(3):
+        net.zero_grad(set_to_none=True)
+        net(torch.randn(4, 6)).pow(2).mean().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        if step > 0:
+            for idx in reversed(range(len(local))):
+                if local[idx] is not None:
+                    net._grad_sink(idx, local[idx])
+        buckets.finish()
+        for p, g in zip(net.parameters(), local):
+            if g is None:
+                continue
+            assert p.grad.dtype == torch.float32  # the optimizer still sees f32 gradients
+            ref = g.bfloat16()
+            dist.all_reduce(ref)  # what a bf16 transport computes: rounded per rank, summed in bf16
+            torch.testing.assert_close(p.grad, ref.float() / world, atol=1e-6, rtol=1e-5)
+            dist.all_reduce(g)
+            torch.testing.assert_close(p.grad, g / world, atol=2e-2 * float(g.abs().max()) / world + 1e-6, rtol=2e-2)
+    assert buckets.payload_bytes() == 2 * sum(p.numel() for p in (net.a.weight, net.a.bias, net.b.weight, net.b.bias))
+    assert buckets.allreduce_ms(2) >= 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(rank)
+
+
+def test_bf16_transport_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
 def test_patient_sharding():
     world = 8
     shards = [shard_indices(21, r, world, epoch=3) for r in range(world)]
