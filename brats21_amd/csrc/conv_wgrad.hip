@@ -477,6 +477,224 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// All-taps kernel, second form (48-channel ci blocks; the default since round 2).  Same roles and MFMA phase as above;
+// what changed is everything around the MFMAs, which by ablation cost as much as they did:
+//  * the X halo tile (61 KB) is fetched by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass --
+//    11 ds_write_b128 per thread and 32 VGPRs less) into one of TWO X buffers, for the NEXT tile, while the MFMA phase
+//    of the current tile runs out of the other (2 x 61 KB + dY 24 KB = 146 KB of the CU's 160 KB); the flat piece order
+//    P = tid + 512 i is exactly the lane-linear image LDS-DMA writes, pieces outside the volume get an out-of-range
+//    offset and the DMA writes zeros;
+//  * only the dY tile (3 pieces per thread) still goes through registers;
+//  * per-piece byte offsets are computed once per kernel: an interior tile (halo box inside the volume, ~2/3 of all
+//    tiles at 128^3) costs ONE v_add per piece instead of ~20 VALU instructions of unpack / range tests / multiply-adds,
+//    which used to run in both waves of every SIMD at the same time, with the matrix pipe idle;
+//  * the freed registers carry one more B fragment in flight (prefetch distance 3).
+struct Wg3b {
+  static constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, HVOX = HZ * HY * HX;   // 6 x 6 x 18
+  static constexpr int SX = 96, SY = 96, XPPV = 6, YPPV = 6;
+  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;   // 3888, 1536
+  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;   // 8, 3 per thread
+  static constexpr int XB = XI * 512 * 16;                               // 65536: a whole number of 1-KB DMA rows per wave
+  static constexpr int LDS = 2 * XB + WG_VOX * SY;                       // 155648
+  static constexpr int PAIRS = 81, PPW = 11;
+};
+
+__global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const WgradParams p) {
+  typedef bf16_t T;
+  using G = Wg3b;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldy = lds + 2 * G::XB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, v = lane & 15;
+  const int lane8 = blockIdx.x % p.nlane, gsub = blockIdx.x / p.nlane, g8 = gridDim.x / p.nlane;
+  const int split = blockIdx.x;
+  const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
+  const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
+  const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 48;
+  const T* xsrc;
+  int xpitch;
+  if (ci0 < p.c1) { xsrc = (const T*)p.x1 + ci0; xpitch = p.p1; }
+  else { xsrc = (const T*)p.x2 + (ci0 - p.c1); xpitch = p.p2; }
+  const int xpb = xpitch * 2, ypb = p.dyp * 2;
+
+  // static per-lane piece data: byte offset from the halo corner (INT_MIN = never valid: origin + INT_MIN is beyond any
+  // buffer), and the packed coordinates hz | hy << 3 | hx << 6 for the range tests of boundary tiles
+  int xoffs[G::XI], xcode[G::XI];
+#pragma unroll
+  for (int i = 0; i < G::XI; ++i) {
+    const int P = tid + 512 * i;
+    const int vox = P / G::XPPV, part = P % G::XPPV;
+    const int hx = vox % G::HX, hy = (vox / G::HX) % G::HY, hz = vox / (G::HX * G::HY);
+    const bool ok = P < G::XPIECES;
+    xoffs[i] = ok ? ((hz * p.H + hy) * p.W + hx) * xpb + part * 16 : (int)0x80000000;
+    xcode[i] = ok ? (hz | hy << 3 | hx << 6 | 1 << 14) : 0;
+  }
+  const unsigned xsample_bytes = (unsigned)p.D * p.H * p.W * xpitch * 2;
+  const unsigned ysample_bytes = (unsigned)p.D * p.H * p.W * p.dyp * 2;
+
+  int poff[G::PPW];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 8 * jj;
+    const int t = pid / 3, nn = pid % 3;
+    poff[jj] = pid < G::PAIRS ? (((t / 9) * G::HY + (t / 3) % 3) * G::HX + t % 3) * G::SX + nn * 32 : 0;
+  }
+  f32x4 acc[G::PPW][3];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ry[G::YI];
+  // The loads of a tile -- X -> LDS buffer `buf` by 8 LDS-DMA instructions per wave, dY -> 3 register loads -- as a
+  // scalar set-up plus per-piece issue functions.  Issuing an LDS-DMA instruction stalls the issuing wave for 100-300
+  // cycles (measured with s_memtime stamps, scripts/probes/wgrad_stamps.*: 2400 of a tile's 13000 cycles for the eight
+  // of a wave, 8000 for the MFMA phase, 2100 waiting for the slowest wave at the barrier);
+  // all pieces of the NEXT tile are issued in one batch right before the MFMA phase (alternatives: see the call site).
+  // Range tests are branch-free (an interior tile ORs an all-ones mask in).
+  struct TileLoads {
+    __amdgpu_buffer_rsrc_t xrs, yrs;
+    int xorg, yorg;
+    unsigned zm, ym, xm, inter;  // bit h: halo plane / row / column h is inside the volume; inter = all ones for an interior tile
+    char* xdst;
+  };
+  auto setup_loads = [&](int tile, int buf) {
+    TileLoads L;
+    int bt = tile;
+    const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
+    const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
+    const int z0 = (bt % p.tz) * WG_TZ;
+    const int n = bt / p.tz;
+    const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+    L.xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0, (int)xsample_bytes, 0x00020000);
+    L.yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0), (short)0, (int)ysample_bytes, 0x00020000);
+    L.xorg = (((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * xpb;  // byte offset of the halo corner (negative at the low faces)
+    L.yorg = ((z0 * p.H + y0) * p.W + x0) * ypb;
+    L.xdst = lds + buf * G::XB + wave * 1024;  // wave-uniform: the DMA adds lane * 16
+    // bit h set <=> 0 <= o - 1 + h < size  <=>  max(0, 1 - o) <= h < min(HN, size - o + 1)
+    auto inside = [](int o, int size, int hn) {
+      const int lo = o >= 1 ? 0 : 1 - o, hi = size - o + 1 < hn ? size - o + 1 : hn;
+      return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    L.zm = inside(z0, p.D, G::HZ); L.ym = inside(y0, p.H, G::HY); L.xm = inside(x0, p.W, G::HX);
+    L.inter = (L.zm == (1u << G::HZ) - 1 && L.ym == (1u << G::HY) - 1 && L.xm == (1u << G::HX) - 1) ? 1u : 0u;
+    return L;
+  };
+  auto issue_x = [&](const TileLoads& L, auto i_) {
+    constexpr int i = i_;
+    const int c = xcode[i];
+    const unsigned ok = (unsigned)(c >> 14) & (L.inter | ((L.zm >> (c & 7)) & (L.ym >> ((c >> 3) & 7)) & (L.xm >> ((c >> 6) & 31)))) & 1u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(L.xrs, (__attribute__((address_space(3))) void*)(L.xdst + i * 8192), 16,
+                                             (L.xorg + xoffs[i]) | ((int)ok - 1), 0, 0, 0);
+  };
+  auto issue_y = [&](const TileLoads& L, auto i_) {
+    constexpr int i = i_;
+    // (3 pieces per tile: offset and coordinates are recomputed here instead of living in 6 registers)
+    const int P = tid + 512 * i;
+    const int vox = P / G::YPPV, part = P % G::YPPV;
+    const int z = vox >> 6, y = (vox >> 4) & 3, x = vox & 15;
+    const int yo = ((z * p.H + y) * p.W + x) * ypb + part * 16;
+    const unsigned ok = (L.inter | ((L.zm >> (z + 1)) & (L.ym >> (y + 1)) & (L.xm >> (x + 1)))) & 1u;  // the dY tile = the halo box without its rim
+    ry[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(L.yrs, (L.yorg + yo) | ((int)ok - 1), 0, 0));
+  };
+
+  const int tile_first = lane8 * tpx + gsub;
+  const int qq = v >> 2, pp = v & 3;
+  const int ybase = (4 * q + qq) * G::SY + pp * 8;
+  const int xbase = (4 * q + qq) * G::SX + pp * 8;
+  int cur = 0;
+#ifdef BRATS_WGRAD_STAMPS  // diagnostic build only (scripts/probes/wgrad_stamps.sh): where does a tile's time go?
+  long long tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define WG_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#endif
+  if (tile_first < tile_end) {
+    const TileLoads L = setup_loads(tile_first, 0);
+    static_for<0, G::XI>([&](auto i_) { issue_x(L, i_); });
+    static_for<0, G::YI>([&](auto i_) { issue_y(L, i_); });
+  }
+  for (int tile = tile_first; tile < tile_end; tile += g8, cur ^= 1) {
+    // my DMA pieces of this tile have landed (they were issued during the previous MFMA phase); after the barrier
+    // everybody's have, and everybody is done reading dY and the other X buffer
+    WG_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(0);
+    __syncthreads();
+    WG_STAMP(1);
+#pragma unroll
+    for (int i = 0; i < G::YI; ++i) *(u32x4*)(ldy + (tid + 512 * i) * 16) = ry[i];
+    __syncthreads();
+    WG_STAMP(2);
+    const bool more = tile + g8 < tile_end;  // scalar
+    TileLoads L = setup_loads(more ? tile + g8 : tile, cur ^ 1);
+    if (!more) L.zm = L.inter = 0;  // nothing follows: every piece is dropped by the range check
+    __builtin_amdgcn_sched_barrier(0);
+    WG_STAMP(3);
+    const char* ldx = lds + cur * G::XB;
+    constexpr int PD = 3;
+    bf16x8 a[2][3], b[PD + 1];
+    auto read_a = [&](auto s_) {
+      constexpr int s = s_;
+      const int yoff = ybase + (32 * s) * G::SY;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
+    };
+    auto read_b = [&](auto u_) {
+      constexpr int u = u_;
+      constexpr int s = u / G::PPW, jj = u % G::PPW;
+      const int xoff = xbase + (((s >> 1) * G::HY + 2 * (s & 1)) * G::HX) * G::SX + poff[jj];
+      b[u % (PD + 1)] = tr_pair(ldx + xoff, ldx + xoff + G::HX * G::SX);
+    };
+    constexpr int NU = 8 * G::PPW;
+    // the next tile's loads, all issued here, back to back.  Measured alternatives (same box, 48 -> 48 @128^3, this form
+    // 0.48 ms): one piece every 10 u-steps inside the MFMA loop 0.53 ms (a lone LDS-DMA among MFMAs stalls its wave ~3x
+    // longer than one in a batch, and both waves of a SIMD reach it together); waves 4-7 issuing theirs in the middle of
+    // the phase 0.75 ms; only waves 4-7 issuing (16 pieces each) while waves 0-3 compute 0.71 ms.  The issue rate IS
+    // the CU's load bandwidth (~25 GB/s: 61 KB take >= 2400 cycles whoever issues them).
+    static_for<0, G::XI>([&](auto i_) { issue_x(L, i_); });
+    static_for<0, G::YI>([&](auto i_) { issue_y(L, i_); });
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(std::integral_constant<int, 0>{});
+    static_for<0, PD>([&](auto u_) { read_b(u_); });
+    static_for<0, NU>([&](auto u_) {
+      constexpr int u = u_;
+      constexpr int s = u / G::PPW, jj = u % G::PPW;
+      if constexpr (u + PD < NU) read_b(std::integral_constant<int, u + PD>{});
+      if constexpr (jj == 0 && s + 1 < 8) read_a(std::integral_constant<int, s + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+        acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+
+#ifdef BRATS_WGRAD_STAMPS
+  WG_STAMP(4);
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.z == 0) {  // behind the slabs: [split][wave][5] cycle sums
+    long long* st = (long long*)(p.ws + (size_t)gridDim.x * 27 * p.cout * p.cin) + ((size_t)blockIdx.x * 8 + wave) * 5;
+    for (int i = 0; i < 5; ++i) st[i] = tacc[i];
+  }
+#endif
+  // ---- slab: ws[split][tap][co][ci] ----
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 8 * jj;
+    if (pid < G::PAIRS) {
+      const int t = pid / 3, nn = pid % 3;
+      float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
+      const int ci = ci0 + nn * 16 + v;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
+    }
+  }
+}
+
 // dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order -> bitwise reproducible; 16-byte loads)
 // A block = 32 consecutive f32x4 elements x 8 split groups: thread (e, g) adds splits g, g+8, ... and the 8 partial
 // sums are combined in group order through LDS (one thread per element deep the kernel had 61 workgroups, each
@@ -664,11 +882,20 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
       if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3<3>::LDS, hipGetErrorString(e));
       done = true;
     }
+    static int form = -1;  // BRATS_WGRAD_ALLTAPS=1: the round-1 form (register staging, one X buffer) for same-box A/B runs
+    if (form < 0) {
+      const char* e = getenv("BRATS_WGRAD_ALLTAPS");
+      form = (e && atoi(e) == 1) ? 1 : 2;
+      hipError_t e2 = hipFuncSetAttribute((const void*)conv_wgrad_alltaps2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3b::LDS);
+      if (e2 != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3b::LDS, hipGetErrorString(e2));
+    }
     if (c2 <= 0 && c1 <= 16) {
       // the slab columns of the padded ci lanes (c1 < 16) are never written and never read (cin = c1)
       hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<1>, dim3(p.nsplit, cout / 48, 1), dim3(512), Wg3<1>::LDS, st, p);
-    } else {
+    } else if (form == 1) {
       hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<3>, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3<3>::LDS, st, p);
+    } else {
+      hipLaunchKernelGGL(conv_wgrad_alltaps2_kernel, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3b::LDS, st, p);
     }
     rc = 0;
   } else if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);

@@ -18,7 +18,7 @@ with torch.cuda.stream(s):
 torch.cuda.current_stream().wait_stream(s)
 g = torch.cuda.CUDAGraph()
 try:
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         y = x * 2
         h = dist.all_reduce(y, async_op=True)
         h.wait()
