@@ -231,6 +231,9 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
   p.N = N; p.D = D; p.H = H; p.W = W; p.cout = cout; p.rows16 = ceil_div(cout, 16);
   p.nchunks = (c1 + c2) / ck;
   p.tz = ceil_div(D, CONV_TZ); p.ty = ceil_div(H, CONV_TY); p.tx = ceil_div(W, CONV_TX);
+#ifdef BRATS_VS8_STAMPS
+  { const char* e = getenv("BRATS_VS8_STAMP_PTR"); p.stamps = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   hipStream_t st = (hipStream_t)s;
   if (ksize == 1) dil = 1;
 #define GO(T) \

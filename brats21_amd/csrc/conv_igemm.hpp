@@ -25,6 +25,9 @@ struct ConvParams {
   void* y2; int y2pitch; int ysplit;  // optional second destination for output channels >= ysplit (dgrad of a concat input)
   int N, D, H, W, cout, rows16, nchunks;
   int tz, ty, tx;
+#ifdef BRATS_VS8_STAMPS
+  long long* stamps;  // diagnostic build only
+#endif
 };
 
 constexpr int CONV_TZ = 4, CONV_TY = 4, CONV_TX = 16;  // a voxel fragment = one x-row of 16
@@ -110,7 +113,11 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       constexpr int k = k_;
       constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
 #pragma unroll
+#ifdef BRATS_VS8_FAKEW  // ablation (diagnostic build only, wrong results): every step re-reads the first 3 KB -> L1-resident weights
+      for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)(ms & 0) * rows16 + f) * 64];
+#else
       for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
+#endif
     };
     auto read_b = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
@@ -333,7 +340,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     // running sums through v_mov at every row)
     const bool full = z0 + CONV_TZ <= p.D && y0 + CONV_TY <= p.H && x0 + CONV_TX <= p.W &&
                       (ct + 1) * TL::NFW * 16 <= p.cout;  // scalar
-    if (full) {
+    if (full && G::BF && (ypit % 8) == 0 && (csub % 8) == 0 && ((size_t)ydst & 15) == 0) {
+      // bf16: 16-byte stores (the epilogue is store-ISSUE bound).  The lanes of MFMA rows q and q ^ 1 hold channels
+      // 4q..4q+3 and the next four of the SAME voxel; exchanging halves between two x-rows (v_permlane16_swap: odd 16-lane
+      // rows of the first operand <-> even rows of the second) gives every lane 8 consecutive channels of ONE voxel:
+      // rows 0 / 2 keep x-row i, rows 1 / 3 take x-row i + 1.
+      const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
+#pragma unroll
+      for (int i = 0; i < NB; i += 2) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
+        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          uint32_t pk[2][2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o[r] = acc[f][i + e][r] + bias[f][r];
+              s1[f][r] += o[r];
+              s2[f][r] += o[r] * o[r];
+            }
+            pk[e][0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+            pk[e][1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+          }
+          const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          *(u32x4*)((bf16_t*)rowp + lane_w + (f0 + f) * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+        }
+      }
+    } else if (full) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);

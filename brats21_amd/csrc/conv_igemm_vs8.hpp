@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
 
   const int lane_b = ((wm * 2) * G::HY * G::HX + wn * YB * G::HX + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;
+#ifdef BRATS_VS8_STAMPS  // diagnostic build only (scripts/probes/vs8_stamps.*)
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define VS8_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define VS8_STAMP(i) do { } while (0)
+#endif
 
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     const int c0 = chunk * CK;
@@ -95,7 +101,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
         r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
       }
     }
+    VS8_STAMP(0);  // prologue / issue of the halo loads
     if (chunk > 0) __syncthreads();
+    VS8_STAMP(1);  // barrier: everybody done with the previous chunk
+#ifdef BRATS_VS8_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VS8_STAMP(2);  // the halo loads landing
+#endif
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
       if (wave + 4 * k < NROWS) {
@@ -105,8 +117,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
       }
     }
     __syncthreads();
+    VS8_STAMP(3);  // LDS writes + barrier
     const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
     conv_mma_chunk<T, 3, CK, DIL, NF, -1, NB, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    VS8_STAMP(4);  // MFMA loop
   }
 
   // --- epilogue: bias, statistics per 4x4x16 sub-tile, NDHWC store ---
@@ -131,21 +145,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
       }
     }
     const bool full = z0 + CONV_TZ <= p.D && y0 + VS8_TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * NF * 16 <= p.cout;
-    if (full) {
+    if (full && ypit % 8 == 0 && csub % 8 == 0 && ((size_t)ydst & 15) == 0) {
+      // 16-byte stores: the lanes of MFMA rows q and q ^ 1 hold channels 4q..4q+3 and the next four of the SAME voxel;
+      // exchanging halves between two x-rows (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of
+      // the second) gives every lane 8 consecutive channels of ONE voxel: rows 0 / 2 keep x-row i, rows 1 / 3 take x-row
+      // i + 1.  Half the store instructions; worth ~1 % (the epilogue waits on the CU's ~10 B/clk store path, not on issue).
+      const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
+      for (int i = 0; i < NB; i += 2) {
         const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
         T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          float o[4];
+          uint32_t pk[2][2];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            o[rr] = acc[f][i][rr] + bias[f][rr];
-            s1[f][rr] += o[rr];
-            s2[f][rr] += o[rr] * o[rr];
+          for (int e = 0; e < 2; ++e) {
+            float o[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              o[rr] = acc[f][i + e][rr] + bias[f][rr];
+              s1[f][rr] += o[rr];
+              s2[f][rr] += o[rr] * o[rr];
+            }
+            pk[e][0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+            pk[e][1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
           }
-          Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
+          const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+          const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+          *(u32x4*)(rowp + lane_w + (f0 + f) * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
         }
       }
     } else {
@@ -190,6 +217,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
       }
     }
   }
+#ifdef BRATS_VS8_STAMPS
+  VS8_STAMP(5);  // epilogue
+  if (lane == 0 && p.stamps) {
+    long long* st = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 6;
+    for (int i = 0; i < 6; ++i) st[i] = tacc[i];
+  }
+#endif
   if (p.stats) {
     __syncthreads();
     if (tid < 2 * NF * 16) {  // one 4x4x16 statistics entry per y-half (wn)
