@@ -190,8 +190,8 @@ def main():
     use_amp = args.precision == "bf16"
     train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets)
 
-    if args.graph:
-        assert world == 1 and args.optimizer == "ranger", "--graph: single GPU, ranger optimizer"
+    if args.graph:  # (with N > 1 the bucketed RCCL all-reduces are captured into the graph too)
+        assert args.optimizer == "ranger", "--graph: ranger optimizer (capturable)"
         from brats21_amd.engine import GraphedTrainStep
         train_step = GraphedTrainStep(train_step, warmup=2)
 
@@ -211,7 +211,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ops.TIMER = timer if (timer is not None and i % stride == 0) else None
-        if buckets is not None:
+        if buckets is not None and not args.graph:
             buckets.measure = i % stride == 0  # two HIP events around the collective waits of the sampled steps
         loss = step()
     torch.cuda.synchronize()

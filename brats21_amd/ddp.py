@@ -60,6 +60,7 @@ class GradientBuckets:
         if comm_dtype is None and os.environ.get("BRATS_DDP_BF16", "0") != "0":
             comm_dtype = torch.bfloat16
         self.comm_dtype = comm_dtype or torch.float32
+        self.force_collectives = False  # tests: launch the all-reduces even at world size 1
         self.measure = False       # bench.py: record how long finish() has to wait for the collectives (GPU time)
         self.exposed = []          # [(event before the waits, event after them)]
         self.model = model
@@ -134,7 +135,7 @@ class GradientBuckets:
             self._sync = old
 
     def _launch(self, b):
-        if self.world > 1:
+        if self.world > 1 or (self.force_collectives and dist.is_initialized()):
             buf = self._flat[b]
             if self._wire is not None:
                 buf = self._wire[b]

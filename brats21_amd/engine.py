@@ -49,13 +49,24 @@ class GraphedTrainStep:
     takes the Python / launch path off the critical path (EquiUnetASSPEvo is launch-bound on slow hosts: 23 vs 28 ms).
 
     Requirements: fixed input shapes, an optimizer whose step is capturable (brats21_amd.optim.Ranger2020(capturable=
-    True), or a torch optimizer constructed with capturable=True), no gradient buckets (single GPU).  ``warmup`` eager
-    steps run on the first batch before the capture (lazy initialisation, allocator warm-up): they are real steps.
-    The learning rate is baked into the graph: re-create the object after changing it."""
+    True), or a torch optimizer constructed with capturable=True).  ``warmup`` eager steps run on the first batch before
+    the capture (lazy initialisation, allocator warm-up): they are real steps.  The learning rate is baked into the
+    graph: re-create the object after changing it.
+
+    Data parallel: with ``step.buckets`` (brats21_amd.ddp.GradientBuckets over the RCCL backend) the bucketed all-reduces
+    are captured too -- the backward program pushes gradients into the buckets, each bucket's collective is forked onto
+    RCCL's stream inside the graph and joined before the optimizer kernels -- so the 8-GPU step of EquiUnetASSPEvo is one
+    graph launch per rank instead of a host-bound eager step.  The capture then runs in "thread_local" error mode
+    (ProcessGroupNCCL's watchdog thread polls events while the stream is capturing; probed on ROCm 7 / PyTorch 2.10:
+    scripts/probes/nccl_capture.py).  Needs >= 2 warm-up steps: the first one learns the bucket order."""
 
     def __init__(self, step, warmup=2):
         if step.buckets is not None:
-            raise NotImplementedError("GraphedTrainStep: capture with gradient buckets (multi-GPU) is not supported yet")
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend(step.buckets.group) != "nccl":
+                raise NotImplementedError("GraphedTrainStep with gradient buckets needs the nccl (RCCL) backend: a gloo "
+                                          "all-reduce runs on the host and cannot be captured into a hipGraph")
+            warmup = max(warmup, 2)
         if not getattr(step.optimizer, "capturable", False) and not all(
                 g.get("capturable", False) for g in step.optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a capturable optimizer (e.g. brats21_amd.optim.Ranger2020(capturable=True))")
@@ -72,7 +83,11 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self.step.model.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        kw = {}
+        if self.step.buckets is not None:
+            self.step.buckets.measure = False  # (timing events cannot be recorded into a graph and read back per replay)
+            kw["capture_error_mode"] = "thread_local"
+        with torch.cuda.graph(self.graph, **kw):
             self.static_loss = self.step(self.static_image, self.static_target)
 
     def __call__(self, image, target):

@@ -81,3 +81,43 @@ def test_two_ranks_on_one_gpu(ddp_two_rank_result):
     assert res["ok"] and res["world"] == 2
     for name in ("equiunet", "equiunet_assp_evo"):
         assert res["cases"][name]["buckets"] > 1 and res["cases"][name]["worst_rel_err"] < 1e-5
+
+
+def test_graphed_step_with_captured_rccl_allreduce():
+    """The whole data-parallel step -- forward, fused Dice, backward program pushing into the buckets, the buckets' RCCL
+    all-reduces, Ranger -- replayed as ONE hipGraph.  World size 1 on the one GPU of the test box (the collectives are
+    forced so that real RCCL kernels sit inside the capture); the result must equal the eager bucket-less steps bit for
+    bit (an all-reduce over one rank is the identity)."""
+    import torch.distributed as dist
+    from brats21_amd.ddp import GradientBuckets
+    from brats21_amd.engine import GraphedTrainStep, TrainStep
+    from brats21_amd.optim import Ranger2020
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        size = (16, 16, 16)
+        x = synth.random_image(2, 4, size, seed=3).to(DEV)
+        t = synth.nested_spheres(2, size).to(DEV)
+        results = []
+        for graphed in (False, True):
+            m = _make("equiunet_assp_evo", 16, "bf16")
+            with contextlib.redirect_stdout(io.StringIO()):
+                opt = Ranger2020(m.parameters(), lr=1e-3, use_gc=False, capturable=True)
+            buckets = None
+            if graphed:
+                buckets = GradientBuckets(m, bucket_bytes=1 << 18)
+                buckets.force_collectives = True
+            step = TrainStep(m, opt, amp=True, buckets=buckets)
+            if graphed:
+                step = GraphedTrainStep(step, warmup=2)
+            # the first graphed call = 2 eager warm-up steps + capture + 1 replay: steps 1..3; the eager run keeps step 3 on
+            losses = [float(step(x, t).detach()) for _ in range(6 if graphed else 8)]
+            losses = losses if graphed else losses[2:]
+            torch.cuda.synchronize()
+            results.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).clone()))
+        assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+        assert torch.equal(results[0][1], results[1][1])
+    finally:
+        dist.destroy_process_group()
