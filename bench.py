@@ -289,12 +289,15 @@ def main():
                   file=sys.stderr)
     patches = world * args.batch * args.steps
     res = {
-        "metric": "train patches/sec (4x128^3, width-48)", "value": round(patches / elapsed, 4), "unit": "patches/s",
+        "metric": f"train patches/sec (4x{args.patch}^3, width-{args.width})", "value": round(patches / elapsed, 4), "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision + (f"+e4m3 conv ({args.fp8})" if args.fp8 else ""), "data": "synthetic",
         "config": {"workload": f"{args.model} width={args.width}, batch={args.batch}/GPU of 4x{args.patch}^3 synthetic patches, "
-                               f"fwd + deep-supervision Dice + bwd + {args.optimizer} (BASELINE.json configs[1])",
+                               f"fwd + deep-supervision Dice + bwd + {args.optimizer}" + (" as one hipGraph" if args.graph else "") +
+                               (" (BASELINE.json configs[1])" if (args.model, args.width, args.fp8) == ("equiunet", 48, None) else
+                                " (BASELINE.json configs[2], per-GPU share)" if (args.model, args.width, args.fp8) == ("equiunet_assp_evo", 48, None) else
+                                " (BASELINE.json configs[4], per-GPU share at 2 patches)" if (args.model, args.width) == ("equiunet_assp_evo", 64) and args.fp8 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
         "roofline": roofline,
     }
