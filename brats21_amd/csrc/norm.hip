@@ -178,7 +178,7 @@ template <typename T> DEVI void record_absmax(float mx, uint32_t* amax) {
 
 // A thread owns one 16-byte channel vector (its scale / shift live in registers) and walks voxels, two in flight;
 // relu -- the published configuration -- is specialised so that the loop body is cvt, fma, max, cvt per element.
-template <typename T, bool HEAVY>
+template <typename T, bool HEAVY, bool NT = false>
 __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
                                                          T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C,
                                                          uint32_t* __restrict__ amax) {
@@ -216,18 +216,18 @@ __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ y
     int vox = live ? blockIdx.x * vl_n + myvl : voxels;
     for (; vox + stride < voxels; vox += 2 * stride) {
       float a0[VW], a1[VW];
-      Vec<T, VW>::load(yb + (size_t)vox * ypitch, a0);
-      Vec<T, VW>::load(yb + (size_t)(vox + stride) * ypitch, a1);
+      vload<T, VW, NT>(yb + (size_t)vox * ypitch, a0);
+      vload<T, VW, NT>(yb + (size_t)(vox + stride) * ypitch, a1);
       body(a0);
       body(a1);
-      Vec<T, VW>::store(zb + (size_t)vox * zpitch, a0);
-      Vec<T, VW>::store(zb + (size_t)(vox + stride) * zpitch, a1);
+      vstore<T, VW, NT>(zb + (size_t)vox * zpitch, a0);
+      vstore<T, VW, NT>(zb + (size_t)(vox + stride) * zpitch, a1);
     }
     if (vox < voxels) {
       float a0[VW];
-      Vec<T, VW>::load(yb + (size_t)vox * ypitch, a0);
+      vload<T, VW, NT>(yb + (size_t)vox * ypitch, a0);
       body(a0);
-      Vec<T, VW>::store(zb + (size_t)vox * zpitch, a0);
+      vstore<T, VW, NT>(zb + (size_t)vox * zpitch, a0);
     }
   };
   if (!HEAVY && act == BRATS_ACT_RELU) run(std::true_type{});
@@ -247,10 +247,14 @@ extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scal
     BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d (C <= %d)", vw, 256 * vw);
   const int vl = 256 / (C / vw);
   const int gx = (voxels + vl * 8 - 1) / (vl * 8);
-  dim3 grid(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
+  const int cap = (dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2)) ? 8192 : 2048;
+  dim3 grid(gx < 1 ? 1 : (gx > cap ? cap : gx), N);  // large tensors: many short-lived blocks stream faster (scripts/probes/stream_rw.hip)
   hipStream_t st = (hipStream_t)s;
   uint32_t* am = (uint32_t*)amax;
-  if (act > BRATS_ACT_LEAKY) {
+  if (dtype == BRATS_BF16 && act <= BRATS_ACT_LEAKY && stream_nt((size_t)N * voxels * C * 2)) {
+    hipLaunchKernelGGL((affine_act_kernel<bf16_t, false, true>), grid, dim3(256), 0, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
+                       zpitch, act, slope, voxels, C, am);
+  } else if (act > BRATS_ACT_LEAKY) {
     if (dtype == BRATS_BF16)
       hipLaunchKernelGGL((affine_act_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
                          zpitch, act, slope, voxels, C, am);
@@ -274,7 +278,7 @@ extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scal
 // A thread owns one 16-byte channel vector (fixed for the whole kernel) and walks voxels: its per-channel constants
 // live in registers (read from LDS per element they made both passes LDS-bound at ~3.5 TB/s), two voxels are in
 // flight per iteration.
-template <typename T, bool HEAVY>
+template <typename T, bool HEAVY, bool NT = false>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                             int ypitch, const float* __restrict__ scale_shift,
                                                             const float* __restrict__ mean_rstd, float* __restrict__ red, int act,
@@ -315,14 +319,14 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     };
     for (; vox + 3 * stride < (size_t)voxels; vox += 4 * stride) {  // 4 voxels (8 loads) in flight per thread
       float g0[VW], y0[VW], g1[VW], y1[VW], g2[VW], y2[VW], g3[VW], y3[VW];
-      Vec<T, VW>::load(dzb + vox * dzpitch, g0);
-      Vec<T, VW>::load(yb + vox * ypitch, y0);
-      Vec<T, VW>::load(dzb + (vox + stride) * dzpitch, g1);
-      Vec<T, VW>::load(yb + (vox + stride) * ypitch, y1);
-      Vec<T, VW>::load(dzb + (vox + 2 * stride) * dzpitch, g2);
-      Vec<T, VW>::load(yb + (vox + 2 * stride) * ypitch, y2);
-      Vec<T, VW>::load(dzb + (vox + 3 * stride) * dzpitch, g3);
-      Vec<T, VW>::load(yb + (vox + 3 * stride) * ypitch, y3);
+      vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+      vload<T, VW, NT>(yb + vox * ypitch, y0);
+      vload<T, VW, NT>(dzb + (vox + stride) * dzpitch, g1);
+      vload<T, VW, NT>(yb + (vox + stride) * ypitch, y1);
+      vload<T, VW, NT>(dzb + (vox + 2 * stride) * dzpitch, g2);
+      vload<T, VW, NT>(yb + (vox + 2 * stride) * ypitch, y2);
+      vload<T, VW, NT>(dzb + (vox + 3 * stride) * dzpitch, g3);
+      vload<T, VW, NT>(yb + (vox + 3 * stride) * ypitch, y3);
       body(g0, y0);
       body(g1, y1);
       body(g2, y2);
@@ -330,8 +334,8 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     }
     for (; vox < (size_t)voxels; vox += stride) {
       float g0[VW], y0[VW];
-      Vec<T, VW>::load(dzb + vox * dzpitch, g0);
-      Vec<T, VW>::load(yb + vox * ypitch, y0);
+      vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+      vload<T, VW, NT>(yb + vox * ypitch, y0);
       body(g0, y0);
     }
   }
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finish_kernel(float* __restrict__ 
 
 // pass 2: dy = rstd*(u*gamma - m1 - xhat*m2) = u*A + y*B + K with per-channel A = rstd*gamma, B = -rstd^2*m2,
 // K = rstd*(mean*rstd*m2 - m1);  block (0,0) also finishes dgamma/dbeta
-template <typename T, bool HEAVY>
+template <typename T, bool HEAVY, bool NT = false>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                            int ypitch, const float* __restrict__ scale_shift,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
@@ -446,26 +450,26 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
   };
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float g0[VW], y0[VW], g1[VW], y1[VW], o0[VW], o1[VW];
-    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
-    Vec<T, VW>::load(yb + vox * ypitch, y0);
-    Vec<T, VW>::load(dzb + (vox + stride) * dzpitch, g1);
-    Vec<T, VW>::load(yb + (vox + stride) * ypitch, y1);
+    vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+    vload<T, VW, NT>(yb + vox * ypitch, y0);
+    vload<T, VW, NT>(dzb + (vox + stride) * dzpitch, g1);
+    vload<T, VW, NT>(yb + (vox + stride) * ypitch, y1);
     body(g0, y0, o0);
     body(g1, y1, o1);
-    Vec<T, VW>::store(dyb + vox * dypitch, o0);
-    Vec<T, VW>::store(dyb + (vox + stride) * dypitch, o1);
+    vstore<T, VW, NT>(dyb + vox * dypitch, o0);
+    vstore<T, VW, NT>(dyb + (vox + stride) * dypitch, o1);
   }
   if (vox < (size_t)voxels) {
     float g0[VW], y0[VW], o0[VW];
-    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
-    Vec<T, VW>::load(yb + vox * ypitch, y0);
+    vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+    vload<T, VW, NT>(yb + vox * ypitch, y0);
     body(g0, y0, o0);
-    Vec<T, VW>::store(dyb + vox * dypitch, o0);
+    vstore<T, VW, NT>(dyb + vox * dypitch, o0);
   }
   if (amax) record_absmax<T>(mx, amax);
 }
 
-constexpr int GN_BWD_MAX_BLOCKS = 512;
+constexpr int GN_BWD_MAX_BLOCKS = 2048;
 extern "C" size_t brats_gn_bwd_ws_floats(int N, int C) { return (size_t)(1 + GN_BWD_MAX_BLOCKS) * N * C * 2; }
 
 extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
@@ -480,11 +484,20 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
   const int cv = C / vw, vl = 256 / cv;
   const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
   // pass 1 leaves one partial sum per block; gn_bwd_finish_kernel adds them in block order
-  dim3 g1(gx < 1 ? 1 : (gx > GN_BWD_MAX_BLOCKS ? GN_BWD_MAX_BLOCKS : gx), N);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const int cap1 = big ? GN_BWD_MAX_BLOCKS : 512;
+  dim3 g1(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx), N);
   const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
-  dim3 g2(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), N);
+  dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
-  if (act > BRATS_ACT_LEAKY) {
+  if (dtype == BRATS_BF16 && act <= BRATS_ACT_LEAKY && stream_nt((size_t)N * voxels * C * 2)) {
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, false, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                       ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
+    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
+                       ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
+                       voxels, C, groups, (uint32_t*)amax);
+  } else if (act > BRATS_ACT_LEAKY) {
   if (dtype == BRATS_BF16) {
       hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
                          ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
