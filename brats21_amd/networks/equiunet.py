@@ -135,7 +135,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
-def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None):
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
     fp8 == "all": the input gradient (dgrad) runs on the e4m3 kernel too, scaled by the |max| of dy that the GroupNorm
     backward records; the weight gradient stays bf16."""
@@ -144,11 +144,16 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     f8 = fp8 == "all" and need_dx and dtype == torch.bfloat16 and ops.conv_f8_chunk(y.shape[-1]) > 0
     amax = slots.take() if (f8 and slots is not None) else None
     dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, act, amax=amax)
-    if x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
-        dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
-    else:
-        dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2)
-    grads[names[unit.conv.weight]] = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
+    with ops.side_stream(side, dy, x, x2) as on_side:
+        # (the weight gradient depends only on dy and the saved input and nobody but the optimizer waits for it: on the
+        # side stream it fills the CUs that the tail of the input-gradient kernel and the small GroupNorm launches leave idle)
+        if x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
+            dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
+        else:
+            dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2)
+        dw = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
+        on_side(dw)
+    grads[names[unit.conv.weight]] = dw
     grads[names[unit.bn.weight]] = dgamma
     grads[names[unit.bn.bias]] = dbeta
     if sink is not None:  # data-parallel: hand finished gradients to the bucketed all-reduce right away
@@ -251,8 +256,12 @@ class _EquiUnetFn(torch.autograd.Function):
         fp8 = m.conv_fp8 if dtype == torch.bfloat16 else None
         slots = _AmaxSlots(32, douts[0].device) if fp8 == "all" else None
 
+        # weight gradients on a side stream (model.wgrad_stream); with gradient buckets they stay on the main stream: the
+        # buckets' copies and collectives are ordered against it
+        side = ops.get_side_stream(douts[0].device) if (m.wgrad_stream and m._grad_sink is None) else None
+
         def cbw(unit, dz, need_dx=True):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots)
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
@@ -291,6 +300,8 @@ class _EquiUnetFn(torch.autograd.Function):
         d_p1 = cbw(m.encoder2.ConvBnRelu1, cbw(m.encoder2.ConvBnRelu2, d_down2))
         d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=d_skip1)
         cbw(m.encoder1.ConvBnRelu1, cbw(m.encoder1.ConvBnRelu2, d_down1), need_dx=False)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)  # every weight gradient is complete before autograd hands them on
         ctx.tape = ctx.bufs = None
         return (None, None, None) + tuple(grads.get(i) for i in range(ctx.nparams))
 
@@ -323,6 +334,10 @@ class EquiUnet(_PackedWeightsModule):
         # when the activations are bf16 (BASELINE.json configs[4]); the weight gradients stay bf16
         self.conv_fp8 = None
         self.skip_deep_heads_in_eval = False
+        # weight gradients on a second HIP stream (they depend only on dy and the saved input).  Off: measured 16.40 ->
+        # 16.63 ms / step same-box -- the all-taps kernel owns a CU's whole LDS, so the two streams only take CUs from
+        # each other, and the tails they could fill are shorter than the interference they add
+        self.wgrad_stream = os.environ.get("BRATS_WGRAD_STREAM", "0") != "0"
         self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
         # training: one multi-tensor weight-packing launch per step (ops.PackPlan).  Off by default here: this network's
         # step is GPU-bound and the single gather-heavy launch (0.21 ms) saves only 0.05 ms of GPU time over the 34 small

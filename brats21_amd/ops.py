@@ -71,6 +71,41 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SIDE_STREAMS = {}
+
+
+def get_side_stream(device):
+    """One extra HIP stream per device for work nobody waits for until the end of the backward program."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
+
+
+@contextlib.contextmanager
+def side_stream(side, *inputs):
+    """Run the block on `side` after everything enqueued so far on the current stream (fork); the caller joins once, at the
+    end.  `inputs` were allocated on the current stream and are read on the side stream: the caching allocator is told
+    (record_stream) so that their memory is not handed out again before the side stream is done with it.  The block
+    registers its results through the yielded function: they are consumed on the main stream after the join.  With
+    side=None the block simply runs in line."""
+    if side is None or TIMER is not None:  # (per-kernel HIP-event timing wants kernels one after the other)
+        yield lambda *t: None
+        return
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        def produced(*tensors):
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(main)
+        yield produced
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+
+
 def _code(dtype):
     if dtype == torch.bfloat16:
         return BF16
