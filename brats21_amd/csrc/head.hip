@@ -55,6 +55,72 @@ __global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const floa
   }
 }
 
+// bf16, C <= 64 (the full-resolution head: 48 -> 3 at 128^3, 403 MB read): the K <= 4 logits of 16 voxels are ONE pair of
+// v_mfma_f32_16x16x32_bf16 -- rows = classes (3 of 16 used: the matrix pipe is idle anyway), columns = voxels, k =
+// channels; the B operand of lane (voxel l & 15, q = l >> 4) is one 16-byte load of 8 consecutive channels, so a wave
+// instruction reads 1 KB of contiguous activations, and nothing goes through LDS or a cross-lane reduction (the first form
+// read its weights from LDS per element and reduced six channel-vector threads per voxel through LDS: 2.7 TB/s).
+__global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __restrict__ x, int xpitch, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float* __restrict__ low, int C, int K,
+                                                             size_t voxels) {
+  const int lane = threadIdx.x & 63, v = lane & 15, q = lane >> 4;
+  const int n = blockIdx.y;
+  // the f32 weights enter as three bf16 terms (w = hi + mid + lo exactly: 3 x 8 mantissa bits), so the products are
+  // those of the f32 weights with the bf16 activations, as in the reference's arithmetic; six MFMAs per 16 voxels
+  bf16x8 wa[3][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 t[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 32 * s + 8 * q + j;
+      float rest = (v < K && c < C) ? w[v * C + c] : 0.f;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        const bf16_t hb = f2bf(rest);
+        t[part][j] = (short)hb;
+        rest -= bf2f(hb);
+      }
+    }
+#pragma unroll
+    for (int part = 0; part < 3; ++part) wa[part][s] = __builtin_bit_cast(bf16x8, t[part]);
+  }
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = (b && r < K) ? b[r] : 0.f;
+  const bf16_t* xb = x + (size_t)n * voxels * xpitch;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, (short)0, (int)(voxels * xpitch * 2), 0x00020000);
+  const int dead1 = 32 + 8 * q < C ? 0 : -1;  // channels 32 + 8q.. of the second k-step exist?
+  const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+  float* lowp = low + (size_t)n * K * voxels;
+  for (size_t v0 = wave_id * 64; v0 < voxels; v0 += nwaves * 64) {  // 4 chunks of 16 voxels per iteration: 8 loads in flight
+    bf16x8 xb0[4], xb1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t vv = v0 + 16 * i + v;
+      const int off = vv < voxels ? (int)(vv * xpitch * 2) + 16 * q : -1;
+      xb0[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      xb1[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + 64) | dead1 | (off >> 31), 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int part = 2; part >= 0; --part) {  // small terms first
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[part][0], xb0[i], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[part][1], xb1[i], acc, 0, 0, 0);
+      }
+      const size_t vv = v0 + 16 * i + v;
+      if (q == 0 && vv < voxels) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < K) lowp[(size_t)r * voxels + vv] = acc[r] + bias[r];
+      }
+    }
+  }
+}
+
 struct Lerp { int i0, i1; float w0, w1; };
 DEVI Lerp lerp_coef(int o, int in_len, float scale) {
   const float src = scale * (float)o;
@@ -68,26 +134,36 @@ DEVI Lerp lerp_coef(int o, int in_len, float scale) {
 }
 static inline float ac_scale(int in_len, int out_len) { return out_len > 1 ? (float)(in_len - 1) / (float)(out_len - 1) : 0.f; }
 
-__global__ void upsample_planes_kernel(const float* __restrict__ low, float* __restrict__ out, size_t planes, int D, int H,
-                                       int W, int sc, float sd, float sh, float sw) {
-  const int Do = D * sc, Ho = H * sc, Wo = W * sc;
-  const size_t total = planes * Do * Ho * Wo;
-  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-    size_t v = it;
-    const int xo = v % Wo; v /= Wo;
-    const int yo = v % Ho; v /= Ho;
-    const int zo = v % Do;
-    const size_t pl = v / Do;
-    const Lerp lz = lerp_coef(zo, D, sd), ly = lerp_coef(yo, H, sh), lx = lerp_coef(xo, W, sw);
-    const float* p = low + pl * D * H * W;
-    float o = 0.f;
+// grid = (chunks of the (yo, xo / 4) plane, Do, planes): z coefficients are scalar, a thread writes 4 consecutive x (one
+// 16-byte store) -- the first form computed one f32 per thread behind three 64-bit div / mod chains and wrote the deep
+// heads' 50 MB planes at 0.85 TB/s.  Same weights and summation order (w = wz * wy * wx, k = 0..7): bit-identical.
+__global__ void __launch_bounds__(256) upsample_planes_kernel(const float* __restrict__ low, float* __restrict__ out, int D, int H, int W, int sc,
+                                                              float sd, float sh, float sw) {
+  const int Ho = H * sc, Wo = W * sc, Do = D * sc, W4 = Wo / 4;
+  const int zo = blockIdx.y;
+  const size_t pl = blockIdx.z;
+  const Lerp lz = lerp_coef(zo, D, sd);
+  const float* p0 = low + pl * D * H * W + (size_t)lz.i0 * H * W;
+  const float* p1 = low + pl * D * H * W + (size_t)lz.i1 * H * W;
+  float* o = out + (pl * Do + zo) * (size_t)Ho * Wo;
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < Ho * W4; it += gridDim.x * blockDim.x) {
+    const int yo = it / W4, x0 = (it % W4) * 4;
+    const Lerp ly = lerp_coef(yo, H, sh);
+    f32x4 r;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int z = (k & 4) ? lz.i1 : lz.i0, yy = (k & 2) ? ly.i1 : ly.i0, xx = (k & 1) ? lx.i1 : lx.i0;
-      const float wgt = ((k & 4) ? lz.w1 : lz.w0) * ((k & 2) ? ly.w1 : ly.w0) * ((k & 1) ? lx.w1 : lx.w0);
-      o += wgt * p[((size_t)z * H + yy) * W + xx];
+    for (int j = 0; j < 4; ++j) {
+      const Lerp lx = lerp_coef(x0 + j, W, sw);
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float* p = (k & 4) ? p1 : p0;
+        const int yy = (k & 2) ? ly.i1 : ly.i0, xx = (k & 1) ? lx.i1 : lx.i0;
+        const float wgt = ((k & 4) ? lz.w1 : lz.w0) * ((k & 2) ? ly.w1 : ly.w0) * ((k & 1) ? lx.w1 : lx.w0);
+        acc += wgt * p[yy * W + xx];
+      }
+      r[j] = acc;
     }
-    out[it] = o;
+    *(f32x4*)(o + (size_t)yo * Wo + x0) = r;
   }
 }
 
@@ -104,14 +180,19 @@ extern "C" int brats_head_fwd(const void* x, int xpitch, const float* w, const f
   if (cvh > 256) BRATS_FAIL(BRATS_E_UNSUPPORTED, "head_fwd: C too large");
   dim3 grid(sgrid((vox + vlh - 1) / vlh, 1), N);
   const size_t ldsh = (size_t)(HEAD_KMAX * C + 256 * HEAD_KMAX) * sizeof(float);
-  if (dtype == BRATS_BF16)
+  if (dtype == BRATS_BF16 && C <= 64 && (double)vox * xpitch * 2 < 2147483648.0) {
+    const size_t waves = (vox + 63) / 64;
+    const unsigned gx = (unsigned)(waves / 4 < 1 ? 1 : (waves / 4 > 8192 ? 8192 : waves / 4));
+    hipLaunchKernelGGL(head_conv_mfma_kernel, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)x, xpitch, w, b, low, C, K, vox);
+  } else if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(head_conv_kernel<bf16_t>, grid, dim3(256), ldsh, st, (const bf16_t*)x, xpitch, w, b, low, C, K, vox);
   else
     hipLaunchKernelGGL(head_conv_kernel<float>, grid, dim3(256), ldsh, st, (const float*)x, xpitch, w, b, low, C, K, vox);
   if (scale > 1) {
-    const size_t total = (size_t)N * K * vox * scale * scale * scale;
-    hipLaunchKernelGGL(upsample_planes_kernel, dim3(sgrid(total, 256)), dim3(256), 0, st, (const float*)low, out, (size_t)N * K,
-                       D, H, W, scale, ac_scale(D, D * scale), ac_scale(H, H * scale), ac_scale(W, W * scale));
+    if ((W * scale) % 4) BRATS_FAIL(BRATS_E_UNSUPPORTED, "head_fwd: up-sampled width %d must be a multiple of 4", W * scale);
+    const int items = H * scale * (W * scale / 4);
+    hipLaunchKernelGGL(upsample_planes_kernel, dim3((unsigned)((items + 255) / 256), (unsigned)(D * scale), (unsigned)(N * K)), dim3(256), 0, st,
+                       (const float*)low, out, D, H, W, scale, ac_scale(D, D * scale), ac_scale(H, H * scale), ac_scale(W, W * scale));
   }
   BRATS_CHECK_LAUNCH();
   return 0;
