@@ -69,7 +69,7 @@ def kernel_source_sha():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "brats21_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.startswith("conv_") or name == "common.hpp":
+        if (name.startswith("conv_") and name.endswith((".hip", ".hpp"))) or name == "common.hpp":
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]
