@@ -11,10 +11,18 @@ static inline int igrid(size_t total) {
   return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
 
-// dst[b][c][z][y][x] = src[n_b][c][z0_b + z - pad_z][...] or cval outside the source volume
-// (fuses the centred constant padding of inferers.py:103-109 with the window slicing of :126-130)
+// dst[b][c][z][y][x] = src[n_b][c][z0_b + z - pad_z][...]; outside the source volume: cval (constant) or the voxel that
+// F.pad's reflect / replicate / circular modes would put there (PytorchPadMode, inferers.py:109)
+// (fuses the centred padding of inferers.py:103-109 with the window slicing of :126-130)
+__device__ __forceinline__ int sw_pad_index(int i, int L, int mode) {
+  if (mode == 1) { i = i < 0 ? -i : i; return i >= L ? 2 * (L - 1) - i : i; }  // reflect (no edge repeat; pad < L)
+  if (mode == 2) return i < 0 ? 0 : (i >= L ? L - 1 : i);                      // replicate
+  i %= L;                                                                      // circular
+  return i < 0 ? i + L : i;
+}
 __global__ void sw_gather_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ win,
-                                 int B, int C, int D, int H, int W, int rd, int rh, int rw, int pz, int py, int px, float cval) {
+                                 int B, int C, int D, int H, int W, int rd, int rh, int rw, int pz, int py, int px, float cval,
+                                 int mode) {
   const size_t total = (size_t)B * C * rd * rh * rw;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t t = i;
@@ -23,7 +31,9 @@ __global__ void sw_gather_kernel(const float* __restrict__ src, float* __restric
     const int z = t % rd; t /= rd;
     const int c = t % C;
     const int b = (int)(t / C);
-    const int n = win[b * 4], sz = win[b * 4 + 1] + z - pz, sy = win[b * 4 + 2] + y - py, sx = win[b * 4 + 3] + x - px;
+    const int n = win[b * 4];
+    int sz = win[b * 4 + 1] + z - pz, sy = win[b * 4 + 2] + y - py, sx = win[b * 4 + 3] + x - px;
+    if (mode != 0) { sz = sw_pad_index(sz, D, mode); sy = sw_pad_index(sy, H, mode); sx = sw_pad_index(sx, W, mode); }
     float v = cval;
     if (sz >= 0 && sz < D && sy >= 0 && sy < H && sx >= 0 && sx < W) v = src[((((size_t)n * C + c) * D + sz) * H + sy) * W + sx];
     dst[i] = v;
@@ -87,10 +97,12 @@ __global__ void signed_perm_kernel(const float* __restrict__ src, float* __restr
 }
 
 extern "C" int brats_sw_gather(const float* src, float* dst, const int* windows, int B, int C, int D, int H, int W, int rd,
-                               int rh, int rw, int pad_z, int pad_y, int pad_x, float cval, brats_stream_t s) {
-  if (!src || !dst || !windows || B <= 0) BRATS_FAIL(BRATS_E_ARG, "sw_gather: bad argument");
+                               int rh, int rw, int pad_z, int pad_y, int pad_x, float cval, int pad_mode, brats_stream_t s) {
+  if (!src || !dst || !windows || B <= 0 || pad_mode < 0 || pad_mode > 3) BRATS_FAIL(BRATS_E_ARG, "sw_gather: bad argument");
+  if (pad_mode == 1 && (rd - D >= 2 * D - 1 || rh - H >= 2 * H - 1 || rw - W >= 2 * W - 1))  // F.pad: "padding size should be less than the input dimension"
+    BRATS_FAIL(BRATS_E_ARG, "sw_gather: reflect padding must be smaller than the image");
   hipLaunchKernelGGL(sw_gather_kernel, dim3(igrid((size_t)B * C * rd * rh * rw)), dim3(256), 0, (hipStream_t)s, src, dst, windows, B,
-                     C, D, H, W, rd, rh, rw, pad_z, pad_y, pad_x, cval);
+                     C, D, H, W, rd, rh, rw, pad_z, pad_y, pad_x, cval, pad_mode);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

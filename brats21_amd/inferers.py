@@ -168,8 +168,9 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
         raise ValueError("expected NCDHW input")
     if overlap < 0 or overlap >= 1:
         raise AssertionError("overlap must be >= 0 and < 1.")
-    if getattr(padding_mode, "value", padding_mode) != "constant":
-        raise NotImplementedError("only constant padding is implemented (the reference's default)")
+    pad_mode = {"constant": 0, "reflect": 1, "replicate": 2, "circular": 3}.get(getattr(padding_mode, "value", padding_mode))
+    if pad_mode is None:
+        raise ValueError(f"padding_mode {padding_mode!r} is not a PytorchPadMode (constant, reflect, replicate, circular)")
     if not inputs.is_cuda:
         raise _lib.BratsHipError("brats21_amd.sliding_window_inference runs on the GPU only (no CPU fallback)")
     lib = _lib.lib()
@@ -192,7 +193,7 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
         b = min(sw_batch_size, total - g0)
         window = torch.empty((b, c) + roi, dtype=torch.float32, device=x.device)
         _lib.check(lib.brats_sw_gather(x.data_ptr(), window.data_ptr(), win_tbl[g0:g0 + b].data_ptr(), b, c, *image_size_,
-                                       *roi, *pad, float(cval), stream), "sw_gather")
+                                       *roi, *pad, float(cval), pad_mode, stream), "sw_gather")
         prob = _first(predictor(window, *args, **kwargs)).contiguous().float()
         if out is None:
             k = prob.shape[1]

@@ -239,8 +239,9 @@ int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout,
 /* ---- sliding-window inference on the GPU (utils/inferers.py:103-162; the reference stitches on
  * the CPU, learning/engine.py:305-307).  NCDHW f32.  `windows` = device int32 [B][4] = (n, z, y, x)
  * window origins in the *padded* image; pad_* = leading constant padding (inferers.py:103-109). */
+/* pad_mode = PytorchPadMode of inferers.py:34,109: 0 constant (cval), 1 reflect, 2 replicate, 3 circular */
 int brats_sw_gather(const float* src, float* dst, const int* windows, int B, int C, int D, int H, int W,
-                    int rd, int rh, int rw, int pad_z, int pad_y, int pad_x, float cval, brats_stream_t s);
+                    int rd, int rh, int rw, int pad_z, int pad_y, int pad_x, float cval, int pad_mode, brats_stream_t s);
 /* out[n][:, window] += importance * prob ; count[...] += importance (inferers.py:149-151) */
 int brats_sw_accumulate(const float* prob, const float* importance, float* out, float* count, int K,
                         int Dp, int Hp, int Wp, int rd, int rh, int rw, int n, int z0, int y0, int x0,

@@ -44,8 +44,8 @@ def importance_map(patch, mode="constant", sigma_scale=0.125):
 
 
 def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap=0.25, mode="constant",
-                             sigma_scale=0.125, cval=0.0):
-    """utils/inferers.py:26-162 (constant padding mode only): centre-pad up to roi (:103-109),
+                             sigma_scale=0.125, cval=0.0, padding_mode="constant"):
+    """utils/inferers.py:26-162: centre-pad up to roi (:103-109),
     windows (:111-116), weighted accumulate (:125-151), divide (:154), crop the pad (:156-162).
     The predictor may return (out, [deeps]); only the first tensor is kept (:135-136)."""
     if not 0 <= overlap < 1:
@@ -59,7 +59,7 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
         diff = max(roi[k - 2] - inputs.shape[k], 0)
         half = diff // 2
         pad.extend([half, diff - half])
-    x = F.pad(inputs, pad, mode="constant", value=cval)
+    x = F.pad(inputs, pad, mode=padding_mode, value=cval) if padding_mode == "constant" else F.pad(inputs, pad, mode=padding_mode)
     starts = window_starts(image_size, roi, scan_interval(image_size, roi, overlap))
     imp = importance_map(tuple(min(r, i) for r, i in zip(roi, image_size)), mode, sigma_scale)
     out = cnt = None

@@ -176,6 +176,9 @@ def inference_fixtures():
             res[f"sw_{mode}_{int(ov * 100)}"] = y.numpy()
     y = sliding_window_inference(x[..., :12], (16, 16, 16), 2, predictor, overlap=0.5)  # roi > image: padded
     res["sw_pad"] = y.numpy()
+    for pm in ("reflect", "replicate", "circular"):  # PytorchPadMode of utils/inferers.py:34,109 (roi > image in two dims)
+        y = sliding_window_inference(x[:, :, :, :11, :12], (16, 16, 16), 2, predictor, overlap=0.5, padding_mode=pm)
+        res[f"sw_pad_{pm}"] = y.numpy()
     # TTA: parameter order + augmented/deaugmented tensors of a tiny non-cubic volume
     from src_definer_tta import get_tta  # noqa
     comp = get_tta(tta)

@@ -35,6 +35,11 @@ def test_sliding_window_matches_reference_golden(golden_dir):
             np.testing.assert_allclose(y.cpu().numpy(), g[f"sw_{mode}_{int(ov * 100)}"], atol=2e-6)
     y = sliding_window_inference(x[..., :12].contiguous(), (16, 16, 16), 2, pred, overlap=0.5)  # roi > image
     np.testing.assert_allclose(y.cpu().numpy(), g["sw_pad"], atol=2e-6)
+    for pm in ("reflect", "replicate", "circular"):  # PytorchPadMode (utils/inferers.py:34,109), roi > image in two dims
+        y = sliding_window_inference(x[:, :, :, :11, :12].contiguous(), (16, 16, 16), 2, pred, overlap=0.5, padding_mode=pm)
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"sw_pad_{pm}"], atol=2e-6)
+    with pytest.raises(ValueError):
+        sliding_window_inference(x, (16, 16, 16), 1, pred, padding_mode="mirror")
     y = sliding_window_inference(x, (16, 16, 16), 4, pred, overlap=0.5, device=torch.device("cpu"))
     assert y.device.type == "cpu"
     np.testing.assert_allclose(y.numpy(), g["sw_constant_50"], atol=2e-6)

@@ -121,6 +121,9 @@ def test_sliding_window_and_tta_vectors(golden_dir):
             np.testing.assert_allclose(y.numpy(), g[f"sw_{mode}_{int(ov * 100)}"], atol=1e-6)
     y = oinf.sliding_window_inference(x[..., :12], (16, 16, 16), 2, predictor, overlap=0.5)
     np.testing.assert_allclose(y.numpy(), g["sw_pad"], atol=1e-6)
+    for pm in ("reflect", "replicate", "circular"):
+        y = oinf.sliding_window_inference(x[:, :, :, :11, :12], (16, 16, 16), 2, predictor, overlap=0.5, padding_mode=pm)
+        np.testing.assert_allclose(y.numpy(), g[f"sw_pad_{pm}"], atol=1e-6)
     params = oinf.tta_param_list()
     assert [[a, f, r] for a, f, r in params] == json.loads(str(g["tta_params"]))
     v = synth.closed_form("ttav", (1, 2, 4, 6, 6))
