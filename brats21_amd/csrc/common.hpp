@@ -86,6 +86,30 @@ template <typename T, int N, bool NT> DEVI void vstore(T* p, const float* o) {
 // (affine_act at 2 x 64^3 x 96: 0.031 ms with plain loads, 0.037 ms with the hints)
 static inline bool stream_nt(size_t bytes) { return bytes >= ((size_t)256 << 20); }
 
+// ---- e4m3 helpers shared by the fp8 convolution (conv_igemm_f8.hpp) and the fp8 weight gradient (conv_wgrad.hip) ----
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+DEVI u32x2 f8_quant8(u32x4 v, float scale) {  // 8 bf16 -> 8 e4m3 (value / scale), channel order kept
+  // the elements go through scalars first: __builtin_bit_cast applied to a vector-element lvalue (v[1]) reads element 0
+  // with this hipcc
+  const uint32_t e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+  s16x2 lo = {0, 0}, hi = {0, 0};
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, e0), scale, false);
+  lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, e1), scale, true);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, e2), scale, false);
+  hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, e3), scale, true);
+  return u32x2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
+}
+
+// power-of-two scale that puts amax into [128, 256) after division (e4m3 tops out at 448)
+DEVI float f8_scale_from_amax(float amax) {
+  uint32_t e = (__float_as_uint(amax) >> 23) & 0xffu;
+  e = e == 255u ? 127u : (e < 8u ? 1u : e - 7u);  // inf/NaN: scale 1 (they convert to NaN and propagate)
+  return __uint_as_float(e << 23);
+}
+
+
 // compile-time loop with a constexpr index
 template <int I, int N, typename F> DEVI void static_for(F&& f) {
   if constexpr (I < N) {

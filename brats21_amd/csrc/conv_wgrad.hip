@@ -695,6 +695,243 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// e4m3 all-taps kernel (BASELINE.json configs[4], model.conv_fp8 = "all"): the weight gradient of the 48 x 48 channel
+// blocks on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 MFMA rate).  X and dY stay bf16 in HBM; the X halo tile and
+// the dY tile arrive by LDS-DMA in bf16 staging buffers (as X does in the kernel above), and every thread quantises the pieces IT
+// fetched (x / 2^e with the power-of-two scales of the e4m3 convolutions: from the tensors' recorded |max|) into the
+// e4m3 tiles the MFMA phase reads (X 31 KB + dY 12 KB; one staging buffer is enough: it is consumed by its own thread
+// before the next tile's DMA is issued).  A k-step is 128 voxels = 8 x-rows of the tile.  Both operands are
+// channel-minor and the MFMA wants 32 consecutive k per lane: four 8-bit transposing LDS reads per fragment
+// (ds_read_b64_tr_b8: per 16-lane group 8 voxels x 16 channels, lane i <- channel i, byte r <- voxel r; probed in
+// scripts/probes/tr8.hip).  Roles as above: 81 (tap, ci-fragment) pairs over 8 waves, 3 co fragments each, accumulators
+// kept over all tiles of the workgroup; the slab gets acc * (xscale * dyscale).
+// Two block shapes: 48 co x 48 ci (COF, CIF = 3, 3: the width-48 networks) and 64 co x 32 ci (4, 2: width 64 = configs[4];
+// 54 (tap, ci-fragment) pairs over 8 waves, 7 x 4 accumulators per lane, X 41 KB + dY 32 KB of bf16 per tile).
+template <int COF, int CIF> struct Wg3f {
+  static constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, HVOX = HZ * HY * HX;
+  static constexpr int CO = 16 * COF, CI = 16 * CIF;
+  static constexpr int SX = CI, SY = CO;                                   // e4m3 tiles: bytes per voxel
+  static constexpr int XPPV = CI / 8, YPPV = CO / 8;                       // 16-byte bf16 pieces (8 channels) per voxel in HBM
+  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;
+  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;     // 8, 3 | 6, 4 per thread
+  static constexpr int XB = XI * 512 * 16, YB = YI * 512 * 16;             // bf16 staging buffers (whole 1-KB DMA rows per wave)
+  static constexpr int LDS_X = HVOX * SX;
+  static constexpr int LDS = XB + YB + LDS_X + WG_VOX * SY;                // 65536 + 24576 + 31104 + 12288 | 49152 + 32768 + 20736 + 16384
+  static constexpr int PAIRS = 27 * CIF, PPW = (PAIRS + 7) / 8;            // 81, 11 | 54, 7
+  static_assert(YPIECES % 512 == 0, "");
+};
+
+// 32 voxels (two tile rows x 16) x 16 channels of an e4m3 tile as one MFMA operand: lane (kq, L) of the k-step gets channel L
+// of voxels k = 32 kq .. 32 kq + 31; o0 / o1 = this lane's byte offsets into rows 2 kq / 2 kq + 1 (see the kernel)
+template <int STRIDE> DEVI i32x8 tr8_frag(const char* base, int o0, int o1) {
+  typedef __attribute__((ext_vector_type(2))) int v2i;
+  typedef __attribute__((address_space(3))) v2i* lp;
+  const v2i a0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(base + o0));
+  const v2i a1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(base + o0 + 8 * STRIDE));
+  const v2i a2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(base + o1));
+  const v2i a3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(base + o1 + 8 * STRIDE));
+  return i32x8{a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
+}
+
+// a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop
+// into registers the accumulators need.  (The host pass of hipcc instantiates the kernel template's generic lambdas too
+// and silently drops the kernel stub when it meets a "v" constraint there, hence the device-pass guard.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OPAQUE_V(x) asm volatile("" : "+v"(x))
+#else
+#define OPAQUE_V(x) do { } while (0)
+#endif
+
+// one LDS-DMA instruction: lane l's 16 bytes at buffer offset `off` (out of range: zeros) land at dst + 16 l; dst wave-uniform.
+// (A function of its own: called directly inside the kernel TEMPLATE's generic lambdas the builtin makes hipcc's host pass
+// drop the kernel stub without a diagnostic.)
+DEVI void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, int off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+}
+
+struct WgradF8Params { WgradParams w; const float* amax_x1; const float* amax_x2; const float* amax_dy; };
+
+template <int COF, int CIF>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_f8_kernel(const WgradF8Params pp) {
+  typedef bf16_t T;
+  using G = Wg3f<COF, CIF>;
+  const WgradParams& p = pp.w;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldx = lds + G::XB + G::YB;
+  char* ldy = ldx + G::LDS_X;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kq = lane >> 4, L = lane & 15;
+  const int lane8 = blockIdx.x % p.nlane, gsub = blockIdx.x / p.nlane, g8 = gridDim.x / p.nlane;
+  const int split = blockIdx.x;
+  const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
+  const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
+  const int co0 = blockIdx.y * G::CO, ci0 = blockIdx.z * G::CI;
+  const T* xsrc;
+  int xpitch;
+  if (ci0 < p.c1) { xsrc = (const T*)p.x1 + ci0; xpitch = p.p1; }
+  else { xsrc = (const T*)p.x2 + (ci0 - p.c1); xpitch = p.p2; }
+  const int xpb = xpitch * 2, ypb = p.dyp * 2;
+  float ax = *pp.amax_x1;
+  if (pp.amax_x2) ax = fmaxf(ax, *pp.amax_x2);  // (one scale for the concatenated input, as the e4m3 forward uses)
+  const float xs = f8_scale_from_amax(ax), ys = f8_scale_from_amax(*pp.amax_dy);
+
+  int xoffs[G::XI], xcode[G::XI];
+#pragma unroll
+  for (int i = 0; i < G::XI; ++i) {
+    const int P = tid + 512 * i;
+    const int vox = P / G::XPPV, part = P % G::XPPV;
+    const int hx = vox % G::HX, hy = (vox / G::HX) % G::HY, hz = vox / (G::HX * G::HY);
+    const bool ok = P < G::XPIECES;
+    xoffs[i] = ok ? ((hz * p.H + hy) * p.W + hx) * xpb + part * 16 : (int)0x80000000;
+    xcode[i] = ok ? (hz | hy << 3 | hx << 6 | 1 << 14) : 0;
+  }
+  const unsigned xsample_bytes = (unsigned)p.D * p.H * p.W * xpitch * 2;
+  const unsigned ysample_bytes = (unsigned)p.D * p.H * p.W * p.dyp * 2;
+
+  int poff[G::PPW];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 8 * jj;
+    const int t = pid / CIF, nn = pid % CIF;
+    poff[jj] = pid < G::PAIRS ? (((t / 9) * G::HY + (t / 3) % 3) * G::HX + t % 3) * G::SX + nn * 16 : 0;
+  }
+  f32x4 acc[G::PPW][COF];
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj)
+#pragma unroll
+    for (int m = 0; m < COF; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct TileLoads {
+    __amdgpu_buffer_rsrc_t xrs, yrs;
+    int xorg, yorg;
+    unsigned zm, ym, xm, inter;
+  };
+  auto setup_loads = [&](int tile) {
+    TileLoads T_;
+    int bt = tile;
+    const int x0 = (bt % p.tx) * WG_TX; bt /= p.tx;
+    const int y0 = (bt % p.ty) * WG_TY; bt /= p.ty;
+    const int z0 = (bt % p.tz) * WG_TZ;
+    const int n = bt / p.tz;
+    const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
+    T_.xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0, (int)xsample_bytes, 0x00020000);
+    T_.yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0), (short)0, (int)ysample_bytes, 0x00020000);
+    T_.xorg = (((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * xpb;
+    T_.yorg = ((z0 * p.H + y0) * p.W + x0) * ypb;
+    auto inside = [](int o, int size, int hn) {
+      const int lo = o >= 1 ? 0 : 1 - o, hi = size - o + 1 < hn ? size - o + 1 : hn;
+      return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    T_.zm = inside(z0, p.D, G::HZ); T_.ym = inside(y0, p.H, G::HY); T_.xm = inside(x0, p.W, G::HX);
+    T_.inter = (T_.zm == (1u << G::HZ) - 1 && T_.ym == (1u << G::HY) - 1 && T_.xm == (1u << G::HX) - 1) ? 1u : 0u;
+    return T_;
+  };
+  char* const xdst = lds + wave * 1024;  // wave-uniform: the DMA adds lane * 16
+  auto issue_x = [&](const TileLoads& T_, auto i_) {
+    constexpr int i = i_;
+    int c = xcode[i];
+    OPAQUE_V(c);  // (decoded per tile: the hoisted fields would cost 3 registers per piece)
+    const unsigned ok = (unsigned)(c >> 14) & (T_.inter | ((T_.zm >> (c & 7)) & (T_.ym >> ((c >> 3) & 7)) & (T_.xm >> ((c >> 6) & 31)))) & 1u;
+    lds_dma16(T_.xrs, xdst + i * 8192, (T_.xorg + xoffs[i]) | ((int)ok - 1));
+  };
+  auto issue_y = [&](const TileLoads& T_, auto i_) {
+    constexpr int i = i_;
+    int t_ = tid;
+    OPAQUE_V(t_);  // (recomputed per tile: hoisted out of the tile loop these offsets cost registers the MFMA phase needs)
+    const int P = t_ + 512 * i;
+    const int vox = P / G::YPPV, part = P % G::YPPV;
+    const int z = vox >> 6, y = (vox >> 4) & 3, x = vox & 15;
+    const int yo = ((z * p.H + y) * p.W + x) * ypb + part * 16;
+    const unsigned ok = (T_.inter | ((T_.zm >> (z + 1)) & (T_.ym >> (y + 1)) & (T_.xm >> (x + 1)))) & 1u;
+    lds_dma16(T_.yrs, xdst + G::XB + i * 8192, (T_.yorg + yo) | ((int)ok - 1));
+  };
+
+  // per-lane offsets of the transposing reads: lane (kq, L) owns k = 32 kq .. 32 kq + 31 of a k-step = tile rows 2 kq + e
+  // (e = 0, 1) x 16 voxels; within one read lane L supplies voxel x = (L >> 1) (+ 8 for the second half row), channel
+  // bytes 8 (L & 1) .. of the 16-channel fragment.  A and B use the same voxel <-> k mapping, which is all that matters.
+  int xl[2], yl[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int r = 2 * kq + e;  // row inside the k-step's 8 rows: z = r >> 2, y = r & 3
+    xl[e] = (((r >> 2) * G::HY + (r & 3)) * G::HX + (L >> 1)) * G::SX + (L & 1) * 8;
+    yl[e] = (r * 16 + (L >> 1)) * G::SY + (L & 1) * 8;
+  }
+
+  const int tile_first = lane8 * tpx + gsub;
+  if (tile_first < tile_end) {
+    const TileLoads T_ = setup_loads(tile_first);
+    static_for<0, G::XI>([&](auto i_) { issue_x(T_, i_); });
+    static_for<0, G::YI>([&](auto i_) { issue_y(T_, i_); });
+  }
+  for (int tile = tile_first; tile < tile_end; tile += g8) {
+    // my own pieces have landed; quantise them while the slower waves finish the previous MFMA phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32x2 qx[G::XI], qy[G::YI];
+#pragma unroll
+    for (int i = 0; i < G::XI; ++i) qx[i] = f8_quant8(*(const u32x4*)(lds + (tid + 512 * i) * 16), xs);
+#pragma unroll
+    for (int i = 0; i < G::YI; ++i) qy[i] = f8_quant8(*(const u32x4*)(lds + G::XB + (tid + 512 * i) * 16), ys);
+    __syncthreads();  // everybody is done reading the e4m3 tiles of the previous tile
+#pragma unroll
+    for (int i = 0; i < G::XI; ++i)
+      if (i + 1 < G::XI || tid + 512 * i < G::XPIECES) *(u32x2*)(ldx + (tid + 512 * i) * 8) = qx[i];
+#pragma unroll
+    for (int i = 0; i < G::YI; ++i) *(u32x2*)(ldy + (tid + 512 * i) * 8) = qy[i];
+    __syncthreads();
+    const bool more = tile + g8 < tile_end;  // scalar
+    TileLoads T_ = setup_loads(more ? tile + g8 : tile);
+    if (!more) T_.zm = T_.inter = 0;  // nothing follows: every piece is dropped by the range check
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, G::XI>([&](auto i_) { issue_x(T_, i_); });
+    static_for<0, G::YI>([&](auto i_) { issue_y(T_, i_); });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 2>([&](auto ks_) {
+      constexpr int ks = ks_;  // k-step = tile rows 8 ks .. 8 ks + 7 (z = 2 ks, 2 ks + 1)
+      const char* xk = ldx + ks * (2 * G::HY * G::HX * G::SX);
+      i32x8 a[COF];
+#pragma unroll
+      for (int m = 0; m < COF; ++m) a[m] = tr8_frag<G::SY>(ldy + ks * (8 * 16 * G::SY) + m * 16, yl[0], yl[1]);
+      i32x8 b[2];
+      // (lane offset + pair offset added per use: hoisted out of the tile loop the 2 x PPW sums cost registers)
+      auto read_b = [&](auto jj_) {
+        constexpr int jj = jj_;
+        int o[2] = {xl[0] + poff[jj], xl[1] + poff[jj]};
+        OPAQUE_V(o[0]); OPAQUE_V(o[1]);
+        b[jj & 1] = tr8_frag<G::SX>(xk, o[0], o[1]);
+      };
+      read_b(std::integral_constant<int, 0>{});
+      static_for<0, G::PPW>([&](auto jj_) {
+        constexpr int jj = jj_;
+        if constexpr (jj + 1 < G::PPW) read_b(std::integral_constant<int, jj + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < COF; ++m)
+          acc[jj][m] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m], b[jj & 1], acc[jj][m], 0, 0, 0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  }
+
+  // ---- slab: ws[split][tap][co][ci] = acc * (xscale * dyscale); C/D layout: lane (q = lane >> 4, v = lane & 15) holds
+  //      rows (co) 4q..4q+3 of column (ci) v ----
+  const float os = xs * ys;
+#pragma unroll
+  for (int jj = 0; jj < G::PPW; ++jj) {
+    const int pid = wave + 8 * jj;
+    if (pid < G::PAIRS) {
+      const int t = pid / CIF, nn = pid % CIF;
+      float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
+      const int ci = ci0 + nn * 16 + L;
+#pragma unroll
+      for (int m = 0; m < COF; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * kq + r) * p.cin + ci] = acc[jj][m][r] * os;
+    }
+  }
+}
+
 // dw[co][ci][tap] = sum_split ws[split][tap][co][ci]   (fixed summation order -> bitwise reproducible; 16-byte loads)
 // A block = 32 consecutive f32x4 elements x 8 split groups: thread (e, g) adds splits g, g+8, ... and the 8 partial
 // sums are combined in group order through LDS (one thread per element deep the kernel had 61 workgroups, each
@@ -976,6 +1213,87 @@ extern "C" int brats_conv3d_wgrad_shift(const void* x, int cin, int xpitch, cons
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
     else hipLaunchKernelGGL(dbias_kernel<float>, dim3(cout), dim3(256), 0, st, (const float*)dy, dypitch, dbias, vox, cout);
   }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- e4m3 weight gradient (all-taps blocks only; everything else stays on the bf16 kernels) --------------------------
+// block shape (co fragments, ci fragments) and workgroups per XCD range; false = not built for this layer
+static bool wgrad_f8_shape(int N, int D, int H, int W, int c1, int c2, int cout, int* cof, int* cif, int* g8_out, int* nl_out, int* ntiles_out) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  if (c2 < 0) c2 = 0;
+  if (c1 <= 0 || cout <= 0) return false;
+  if (cout % 48 == 0 && c1 % 48 == 0 && c2 % 48 == 0) { *cof = 3; *cif = 3; }
+  else if (cout % 64 == 0 && c1 % 32 == 0 && c2 % 32 == 0) { *cof = 4; *cif = 2; }
+  else return false;
+  const int ntiles = N * ceil_div(D, WG_TZ) * ceil_div(H, WG_TY) * ceil_div(W, WG_TX);
+  const int blocks = (cout / (16 * *cof)) * ((c1 + c2) / (16 * *cif));
+  const int nl = wgrad_nlane(ntiles);
+  int g8 = ceil_div(ncu, nl * blocks);
+  if (g8 < 1) g8 = 1;
+  if (ntiles < 4 * nl * g8) return false;  // too few tiles per workgroup to amortise the 27-tap slab
+  *g8_out = g8; *nl_out = nl; *ntiles_out = ntiles;
+  return true;
+}
+
+extern "C" size_t brats_conv3d_wgrad_f8_ws_bytes(int N, int D, int H, int W, int c1, int c2, int cout) {
+  int cof, cif, g8, nl, nt;
+  if (!wgrad_f8_shape(N, D, H, W, c1, c2, cout, &cof, &cif, &g8, &nl, &nt)) return 0;  // 0 = not supported: use brats_conv3d_wgrad
+  return (size_t)nl * g8 * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
+}
+
+template <int COF, int CIF>
+static int wgrad_f8_launch(const WgradF8Params& pp, hipStream_t st) {
+  using G = Wg3f<COF, CIF>;
+  auto kern = conv_wgrad_alltaps_f8_kernel<COF, CIF>;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad_f8: hipFuncSetAttribute(%d): %s", G::LDS, hipGetErrorString(e));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pp.w.nsplit, pp.w.cout / G::CO, pp.w.cin / G::CI), dim3(512), G::LDS, st, pp);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int brats_conv3d_wgrad_f8(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+                                     const float* amax2, const void* dy, int dypitch, const float* amax_dy, float* ws, float* dw,
+                                     int N, int D, int H, int W, int cout, brats_stream_t s) {
+  if (!x1 || !dy || !ws || !dw || !amax1 || !amax_dy || c1 <= 0 || cout <= 0) BRATS_FAIL(BRATS_E_ARG, "wgrad_f8: null pointer / bad size");
+  if (c2 < 0) c2 = 0;
+  if (c2 > 0 && (!x2 || !amax2)) BRATS_FAIL(BRATS_E_ARG, "wgrad_f8: c2 > 0 needs x2 and its |max|");
+  int cof, cif, g8, nl, nt;
+  if (!wgrad_f8_shape(N, D, H, W, c1, c2, cout, &cof, &cif, &g8, &nl, &nt))
+    BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_f8: built for 48 x 48 / 64 x 32 channel blocks of layers with enough tiles "
+               "(brats_conv3d_wgrad_f8_ws_bytes() == 0 otherwise): use brats_conv3d_wgrad");
+  if (pitch1 % 8 || (c2 && pitch2 % 8) || dypitch % 8) BRATS_FAIL(BRATS_E_ARG, "wgrad_f8: pitches must be multiples of 8");
+  {
+    const int mp = pitch1 > pitch2 ? (pitch1 > dypitch ? pitch1 : dypitch) : (pitch2 > dypitch ? pitch2 : dypitch);
+    if ((double)D * H * W * mp * 2 >= 2147483648.0) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_f8: sample exceeds the 2 GiB buffer-offset range");
+  }
+  WgradF8Params pp;
+  WgradParams& p = pp.w;
+  p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
+  p.dy = dy; p.dyp = dypitch; p.ws = ws;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.cin = c1 + c2; p.cout = cout;
+  p.tz = ceil_div(D, WG_TZ); p.ty = ceil_div(H, WG_TY); p.tx = ceil_div(W, WG_TX);
+  p.ntiles = nt;
+  p.nlane = nl;
+  p.ntaps = 27; p.dil = 1;
+  p.nsplit = nl * g8;
+  pp.amax_x1 = amax1; pp.amax_x2 = c2 ? amax2 : nullptr; pp.amax_dy = amax_dy;
+  hipStream_t st = (hipStream_t)s;
+  const int rc = cof == 3 ? wgrad_f8_launch<3, 3>(pp, st) : wgrad_f8_launch<4, 2>(pp, st);
+  if (rc) return rc;
+  const size_t per = (size_t)27 * cout * p.cin;
+  const size_t blocks = (per / 4 + 31) / 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, p.cin, 27);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

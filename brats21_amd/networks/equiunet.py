@@ -137,17 +137,25 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
 
 def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
-    fp8 == "all": the input gradient (dgrad) runs on the e4m3 kernel too, scaled by the |max| of dy that the GroupNorm
-    backward records; the weight gradient stays bf16."""
+    fp8 == "all": the input gradient (dgrad) and -- for the dilation-1 layers the all-taps kernel covers -- the weight
+    gradient run on the e4m3 kernels too, scaled by the |max| of dy that the GroupNorm backward records (and the |max| of
+    the layer input recorded in the forward pass)."""
     unit, x, x2, y, mean_rstd, scale_shift = rec
     cin = unit.conv.weight.shape[1]
-    f8 = fp8 == "all" and need_dx and dtype == torch.bfloat16 and ops.conv_f8_chunk(y.shape[-1]) > 0
-    amax = slots.take() if (f8 and slots is not None) else None
+    all8 = fp8 == "all" and dtype == torch.bfloat16
+    f8 = all8 and need_dx and ops.conv_f8_chunk(y.shape[-1]) > 0
+    # e4m3 weight gradient: where the all-taps kernel is built for the layer and the producers of x (x2) recorded |max|
+    ax, ax2 = getattr(x, "_amax", None), (getattr(x2, "_amax", None) if x2 is not None else None)
+    w8 = (all8 and unit.dilation == 1 and ax is not None and (x2 is None or ax2 is not None) and y.dtype == torch.bfloat16
+          and ops.conv3d_wgrad_f8_ok(x, y, x2))
+    amax = slots.take() if ((f8 or w8) and slots is not None) else None
     dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, act, amax=amax)
     with ops.side_stream(side, dy, x, x2) as on_side:
         # (the weight gradient depends only on dy and the saved input and nobody but the optimizer waits for it: on the
         # side stream it fills the CUs that the tail of the input-gradient kernel and the small GroupNorm launches leave idle)
-        if x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
+        if w8 and amax is not None:
+            dw = ops.conv3d_wgrad_f8(x, dy, ax, amax, x2=x2, amax2=ax2)
+        elif x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
             dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
         else:
             dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2)

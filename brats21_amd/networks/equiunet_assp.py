@@ -124,7 +124,11 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
         dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1)  # a GEMM over the voxels: the shifted-tap weight-gradient kernel, 1 tap
         cx.put(conv.weight, dw)
     else:
-        dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil)
+        ax, ady = getattr(xin, "_amax", None), getattr(dy, "_amax", None)
+        if cx.fp8 == "all" and dil == 1 and ax is not None and ady is not None and ops.conv3d_wgrad_f8_ok(xin, dy):
+            dw = ops.conv3d_wgrad_f8(xin, dy, ax, ady)  # e4m3 operands, scales from the recorded |max| of both
+        else:
+            dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil)
         cx.put(conv.weight, dw[:, :cin].contiguous() if dw.shape[1] != cin else dw)
     cx.put(conv.bias, db)
     if not need_dx:
@@ -192,7 +196,7 @@ def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
 
 def _conv_evo_bwd(cx, rec, dz, need_dx=True):
     conv, evo, saved, y, mr, chan = rec
-    amax = cx.slot(y.device) if (cx.fp8 == "all" and need_dx) else None
+    amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
     dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax)
     if amax is not None:
         dy._amax = amax

@@ -529,6 +529,36 @@ def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
     return dw, db
 
 
+def conv3d_wgrad_f8_ok(x, dy, x2=None):
+    """Is the e4m3 weight-gradient kernel built for this layer (3x3x3, dilation 1, 48 x 48 / 64 x 32 channel blocks)?"""
+    n, d, h, w, c = x.shape
+    return (x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and
+            _lib.lib().brats_conv3d_wgrad_f8_ws_bytes(n, d, h, w, c, x2.shape[-1] if x2 is not None else 0, dy.shape[-1]) > 0)
+
+
+def conv3d_wgrad_f8(x, dy, amax, amax_dy, x2=None, amax2=None):
+    """dW [cout, cin (+cin2), 3, 3, 3] f32 of a dilation-1 layer with X and dY rounded to e4m3 on the way into the MFMA
+    (v_mfma_scale_f32_16x16x128_f8f6f4).  amax* : 1-element f32 device tensors holding max|x|, max|x2|, max|dy| (recorded
+    by the kernels that produced the tensors; absmax() otherwise).  Only where conv3d_wgrad_f8_ok()."""
+    ptr, c, p = _desc(x)
+    ptr2, c2, p2 = (None, 0, 0)
+    if x2 is not None:
+        ptr2, c2, p2 = _desc(x2)
+    dptr, cout, dp = _desc(dy)
+    n, d, h, w, _ = x.shape
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+        raise _lib.BratsHipError("conv3d_wgrad_f8: bf16 activations only")
+    nbytes = _lib.lib().brats_conv3d_wgrad_f8_ws_bytes(n, d, h, w, c, c2, cout)
+    if nbytes == 0:
+        raise _lib.BratsHipError(f"conv3d_wgrad_f8: not built for {c}+{c2} -> {cout} channels at {n}x{d}x{h}x{w} (use conv3d_wgrad)")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, c + c2, 3, 3, 3), dtype=torch.float32, device=x.device)
+    with _span("conv_wgrad_f8", c + c2, cout, 3, 1, n, d, h, w, "e4m3"):
+        _lib.check(_lib.lib().brats_conv3d_wgrad_f8(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2), dptr, dp, _f32(amax_dy),
+                                                    ws.data_ptr(), dw.data_ptr(), n, d, h, w, cout, _stream()), "conv3d_wgrad_f8")
+    return dw
+
+
 # ------------------------------------------------------------------------------------------ GroupNorm + act
 def gn_finalize(stats, n, c, groups, voxels, gamma, beta, eps=1e-5):
     mean_rstd = torch.empty((n, groups, 2), dtype=torch.float32, device=stats.device)

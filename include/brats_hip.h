@@ -123,6 +123,15 @@ int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c
                        const void* dy, int dypitch, float* ws, float* dw, float* dbias,
                        int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                        brats_stream_t s);
+/* e4m3 weight gradient (BASELINE.json configs[4]; model.conv_fp8 = "all"): X and dY (bf16 in HBM) are quantised to e4m3
+ * while they are staged (power-of-two scales from their |max|, the device scalars amax*: as brats_conv3d_f8_fwd; one
+ * scale for [x1 | x2]), the MMA is v_mfma_scale_f32_16x16x128_f8f6f4, dw is f32.  Built as the all-taps kernel only
+ * (dilation 1; channel blocks 48 x 48 or 64 co x 32 ci; enough tiles): brats_conv3d_wgrad_f8_ws_bytes() returns the
+ * workspace size, or 0 for a layer it is not built for (use brats_conv3d_wgrad there). */
+size_t brats_conv3d_wgrad_f8_ws_bytes(int N, int D, int H, int W, int c1, int c2, int cout);
+int brats_conv3d_wgrad_f8(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+                          const float* amax2, const void* dy, int dypitch, const float* amax_dy, float* ws, float* dw,
+                          int N, int D, int H, int W, int cout, brats_stream_t s);
 /* Weight gradient in the "shifted-tap" form: ksize = 1 (ConvEvo / bridge / upconv / ASPP k1 convolutions,
  * networks/equiunet2021.py:212-222 -- a GEMM over the voxels) and ksize = 3 at ANY dilation >= 1 (the ASPP branches with
  * dilation 4 and 6, :121-189, whose halo does not fit LDS): one workgroup per (tap, channel block, voxel range), its X tile

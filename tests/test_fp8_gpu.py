@@ -214,3 +214,73 @@ def test_conv3d_f8_zero_input_and_nan_propagation():
     w2[7] = 0
     y, _ = ops.conv3d_f8(_ndhwc(_rand((1, cin) + size, 5), dev), ops.pack_weights_f8(w2.to(dev), PACK_FWD), cout, 1, bias=b.to(dev))
     assert torch.equal(y[..., 7].float().cpu(), b[7].to(torch.bfloat16).float().expand(1, *size))
+
+
+def _wgrad_ref_f64(xq, dyq, dev):
+    """dW[o, c, kz, ky, kx] = sum_{n, voxel} dy[n, o, v] * x[n, c, v + k - 1] in float64 (27 matrix products on the GPU)."""
+    n, c, d, h, w = xq.shape
+    xp = F.pad(xq.to(dev).double(), (1, 1, 1, 1, 1, 1))
+    dyd = dyq.to(dev).double()
+    out = torch.empty((dyq.shape[1], c, 3, 3, 3), dtype=torch.float64, device=dev)
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                out[:, :, kz, ky, kx] = torch.einsum("nodhw,ncdhw->oc", dyd, xp[:, :, kz:kz + d, ky:ky + h, kx:kx + w])
+    return out.cpu()
+
+
+# (the persistent all-taps form wants >= 4 tiles of 4 x 4 x 16 voxels per workgroup on a full chip: volumes sized for that)
+@pytest.mark.parametrize("c1,c2,cout,size,n", [
+    (48, 0, 48, (32, 64, 64), 2),    # 48 x 48 blocks, one block: 1024 tiles over 256 workgroups
+    (48, 48, 96, (16, 36, 60), 2),   # two-source input (decoder), ragged tiles in y and x, 2 co blocks x 2 ci blocks
+    (64, 0, 64, (32, 32, 64), 2),    # width 64 (configs[4]): 64 co x 32 ci blocks
+    (32, 32, 128, (10, 32, 64), 3),  # 64 x 32 blocks over a 32 | 32 concat, ragged z
+])
+def test_conv3d_wgrad_f8_matches_quantised_reference(c1, c2, cout, size, n):
+    """e4m3 weight gradient: X and dY rounded to e4m3 with the kernel's power-of-two scales exactly as
+    the kernel does, the products summed in f64 -- what remains is the f32 accumulation order."""
+    from brats21_amd import ops
+    dev = _dev()
+    x = _rand((n, c1 + c2) + size, 21)
+    x[:, :, 1, 2, 3] *= 5.0
+    x = x.to(torch.bfloat16).float()
+    dy = _rand((n, cout) + size, 22, 3e-3)   # gradient-sized values
+    dy[:, :, 0, 0, 0] *= 4.0
+    dy = dy.to(torch.bfloat16).float()
+    x1 = _ndhwc(x[:, :c1], dev)
+    x2 = _ndhwc(x[:, c1:], dev) if c2 else None
+    dyd = _ndhwc(dy, dev)
+    assert ops.conv3d_wgrad_f8_ok(x1, dyd, x2)
+    a1, a2, ady = ops.absmax(x1), (ops.absmax(x2) if c2 else None), ops.absmax(dyd)
+    dw = ops.conv3d_wgrad_f8(x1, dyd, a1, ady, x2=x2, amax2=a2)
+    dw2 = ops.conv3d_wgrad_f8(x1, dyd, a1, ady, x2=x2, amax2=a2)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)  # fixed-order slab reduction: bitwise reproducible
+    xs, ys = _scale_from_amax(float(x.abs().max())), _scale_from_amax(float(dy.abs().max()))
+    ref = _wgrad_ref_f64(_q8(x, xs), _q8(dy, ys), dev)
+    got = dw.cpu().double()
+    err = float((got - ref).abs().max())
+    bound = float(ref.abs().max()) * 2e-5 + 1e-7   # f32 accumulation over n * voxels products
+    print(f"\nwgrad e4m3 {c1}+{c2}->{cout} @{n}x{size}: max |err| {err:.3e} (|dw| max {float(ref.abs().max()):.3e})")
+    assert err <= bound, (err, bound)
+    # the price of e4m3 against the bf16 kernel, measured (not a pass criterion beyond sanity)
+    dwb, _ = ops.conv3d_wgrad(x1, dyd, 3, 1, x2=x2)
+    rel = float((dw - dwb).norm() / dwb.norm())
+    print(f"   e4m3 vs bf16 weight gradient: relative L2 distance {rel:.3e}")
+    assert rel < 0.1
+
+
+def test_conv3d_wgrad_f8_declines_layers_it_is_not_built_for():
+    from brats21_amd import ops
+    from brats21_amd._lib import BratsHipError
+    dev = _dev()
+    x = torch.zeros((1, 8, 8, 16, 24), dtype=torch.bfloat16, device=dev)   # 24 channels: no 48 / 32 block
+    dy = torch.zeros((1, 8, 8, 16, 48), dtype=torch.bfloat16, device=dev)
+    assert not ops.conv3d_wgrad_f8_ok(x, dy)
+    one = torch.ones(1, device=dev)
+    with pytest.raises(BratsHipError):
+        ops.conv3d_wgrad_f8(x, dy, one, one)
+    # too few tiles for the persistent all-taps form (4^3 volume, 1 tile): declined as well
+    x = torch.zeros((1, 4, 4, 4, 48), dtype=torch.bfloat16, device=dev)
+    dy = torch.zeros((1, 4, 4, 4, 48), dtype=torch.bfloat16, device=dev)
+    assert not ops.conv3d_wgrad_f8_ok(x, dy)
