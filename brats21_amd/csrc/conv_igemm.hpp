@@ -115,6 +115,11 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
 #pragma unroll
 #ifdef BRATS_VS8_FAKEW  // ablation (diagnostic build only, wrong results): every step re-reads the first 3 KB -> L1-resident weights
       for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)(ms & 0) * rows16 + f) * 64];
+#elif defined(BRATS_VS8_FAKEW4)  // ablation (wrong results): only every 4th macro-step loads weights -> 1/4 of the weight load instructions
+      for (int f = 0; f < NF; ++f) {
+        if constexpr (k % 4 == 0) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
+        else a[k % (WD + 1)][f] = a[(k + WD) % (WD + 1)][f];
+      }
 #else
       for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
 #endif
