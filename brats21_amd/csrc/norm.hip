@@ -554,7 +554,7 @@ extern "C" int brats_evonorm_finalize(const float* stats, int tiles_per_sample, 
 
 DEVI float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <typename T>
+template <typename T, bool NT = false>
 __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
                                    int zpitch, float* __restrict__ chansum, int voxels, int C, int groups,
@@ -580,7 +580,7 @@ __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const fl
     T* zb = z + (size_t)n * voxels * zpitch;
     for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
       float a[VW];
-      Vec<T, VW>::load(xb + vox * xpitch + c0, a);
+      vload<T, VW, NT>(xb + vox * xpitch + c0, a);
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
         a[j] = a[j] * sigmoidf_(a[j]) * sc[c0 + j] + be[c0 + j];
@@ -590,7 +590,7 @@ __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const fl
 #pragma unroll
         for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(a[j])), __builtin_fabsf(a[j + 1]));
       }
-      Vec<T, VW>::store(zb + vox * zpitch + c0, a);
+      vstore<T, VW, NT>(zb + vox * zpitch + c0, a);
     }
   }
   if (amax) record_absmax<T>(mx, amax);
@@ -627,7 +627,10 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
   dim3 grid((unsigned)(gx < 1 ? 1 : (gx > CHAN_MAX_BLOCKS ? CHAN_MAX_BLOCKS : gx)), N);
   const size_t lds = (size_t)(2 * C + vl * C) * sizeof(float);
-  if (dtype == BRATS_BF16)
+  if (dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2))  // (beyond the Infinity Cache: non-temporal streaming, common.hpp)
+    hipLaunchKernelGGL((evonorm_fwd_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
+                       (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
+  else if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(evonorm_fwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
                        (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
   else
@@ -640,7 +643,7 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
 
 // backward pass 1: red[n][c] = { sum_v dz, sum_v dz * x*sigmoid(x), sum_v dz * d/dx[x*sigmoid(x)] }
 // (the third sum gives the bias gradient of the preceding convolution without another pass over dx)
-template <typename T>
+template <typename T, bool NT = false>
 __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                           float* __restrict__ red, int voxels, int C) {
   constexpr int VW = 16 / sizeof(T);
@@ -667,17 +670,17 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
     size_t vox = (size_t)blockIdx.x * vl_n + myvl;
     for (; vox + stride < (size_t)voxels; vox += 2 * stride) {  // two voxels (4 loads) in flight per thread
       float g0[VW], x0[VW], g1[VW], x1[VW];
-      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g0);
-      Vec<T, VW>::load(xb + vox * xpitch + c0, x0);
-      Vec<T, VW>::load(dzb + (vox + stride) * dzpitch + c0, g1);
-      Vec<T, VW>::load(xb + (vox + stride) * xpitch + c0, x1);
+      vload<T, VW, NT>(dzb + vox * dzpitch + c0, g0);
+      vload<T, VW, NT>(xb + vox * xpitch + c0, x0);
+      vload<T, VW, NT>(dzb + (vox + stride) * dzpitch + c0, g1);
+      vload<T, VW, NT>(xb + (vox + stride) * xpitch + c0, x1);
       body(g0, x0);
       body(g1, x1);
     }
     if (vox < (size_t)voxels) {
       float g0[VW], x0[VW];
-      Vec<T, VW>::load(dzb + vox * dzpitch + c0, g0);
-      Vec<T, VW>::load(xb + vox * xpitch + c0, x0);
+      vload<T, VW, NT>(dzb + vox * dzpitch + c0, g0);
+      vload<T, VW, NT>(xb + vox * xpitch + c0, x0);
       body(g0, x0);
     }
   }
@@ -700,7 +703,7 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
 }
 
 // pass 2: dx = dz*gamma*r*num'(x) - r^3 * A_g * (x - mean_g)/(M-1),  A_g = sum_{c in g} gamma_c * red[n][c][1]
-template <typename T>
+template <typename T, bool NT = false>
 __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                          const float* __restrict__ red, T* __restrict__ dx, int dxpitch,
@@ -769,21 +772,21 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
   size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float g0[VW], x0[VW], g1[VW], x1[VW], o0[VW], o1[VW];
-    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
-    Vec<T, VW>::load(xb + vox * xpitch, x0);
-    Vec<T, VW>::load(dzb + (vox + stride) * dzpitch, g1);
-    Vec<T, VW>::load(xb + (vox + stride) * xpitch, x1);
+    vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+    vload<T, VW, NT>(xb + vox * xpitch, x0);
+    vload<T, VW, NT>(dzb + (vox + stride) * dzpitch, g1);
+    vload<T, VW, NT>(xb + (vox + stride) * xpitch, x1);
     body(g0, x0, o0);
     body(g1, x1, o1);
-    Vec<T, VW>::store(dxb + vox * dxpitch, o0);
-    Vec<T, VW>::store(dxb + (vox + stride) * dxpitch, o1);
+    vstore<T, VW, NT>(dxb + vox * dxpitch, o0);
+    vstore<T, VW, NT>(dxb + (vox + stride) * dxpitch, o1);
   }
   if (vox < (size_t)voxels) {
     float g0[VW], x0[VW], o0[VW];
-    Vec<T, VW>::load(dzb + vox * dzpitch, g0);
-    Vec<T, VW>::load(xb + vox * xpitch, x0);
+    vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+    vload<T, VW, NT>(xb + vox * xpitch, x0);
     body(g0, x0, o0);
-    Vec<T, VW>::store(dxb + vox * dxpitch, o0);
+    vstore<T, VW, NT>(dxb + vox * dxpitch, o0);
   }
   if (amax) record_absmax<T>(mx, amax);
 }
@@ -800,11 +803,19 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
   hipStream_t st = (hipStream_t)s;
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
-  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > 512 ? 512 : gx)), N);  // few fat blocks: 3C atomics per block onto N*3C addresses
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const size_t cap1 = big ? CHAN_MAX_BLOCKS : 512, cap2 = big ? 8192 : 2048;  // large tensors: many short-lived blocks stream faster
+  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx)), N);  // one partial per block, added in block order
   const size_t lds1 = (size_t)(vl * C * 3) * sizeof(float);
-  dim3 g2((unsigned)(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx)), N);
+  dim3 g2((unsigned)(gx < 1 ? 1 : (gx > cap2 ? cap2 : gx)), N);
   const size_t lds2 = (size_t)3 * C * sizeof(float);
-  if (dtype == BRATS_BF16) {
+  if (big) {
+    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
+                       xpitch, red, voxels, C);
+    brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
+    hipLaunchKernelGGL((evonorm_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax);
+  } else if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
                        xpitch, red, voxels, C);
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
@@ -823,7 +834,7 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
 
 // per-(n, channel) reduction over voxels: out[n][c] = sum_v a[v][c] * (b ? b[v][c] : 1)
 // (global average pool of the SE layer and its backward dot product)
-template <typename T>
+template <typename T, bool NT = false>
 __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T* __restrict__ b, int bpitch,
                                    float* __restrict__ out, int voxels, int C) {
   constexpr int VW = 16 / sizeof(T);
@@ -842,10 +853,10 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T*
     if (bb) {
       for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
         float x0[VW], y0[VW], x1[VW], y1[VW];
-        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
-        Vec<T, VW>::load(bb + vox * bpitch + c0, y0);
-        Vec<T, VW>::load(ab + (vox + stride) * apitch + c0, x1);
-        Vec<T, VW>::load(bb + (vox + stride) * bpitch + c0, y1);
+        vload<T, VW, NT>(ab + vox * apitch + c0, x0);
+        vload<T, VW, NT>(bb + vox * bpitch + c0, y0);
+        vload<T, VW, NT>(ab + (vox + stride) * apitch + c0, x1);
+        vload<T, VW, NT>(bb + (vox + stride) * bpitch + c0, y1);
 #pragma unroll
         for (int j = 0; j < VW; ++j) acc[j] += x0[j] * y0[j];
 #pragma unroll
@@ -853,16 +864,16 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T*
       }
       if (vox < (size_t)voxels) {
         float x0[VW], y0[VW];
-        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
-        Vec<T, VW>::load(bb + vox * bpitch + c0, y0);
+        vload<T, VW, NT>(ab + vox * apitch + c0, x0);
+        vload<T, VW, NT>(bb + vox * bpitch + c0, y0);
 #pragma unroll
         for (int j = 0; j < VW; ++j) acc[j] += x0[j] * y0[j];
       }
     } else {
       for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
         float x0[VW], x1[VW];
-        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
-        Vec<T, VW>::load(ab + (vox + stride) * apitch + c0, x1);
+        vload<T, VW, NT>(ab + vox * apitch + c0, x0);
+        vload<T, VW, NT>(ab + (vox + stride) * apitch + c0, x1);
 #pragma unroll
         for (int j = 0; j < VW; ++j) acc[j] += x0[j];
 #pragma unroll
@@ -870,7 +881,7 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T*
       }
       if (vox < (size_t)voxels) {
         float x0[VW];
-        Vec<T, VW>::load(ab + vox * apitch + c0, x0);
+        vload<T, VW, NT>(ab + vox * apitch + c0, x0);
 #pragma unroll
         for (int j = 0; j < VW; ++j) acc[j] += x0[j];
       }
@@ -896,9 +907,13 @@ extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int b
   hipStream_t st = (hipStream_t)s;
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
-  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > 512 ? 512 : gx)), N);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const size_t cap = big ? CHAN_MAX_BLOCKS : 512;
+  dim3 grid((unsigned)(gx < 1 ? 1 : (gx > cap ? cap : gx)), N);
   const size_t lds = (size_t)vl * C * sizeof(float);
-  if (dtype == BRATS_BF16)
+  if (big)
+    hipLaunchKernelGGL((channel_dot_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)a, apitch, (const bf16_t*)b, bpitch, out, voxels, C);
+  else if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(channel_dot_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)a, apitch, (const bf16_t*)b, bpitch, out, voxels, C);
   else
     hipLaunchKernelGGL(channel_dot_kernel<float>, grid, dim3(256), lds, st, (const float*)a, apitch, (const float*)b, bpitch, out, voxels, C);
@@ -908,7 +923,7 @@ extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int b
 }
 
 // dst[v][c] = a[v][c]*sa[n][c] (+ b[v][c]*sb[n][c]) (+ add[n][c])  -- SE scale / residual and their backward
-template <typename T>
+template <typename T, bool NT = false>
 __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const float* __restrict__ sa, const float* __restrict__ add,
                                      T* __restrict__ dst, int dpitch, int voxels, int C, uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
@@ -932,27 +947,27 @@ __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const 
   size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float x0[VW], x1[VW];
-    Vec<T, VW>::load(ab + vox * apitch, x0);
-    Vec<T, VW>::load(ab + (vox + stride) * apitch, x1);
+    vload<T, VW, NT>(ab + vox * apitch, x0);
+    vload<T, VW, NT>(ab + (vox + stride) * apitch, x1);
 #pragma unroll
     for (int j = 0; j < VW; ++j) { x0[j] = x0[j] * cs[j] + ca[j]; x1[j] = x1[j] * cs[j] + ca[j]; }
     if (amax) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(x0[j])), __builtin_fabsf(x1[j]));
     }
-    Vec<T, VW>::store(db + vox * dpitch, x0);
-    Vec<T, VW>::store(db + (vox + stride) * dpitch, x1);
+    vstore<T, VW, NT>(db + vox * dpitch, x0);
+    vstore<T, VW, NT>(db + (vox + stride) * dpitch, x1);
   }
   if (vox < (size_t)voxels) {
     float x0[VW];
-    Vec<T, VW>::load(ab + vox * apitch, x0);
+    vload<T, VW, NT>(ab + vox * apitch, x0);
 #pragma unroll
     for (int j = 0; j < VW; ++j) x0[j] = x0[j] * cs[j] + ca[j];
     if (amax) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) mx = __builtin_fmaxf(mx, __builtin_fabsf(x0[j]));
     }
-    Vec<T, VW>::store(db + vox * dpitch, x0);
+    vstore<T, VW, NT>(db + vox * dpitch, x0);
   }
   if (amax) record_absmax<T>(mx, amax);
 }
@@ -961,8 +976,12 @@ extern "C" int brats_channel_scale(const void* a, int apitch, const float* scale
                                    int dtype, int N, int voxels, int C, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!a || !scale || !dst || C % vw || apitch % vw || dpitch % vw) BRATS_FAIL(BRATS_E_ARG, "channel_scale: bad argument");
-  dim3 grid(stream_grid((size_t)voxels * (C / vw), 256), N);
-  if (dtype == BRATS_BF16)
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  dim3 grid(stream_grid((size_t)voxels * (C / vw), 256) * (big ? 2 : 1), N);  // (4096 blocks per sample; 8192 for the large tensors)
+  if (big)
+    hipLaunchKernelGGL((channel_scale_kernel<bf16_t, true>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)a, apitch,
+                       scale, add, (bf16_t*)dst, dpitch, voxels, C, (uint32_t*)amax);
+  else if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s, (const bf16_t*)a, apitch,
                        scale, add, (bf16_t*)dst, dpitch, voxels, C, (uint32_t*)amax);
   else
