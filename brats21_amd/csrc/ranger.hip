@@ -27,8 +27,55 @@ __global__ void __launch_bounds__(256) ranger_row_means_kernel(const brats_range
   if (threadIdx.x == 0) means[T.row_base + r] = red[0] / (float)T.rowlen;
 }
 
+// use_gcnorm (learning/optimizer.py:23-36,189-190): the (centralised) gradient of every tensor with more than two elements
+// is divided by its unbiased standard deviation + 1e-8.  Two small kernels in front of the update: per 2048-element chunk
+// the sums of x = g - row mean and of x^2 (fixed-order tree), then per tensor the chunk sums added in chunk order in f64.
+__global__ void __launch_bounds__(256) ranger_chunk_stats_kernel(const brats_ranger_tensor* __restrict__ tab,
+                                                                 const int* __restrict__ chunks, const float* __restrict__ means,
+                                                                 float* __restrict__ part /* [nchunks][2] */) {
+  const int t = chunks[blockIdx.x * 2];
+  const long base = (long)chunks[blockIdx.x * 2 + 1] * RANGER_CHUNK;
+  const brats_ranger_tensor T = tab[t];
+  const float* __restrict__ g = (const float*)T.grad;
+  const bool gc = T.rowlen > 0;
+  const long end = base + RANGER_CHUNK < T.numel ? base + RANGER_CHUNK : T.numel;
+  float s1 = 0.f, s2 = 0.f;
+  for (long i = base + threadIdx.x; i < end; i += 256) {
+    float x = g[i];
+    if (gc) x = x + (-means[T.row_base + (int)(i / T.rowlen)]);
+    s1 += x;
+    s2 += x * x;
+  }
+  __shared__ float r1[256], r2[256];
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int m = 128; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = r1[0]; part[blockIdx.x * 2 + 1] = r2[0]; }
+}
+
+__global__ void ranger_tensor_std_kernel(const brats_ranger_tensor* __restrict__ tab, const float* __restrict__ part,
+                                         float* __restrict__ gstd /* [ntensors] */) {
+  const int t = blockIdx.x;
+  const brats_ranger_tensor T = tab[t];
+  const long n = T.numel;
+  const int nch = (int)((n + RANGER_CHUNK - 1) / RANGER_CHUNK);
+  double s1 = 0.0, s2 = 0.0;
+  for (int c = 0; c < nch; ++c) { s1 += part[(size_t)(T.chunk_base + c) * 2]; s2 += part[(size_t)(T.chunk_base + c) * 2 + 1]; }
+  float d = 1.f;  // tensors of one or two elements are left alone (:33)
+  if (n > 2) {
+    double var = (s2 - s1 * s1 / (double)n) / (double)(n - 1);
+    d = (float)sqrt(var > 0.0 ? var : 0.0) + 1e-8f;
+  }
+  gstd[t] = d;
+}
+
 __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_tensor* __restrict__ tab,
                                                             const int* __restrict__ chunks, const float* __restrict__ means,
+                                                            const float* __restrict__ gstd,
                                                             const brats_ranger_dyn* __restrict__ dyn, float beta1, float beta2,
                                                             float omb1, float omb2, float eps, float alpha) {
   const int t = chunks[blockIdx.x * 2];
@@ -44,9 +91,11 @@ __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_t
   const float neg_step = dyn ? dyn->neg_step : T.neg_step;
   const bool adaptive = flags & 1, look = flags & 2, gc = T.rowlen > 0;
   const long end = base + RANGER_CHUNK < T.numel ? base + RANGER_CHUNK : T.numel;
+  const float gdiv = gstd ? gstd[t] : 1.f;
   for (long i = base + threadIdx.x; i < end; i += 256) {
     float gi = g[i];
     if (gc) gi = gi + (-means[T.row_base + (int)(i / T.rowlen)]);
+    if (gstd) gi = gi / gdiv;
     const float vi = v[i] * beta2 + (omb2 * gi) * gi;
     float mi = m[i] * beta1 + omb1 * gi;
     float pi = p[i];
@@ -100,8 +149,9 @@ extern "C" int brats_ranger_advance(brats_ranger_dyn* dyn, double lr, double bet
 }
 
 extern "C" int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int* chunks, int nchunks, const int* rows,
-                                 int nrows, float* row_means, const brats_ranger_dyn* dyn, float beta1, float beta2,
-                                 float one_minus_beta1, float one_minus_beta2, float eps, float alpha, brats_stream_t s) {
+                                 int nrows, float* row_means, float* chunk_stats, float* grad_std, const brats_ranger_dyn* dyn,
+                                 float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps, float alpha,
+                                 brats_stream_t s) {
   if (!table || ntensors <= 0 || !chunks || nchunks <= 0) BRATS_FAIL(BRATS_E_ARG, "ranger_step: empty tensor / chunk table");
   if (nrows > 0 && (!rows || !row_means)) BRATS_FAIL(BRATS_E_ARG, "ranger_step: gradient centralisation needs rows + row_means");
   hipStream_t st = (hipStream_t)s;
@@ -109,8 +159,14 @@ extern "C" int brats_ranger_step(const brats_ranger_tensor* table, int ntensors,
     hipLaunchKernelGGL(ranger_row_means_kernel, dim3(nrows), dim3(256), 0, st, table, rows, row_means);
     BRATS_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(ranger_update_kernel, dim3(nchunks), dim3(256), 0, st, table, chunks, row_means, dyn, beta1, beta2,
-                     one_minus_beta1, one_minus_beta2, eps, alpha);
+  if ((chunk_stats == nullptr) != (grad_std == nullptr)) BRATS_FAIL(BRATS_E_ARG, "ranger_step: use_gcnorm needs chunk_stats AND grad_std");
+  if (grad_std) {
+    hipLaunchKernelGGL(ranger_chunk_stats_kernel, dim3(nchunks), dim3(256), 0, st, table, chunks, row_means, chunk_stats);
+    hipLaunchKernelGGL(ranger_tensor_std_kernel, dim3(ntensors), dim3(1), 0, st, table, (const float*)chunk_stats, grad_std);
+    BRATS_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(ranger_update_kernel, dim3(nchunks), dim3(256), 0, st, table, chunks, row_means, (const float*)grad_std, dyn,
+                     beta1, beta2, one_minus_beta1, one_minus_beta2, eps, alpha);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

@@ -15,7 +15,7 @@ from . import _lib
 
 _REC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("slow", "<u8"),
                  ("numel", "<i8"), ("rowlen", "<i4"), ("row_base", "<i4"), ("neg_step", "<f4"), ("wd", "<f4"),
-                 ("flags", "<i4"), ("reserved", "<i4")])  # == brats_ranger_tensor (include/brats_hip.h)
+                 ("flags", "<i4"), ("chunk_base", "<i4")])  # == brats_ranger_tensor (include/brats_hip.h)
 
 
 def radam_step_size(step, beta1, beta2, n_sma_threshold):
@@ -41,14 +41,19 @@ class Ranger2020(Optimizer):
             raise ValueError(f'Invalid Learning Rate: {lr}')
         if not eps > 0:
             raise ValueError(f'Invalid eps: {eps}')
-        if use_gcnorm or normloss or not gc_loc:
-            raise NotImplementedError("brats21_amd.optim.Ranger2020 implements the reference's default configuration "
-                                      "(use_gcnorm=False, normloss=False, gc_loc=True)")
+        if normloss:
+            # learning/optimizer.py:192-198: p.mul_() on a leaf that requires grad, outside torch.no_grad() -- the reference's
+            # own step() raises RuntimeError there, so there is no behaviour to reproduce
+            raise NotImplementedError("Ranger2020(normloss=True) is not built: the reference's step() itself fails on it "
+                                      "(in-place operation on a leaf Variable, learning/optimizer.py:198)")
+        if not gc_loc:
+            raise NotImplementedError("brats21_amd.optim.Ranger2020 implements gc_loc=True (the reference's default)")
         defaults = dict(lr=lr, alpha=alpha, k=k, betas=betas, N_sma_threshhold=N_sma_threshhold, eps=eps,
                         weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.N_sma_threshhold, self.alpha, self.k = N_sma_threshhold, alpha, k
         self.use_gc, self.gc_conv_only, self.eps = use_gc, gc_conv_only, eps
+        self.use_gcnorm = use_gcnorm
         # capturable (extension, like torch.optim.Adam's): the step counter and the RAdam scalars live on the device,
         # so a step captured into a hipGraph (engine.GraphedTrainStep) replays without host-side changes.  All
         # parameters of a group then share one step count, and lr is baked into the captured graph.
@@ -63,9 +68,11 @@ class Ranger2020(Optimizer):
         if plan is not None:
             return plan
         chunk = _lib.lib().brats_ranger_chunk()
-        chunks, rows, rowlen, rowbase, nrows = [], [], [], [], 0
+        chunks, rows, rowlen, rowbase, nrows, chunkbase, nch = [], [], [], [], 0, [], 0
         for t, p in enumerate(active):
             n = p.numel()
+            chunkbase.append(nch)
+            nch += (n + chunk - 1) // chunk
             chunks.append(np.stack([np.full((n + chunk - 1) // chunk, t, np.int32),
                                     np.arange((n + chunk - 1) // chunk, dtype=np.int32)], 1))
             gc = self.use_gc and p.dim() > (3 if self.gc_conv_only else 1)
@@ -82,7 +89,10 @@ class Ranger2020(Optimizer):
             "chunks": torch.from_numpy(np.concatenate(chunks)).to(dev),
             "rows": torch.from_numpy(np.concatenate(rows)).to(dev) if rows else None,
             "means": torch.empty(max(nrows, 1), dtype=torch.float32, device=dev),
-            "nrows": nrows, "rowlen": rowlen, "rowbase": rowbase,
+            "nrows": nrows, "rowlen": rowlen, "rowbase": rowbase, "chunkbase": chunkbase,
+            # use_gcnorm workspaces: per-chunk (sum, sum of squares) and the per-tensor standard deviation
+            "chunk_stats": torch.empty((nch, 2), dtype=torch.float32, device=dev) if self.use_gcnorm else None,
+            "grad_std": torch.empty(len(active), dtype=torch.float32, device=dev) if self.use_gcnorm else None,
         }
         self._plans[key] = plan
         return plan
@@ -137,7 +147,7 @@ class Ranger2020(Optimizer):
                             state[name] = s.to(device=dev, dtype=torch.float32).contiguous()
                     state['step'] = int(state['step'])
                 rec[t] = (p.data_ptr(), 0, state['exp_avg'].data_ptr(), state['exp_avg_sq'].data_ptr(),
-                          state['slow_buffer'].data_ptr(), p.numel(), plan["rowlen"][t], plan["rowbase"][t], 0.0, 0.0, 0, 0)
+                          state['slow_buffer'].data_ptr(), p.numel(), plan["rowlen"][t], plan["rowbase"][t], 0.0, 0.0, 0, plan["chunkbase"][t])
             plan["rec"] = rec
             plan["states"] = [self.state[p] for p in active]
             plan["ptrs"] = [(int(r["param"]), int(r["exp_avg"]), int(r["exp_avg_sq"]), int(r["slow"])) for r in rec]
@@ -220,6 +230,7 @@ class Ranger2020(Optimizer):
             _lib.check(lib.brats_ranger_step(
                 table.data_ptr(), len(active), plan["chunks"].data_ptr(), plan["chunks"].shape[0],
                 plan["rows"].data_ptr() if plan["rows"] is not None else None, plan["nrows"], plan["means"].data_ptr(),
+                plan["chunk_stats"].data_ptr() if self.use_gcnorm else None, plan["grad_std"].data_ptr() if self.use_gcnorm else None,
                 dyn.data_ptr() if dyn is not None else None, beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha,
                 stream), "ranger_step")
             for p in active:  # the kernel wrote through raw pointers: tell autograd / the packed-weight cache

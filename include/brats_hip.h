@@ -302,7 +302,11 @@ int brats_overlap_counts(const float* pred, const float* target, unsigned long l
  *   step (step % k == 0); rowlen > 0 enables gradient centralisation over rows of `rowlen` elements
  *   (= numel / shape[0]) with the tensor's rows stored at row_means[row_base ...].
  * chunks: device int32 [nchunks][2] = (tensor index, chunk index), chunk = brats_ranger_chunk()
- * elements; rows: device int32 [nrows][2] = (tensor index, row) for every centralised row. */
+ * elements, tensor-major; rows: device int32 [nrows][2] = (tensor index, row) for every centralised row.
+ * use_gcnorm (learning/optimizer.py:23-36,189-190; off by default): pass chunk_stats (f32 [nchunks][2] workspace) and
+ * grad_std (f32 [ntensors] workspace) -- the centralised gradient of every tensor with more than two elements is
+ * divided by its unbiased standard deviation + 1e-8; both NULL = off.  (normloss, :192-198, is not built: the
+ * reference's own step() raises there.) */
 typedef struct {
   void* param;
   const void* grad;
@@ -315,7 +319,7 @@ typedef struct {
   float neg_step;
   float wd;
   int flags;
-  int reserved;
+  int chunk_base; /* index of the tensor's first entry in `chunks` (its chunks are consecutive) */
 } brats_ranger_tensor;
 /* Graph-capturable stepping: `dyn` (device) holds the step counter and the two step-dependent scalars;
  * brats_ranger_advance increments the counter and recomputes them on the device (f64), and
@@ -331,9 +335,9 @@ int brats_ranger_chunk(void);
 int brats_ranger_advance(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k,
                          double nsma_threshold, brats_stream_t s);
 int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int* chunks, int nchunks,
-                      const int* rows, int nrows, float* row_means, const brats_ranger_dyn* dyn,
-                      float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
-                      float alpha, brats_stream_t s);
+                      const int* rows, int nrows, float* row_means, float* chunk_stats, float* grad_std,
+                      const brats_ranger_dyn* dyn, float beta1, float beta2, float one_minus_beta1,
+                      float one_minus_beta2, float eps, float alpha, brats_stream_t s);
 
 /* ---- input pipeline on the GPU (the reference's CPU transform chain,
  * src/definer.py:449-467).  NCDHW f32.

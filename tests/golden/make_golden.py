@@ -235,7 +235,12 @@ RANGER_SHAPES = {"conv.weight": (6, 4, 3, 3, 3), "conv.bias": (6,), "fc.weight":
                  "unused": (3,)}
 RANGER_CASES = {"gc_wd": dict(use_gc=True, gc_conv_only=False, weight_decay=1e-2),
                 "convonly": dict(use_gc=True, gc_conv_only=True, weight_decay=0.0),
-                "plain": dict(use_gc=False, gc_conv_only=False, weight_decay=1e-5)}
+                "plain": dict(use_gc=False, gc_conv_only=False, weight_decay=1e-5),
+                # use_gcnorm: off by default in the reference (learning/optimizer.py:189-190).  (normloss, :192-198, cannot
+                # be pinned: the reference's step() raises "a leaf Variable that requires grad is being used in an in-place
+                # operation" at :198.)
+                "gcnorm": dict(use_gc=True, gc_conv_only=False, weight_decay=0.0, use_gcnorm=True),
+                "gcnorm_nogc": dict(use_gc=False, gc_conv_only=False, weight_decay=1e-3, use_gcnorm=True)}
 
 
 def ranger_fixture():
@@ -251,7 +256,7 @@ def ranger_fixture():
         params = {n: torch.nn.Parameter(synth.closed_form("rp." + n, s)) for n, s in RANGER_SHAPES.items()}
         with contextlib.redirect_stdout(io.StringIO()):
             opt = Ranger2020(list(params.values()), lr=1e-2, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999),
-                             eps=1e-5, use_gcnorm=False, normloss=False, gc_loc=True, **kw)
+                             eps=1e-5, gc_loc=True, **{"use_gcnorm": False, "normloss": False, **kw})
         for step in range(1, 14):
             for n, p in params.items():
                 p.grad = None if n == "unused" else synth.closed_form(f"rg.{n}.{step}", RANGER_SHAPES[n], 0.1 * step)
