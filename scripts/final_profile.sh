@@ -19,4 +19,7 @@ python3 bench.py --model equiunet_assp_evo --graph --steps 10 --warmup 3 --no-in
 python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --graph --steps 10 --warmup 3 --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_assp64_fp8_graph.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp -- python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline > /dev/null 2>&1
 cp $out/stats_assp/*/*kernel_stats.csv $out/bench_assp_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp64 -- python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --steps 10 --warmup 3 --no-infer --no-cpu-baseline > /dev/null 2>&1
+cp $out/stats_assp64/*/*kernel_stats.csv $out/bench_assp64_fp8_kernel_stats.csv
+PYTHONPATH=. python3 scripts/time_wgrad_f8.py > $out/wgrad_f8_table.txt 2>/dev/null
 tail -c 600 $out/bench.json; echo; cat $out/pmc_conv.txt | cut -c1-250
