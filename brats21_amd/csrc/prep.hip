@@ -115,6 +115,82 @@ __global__ void gamma_noise_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
+// GaussianSmooth (MONAI 0.6 GaussianFilter = separable zero-padded correlations, one per spatial axis): one axis of a tensor
+// viewed as [outer][L][inner]; the taps (host-computed, erf-integrated, <= 63) sit in LDS
+__global__ void __launch_bounds__(256) blur_axis_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t outer, int L,
+                                                        size_t inner, const float* __restrict__ taps, int ntaps) {
+  __shared__ float tp[64];
+  if ((int)threadIdx.x < ntaps) tp[threadIdx.x] = taps[threadIdx.x];
+  __syncthreads();
+  const int r = ntaps / 2;
+  const size_t total = outer * L * inner;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+    const size_t v = it % inner;
+    const int i = (int)((it / inner) % L);
+    const size_t o = it / (inner * L);
+    const float* line = src + o * L * inner + v;
+    const int k0 = i - r < 0 ? r - i : 0, k1 = i + r > L - 1 ? L - 1 - i + r : ntaps - 1;
+    float acc = 0.f;
+    for (int k = k0; k <= k1; ++k) acc += tp[k] * line[(size_t)(i + k - r) * inner];  // tap order = the convolution's summation order
+    dst[it] = acc;
+  }
+}
+
+// CropForeground's bounding box (MONAI generate_spatial_bounding_box, select_fn = x > 0 over ANY channel, margin 0):
+// bbox[n] = {z0, y0, x0, z1, y1, x1}, ends exclusive; min / max are order-independent, so integer atomics are exact
+__global__ void bbox_init_kernel(int* __restrict__ bbox, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * 6) bbox[i] = (i % 6) < 3 ? 0x7fffffff : 0;
+}
+__global__ void __launch_bounds__(256) foreground_bbox_kernel(const float* __restrict__ img, int C, int D, int H, int W,
+                                                              int* __restrict__ bbox) {
+  const int n = blockIdx.y;
+  const size_t vox = (size_t)D * H * W;
+  const float* base = img + (size_t)n * C * vox;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (size_t)gridDim.x * blockDim.x) {
+    bool fg = false;
+    for (int c = 0; c < C; ++c) fg |= base[(size_t)c * vox + v] > 0.f;
+    if (fg) {
+      const int x = (int)(v % W), y = (int)((v / W) % H), z = (int)(v / ((size_t)W * H));
+      lo[0] = min(lo[0], z); lo[1] = min(lo[1], y); lo[2] = min(lo[2], x);
+      hi[0] = max(hi[0], z + 1); hi[1] = max(hi[1], y + 1); hi[2] = max(hi[2], x + 1);
+    }
+  }
+  __shared__ int slo[3], shi[3];
+  if (threadIdx.x < 3) { slo[threadIdx.x] = 0x7fffffff; shi[threadIdx.x] = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (lo[a] != 0x7fffffff) { atomicMin(&slo[a], lo[a]); atomicMax(&shi[a], hi[a]); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && slo[threadIdx.x] != 0x7fffffff) {
+    atomicMin(&bbox[n * 6 + threadIdx.x], slo[threadIdx.x]);
+    atomicMax(&bbox[n * 6 + 3 + threadIdx.x], shi[threadIdx.x]);
+  }
+}
+
+extern "C" int brats_blur_axis(const float* src, float* dst, size_t outer, int L, size_t inner, const float* taps, int ntaps,
+                               brats_stream_t s) {
+  if (!src || !dst || !taps || src == dst || L <= 0 || ntaps < 1 || ntaps > 63 || !(ntaps & 1))
+    BRATS_FAIL(BRATS_E_ARG, "blur_axis: bad argument (odd tap count <= 63, out of place)");
+  hipLaunchKernelGGL(blur_axis_kernel, dim3(qgrid(outer * L * inner)), dim3(256), 0, (hipStream_t)s, src, dst, outer, L, inner, taps, ntaps);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int brats_foreground_bbox(const float* img, int N, int C, int D, int H, int W, int* bbox, brats_stream_t s) {
+  if (!img || !bbox || N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) BRATS_FAIL(BRATS_E_ARG, "foreground_bbox: bad argument");
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3((N * 6 + 63) / 64), dim3(64), 0, st, bbox, N);
+  size_t gx = ((size_t)D * H * W + 255) / 256 / 4;
+  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+  hipLaunchKernelGGL(foreground_bbox_kernel, dim3((unsigned)gx, N), dim3(256), 0, st, img, C, D, H, W, bbox);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int brats_crop_perm(const float* src, float* dst, int planes, int s0, int s1, int s2, int c0, int c1, int c2, int e0,
                                int e1, int e2, int p0, int p1, int p2, int f0, int f1, int f2, const float* scale,
                                const float* shift, brats_stream_t s) {

@@ -4,8 +4,9 @@ training patch (src/definer.py:449-467), as a handful of fused HIP kernels on ba
 deterministic given its arguments, which is how the parity tests drive it.
 
 Names follow the reference / MONAI transforms they replace: NormalizeIntensity (utils/transforms.py:328),
-ConvertToMultiChannelBasedOnBratsClasses (:145 / MONAI), RandSpatialCrop + RandRotate90 + RandFlip +
-RandShiftIntensity (one gather), RandAdjustContrast + RandGaussianNoise (one pass).
+ConvertToMultiChannelBasedOnBratsClasses (:145 / MONAI), CropForeground (bounding box by integer atomics) + SpatialPad
+/ DivisiblePad, RandSpatialCrop + RandRotate90 + RandFlip + RandShiftIntensity (one gather), RandAdjustContrast +
+RandGaussianNoise (one pass), RandGaussianSmooth (three separable passes).
 """
 import numpy as np
 import torch
@@ -105,11 +106,75 @@ def gamma_noise(x, gamma=None, noise=None):
     return out
 
 
+def gaussian_smooth(x, sigma):
+    """MONAI 0.6 GaussianSmooth(sigma=(s0, s1, s2), approx="erf") on [N, C, D, H, W] f32 (RandGaussianSmoothd,
+    src/definer.py:464): GaussianFilter's zero-padded separable correlations, axis 0 first, the same kernel for every
+    channel; taps = the Gaussian integrated over unit cells, cut at round(4 sigma) either side."""
+    from .inferers import _gaussian_taps
+    x = _need(x, "gaussian_smooth")
+    if x.dim() != 5 or len(sigma) != 3:
+        raise ValueError("gaussian_smooth: expected [N, C, D, H, W] and three sigmas")
+    n, c, d, h, w = x.shape
+    cur = x
+    for ax, sg in enumerate(sigma):
+        taps = _gaussian_taps(sg)
+        if taps.numel() == 1 and float(taps[0]) == 1:
+            continue
+        taps = taps.to(x.device)
+        out = torch.empty_like(cur)
+        outer, length, inner = (n * c, d, h * w) if ax == 0 else ((n * c * d, h, w) if ax == 1 else (n * c * d * h, w, 1))
+        _lib.check(_lib.lib().brats_blur_axis(cur.data_ptr(), out.data_ptr(), outer, length, inner, taps.data_ptr(), taps.numel(),
+                                              _stream()), "blur_axis")
+        cur = out
+    return cur if cur is not x else x.clone()
+
+
+def foreground_bbox(img):
+    """Per-sample box of MONAI CropForegroundd(source_key="img") (src/definer.py:452: voxels with any channel > 0, margin
+    0) of [N, C, D, H, W]: int32 device tensor [N, 6] = (z0, y0, x0, z1, y1, x1), ends exclusive."""
+    x = _need(img, "foreground_bbox")
+    if x.dim() != 5:
+        raise ValueError("foreground_bbox: expected [N, C, D, H, W]")
+    box = torch.empty((x.shape[0], 6), dtype=torch.int32, device=x.device)
+    _lib.check(_lib.lib().brats_foreground_bbox(x.data_ptr(), *x.shape, box.data_ptr(), _stream()), "foreground_bbox")
+    return box
+
+
+def crop_foreground(img, seg=None):
+    """CropForegroundd(keys=["img", "seg"], source_key="img") for ONE volume ([1, C, D, H, W]; boxes differ between
+    volumes).  The box comes back to the host (it decides tensor shapes); an image without foreground raises ValueError
+    like MONAI 0.6.0 (np.min of an empty index list)."""
+    if img.shape[0] != 1:
+        raise ValueError("crop_foreground: one volume at a time (the boxes of different volumes differ)")
+    z0, y0, x0, z1, y1, x1 = (int(v) for v in foreground_bbox(img)[0].cpu())
+    if z0 > z1:
+        raise ValueError("crop_foreground: the image has no voxel > 0")
+    crop = img[:, :, z0:z1, y0:y1, x0:x1].contiguous()
+    return crop if seg is None else (crop, seg[:, :, z0:z1, y0:y1, x0:x1].contiguous())
+
+
+def spatial_pad(x, size):
+    """SpatialPadd(spatial_size, method="symmetric") (src/definer.py:453): zero-pad [N, C, D, H, W] up to `size` per axis
+    (floor half in front); never crops."""
+    pads = []
+    for have, want in zip(reversed(x.shape[2:]), reversed(tuple(size))):
+        w = max(int(want) - have, 0)
+        pads += [w // 2, w - w // 2]
+    return torch.nn.functional.pad(x, pads) if any(pads) else x
+
+
+def divisible_pad(x, k=8):
+    """DivisiblePadd(k=8) (src/definer.py:465)."""
+    return spatial_pad(x, [-(-s // k) * k for s in x.shape[2:]])
+
+
 class TrainAugment:
     """The random part of the reference's training chain (src/definer.py:458-466) on GPU-resident, already padded
     volumes: RandSpatialCrop(roi) -> RandRotate90(p=0.7, axes (0, 2)) -> RandFlip(p=0.7, all axes) ->
     RandShiftIntensity(p=0.7, 0.1) -> RandAdjustContrast(p=0.2, gamma 0.5..4.5) -> RandGaussianNoise(p=0.5, std 0.1)
-    -> NormalizeIntensity(nonzero, channel-wise).  RandGaussianSmooth (p=0.2) is not built."""
+    -> RandGaussianSmooth(p=0.2, sigma 0.25..1.5 per axis) -> NormalizeIntensity(nonzero, channel-wise).  (The patch size
+    is a multiple of 8, so DivisiblePadd(8) is the identity here; CropForeground / SpatialPad run once per volume:
+    crop_foreground, spatial_pad.)"""
 
     def __init__(self, roi_size, seed=None, remove_outliers=False):
         self.roi, self.R, self.remove_outliers = tuple(roi_size), np.random.RandomState(seed), remove_outliers
@@ -124,6 +189,7 @@ class TrainAugment:
             "offset": float(self.R.uniform(-0.1, 0.1)) if self.R.rand() < 0.7 else 0.0,
             "gamma": float(self.R.uniform(0.5, 4.5)) if self.R.rand() < 0.2 else None,
             "noise_std": float(self.R.uniform(0, 0.1)) if self.R.rand() < 0.5 else None,
+            "smooth": tuple(float(self.R.uniform(0.25, 1.5)) for _ in range(3)) if self.R.rand() < 0.2 else None,
         }
 
     def __call__(self, img, seg, params=None):
@@ -137,4 +203,6 @@ class TrainAugment:
         if p["gamma"] is not None or p["noise_std"] is not None:
             noise = torch.randn_like(x) * p["noise_std"] if p["noise_std"] is not None else None
             x = gamma_noise(x, p["gamma"], noise)
+        if p.get("smooth") is not None:
+            x = gaussian_smooth(x, p["smooth"])
         return normalize_intensity(x, nonzero=True, channel_wise=True, remove_outliers=self.remove_outliers), y

@@ -352,6 +352,15 @@ int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int*
  *   (1 when 0), clip > 0 clamps to +-clip; zeros stay zero.  stats = f64 workspace [planes][3].
  * gamma_noise: MONAI AdjustContrast ((x - min)/(range + 1e-7))^gamma * range + min (gamma <= 0: skipped)
  *   followed by + noise (may be NULL): RandAdjustContrastd + RandGaussianNoised (:463-464). */
+/* blur_axis: one axis of MONAI 0.6 GaussianSmooth / GaussianFilter (RandGaussianSmoothd, src/definer.py:464) on a tensor
+ *   viewed as [outer][L][inner] f32: dst[o][i][v] = sum_k taps[k] * src[o][i + k - ntaps/2][v], zeros outside; taps = device
+ *   f32 [ntaps], ntaps odd <= 63 (host-computed erf-integrated kernel, truncated at 4 sigma); out of place.
+ * foreground_bbox: the box of MONAI CropForegroundd(source_key="img") (src/definer.py:452; select_fn x > 0 over any
+ *   channel, margin 0) per sample of an NCDHW f32 batch: bbox[n] = {z0, y0, x0, z1, y1, x1}, ends exclusive;
+ *   z0 = INT_MAX for a sample without foreground. */
+int brats_blur_axis(const float* src, float* dst, size_t outer, int L, size_t inner, const float* taps, int ntaps,
+                    brats_stream_t s);
+int brats_foreground_bbox(const float* img, int N, int C, int D, int H, int W, int* bbox, brats_stream_t s);
 int brats_crop_perm(const float* src, float* dst, int planes, int s0, int s1, int s2, int c0, int c1, int c2,
                     int e0, int e1, int e2, int p0, int p1, int p2, int f0, int f1, int f2,
                     const float* scale, const float* shift, brats_stream_t s);

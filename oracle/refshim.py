@@ -150,6 +150,25 @@ def _gaussian_1d(sigma, truncated=4.0):
     return out.clamp(min=0)
 
 
+def _gaussian_filter(x, sigmas, truncated=4.0):
+    """monai.networks.layers.GaussianFilter(spatial_dims, sigma, truncated=4.0, approx="erf").forward of MONAI 0.6.0 on
+    x [B, C, *spatial]: separable_filtering with zero padding -- one grouped convolution per spatial axis (every channel
+    filtered by the same kernel), axis 0 first.  Restated (MONAI is absent here): parity at this boundary stays unpinned."""
+    nsp = x.dim() - 2
+    conv = [F.conv1d, F.conv2d, F.conv3d][nsp - 1]
+    c = x.shape[1]
+    for ax, s in enumerate(sigmas):
+        k = _gaussian_1d(s, truncated)
+        if k.numel() == 1 and float(k[0]) == 1:  # (a unit kernel is skipped)
+            continue
+        shape = [1, 1] + [1] * nsp
+        shape[ax + 2] = -1
+        pad = [0] * nsp
+        pad[ax] = (k.numel() - 1) // 2
+        x = conv(x, k.reshape(shape).repeat([c, 1] + [1] * nsp), padding=pad, groups=c)
+    return x
+
+
 def _compute_importance_map(patch_size, mode="constant", sigma_scale=0.125, device=None):
     """monai.data.utils.compute_importance_map of MONAI 0.6.0 (called at utils/inferers.py:119-121).  gaussian: a unit
     delta at patch // 2 filtered by GaussianFilter(sigmas = sigma_scale * patch) -- separable zero-padded convolutions

@@ -90,3 +90,29 @@ def test_gaussian_importance_map_is_monai_gaussian_filter_of_a_delta():
     # sigma so small that the 4-sigma cut leaves cells untouched: they get the smallest non-zero weight, never 0
     a, b = importance_map((16, 16, 16), "gaussian", 0.03), _compute_importance_map((16, 16, 16), "gaussian", 0.03)
     assert torch.equal(a, b) and float(a.min()) > 0 and float(a[0, 0, 0]) == float(a.min())
+
+
+def test_oracle_input_pipeline_known_answers():
+    """CropForeground / SpatialPad / DivisiblePad / GaussianSmooth restatements (oracle/prep.py; MONAI 0.6.0 is absent, so
+    these are known-answer checks, not pinned parity)."""
+    import numpy as np
+    from oracle import prep
+    img = np.zeros((2, 6, 7, 8), np.float32)
+    img[0, 1:4, 2:5, 3] = 1.0
+    img[1, 5, 6, 7] = 0.5
+    img[1, 0, 0, 0] = -3.0                         # not foreground (x > 0)
+    assert prep.foreground_bbox(img) == ([1, 2, 3], [6, 7, 8])
+    x, y = prep.crop_foreground(img, img[:1])
+    assert x.shape == (2, 5, 5, 5) and y.shape == (1, 5, 5, 5)
+    p = prep.spatial_pad(x, (8, 5, 6))             # 3 missing -> 1 in front, 2 behind; 1 missing -> 0 in front, 1 behind
+    assert p.shape == (2, 8, 5, 6) and np.array_equal(p[:, 1:6, :, 0:5], x) and p[:, 0].sum() == 0 and p[:, 6:].sum() == 0
+    assert prep.divisible_pad(x, 8).shape == (2, 8, 8, 8) and prep.divisible_pad(p[:, :8, :, :], 4).shape == (2, 8, 8, 8)
+    # GaussianFilter: the response to a unit delta is the outer product of the erf-integrated tap vectors; sigma 0.25 ->
+    # 3 taps, sigma 1.5 -> 13 taps (tail = int(max(4 sigma, 0.5) + 0.5)); mass is preserved away from the faces
+    d = np.zeros((1, 15, 15, 15), np.float32)
+    d[0, 7, 7, 7] = 1
+    g = prep.gaussian_smooth(d, (0.25, 1.5, 1.0))[0]
+    nz = np.nonzero(g > 0)
+    assert [int(i.max() - i.min()) + 1 for i in nz] == [3, 13, 9]
+    assert abs(float(g.sum()) - 1.0) < 2e-4 and np.isclose(g[7, 7, 7], g.max())
+    assert np.allclose(g, g[::-1, ::-1, ::-1])
