@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(256) ranger_update_kernel(const brats_ranger_t
 
 // step += 1; neg_step / flags of learning/optimizer.py:198-214 in f64 on the device (one thread), so that a captured
 // hipGraph can be replayed without any host-side change between steps
-__global__ void ranger_advance_kernel(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k, double nsma_thr) {
+__global__ void ranger_advance_kernel(brats_ranger_dyn* dyn, double lr_host, double beta1, double beta2, int k, double nsma_thr) {
+  const double lr = lr_host >= 0.0 ? lr_host : dyn->lr;  // lr < 0: the learning rate lives on the device (LR schedules under replay)
   const int step = dyn->step + 1;
   const double b2t = pow(beta2, (double)step);
   const double nmax = 2.0 / (1.0 - beta2) - 1.0;
@@ -143,6 +144,7 @@ extern "C" int brats_ranger_chunk(void) { return RANGER_CHUNK; }
 extern "C" int brats_ranger_advance(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k, double nsma_threshold,
                                     brats_stream_t s) {
   if (!dyn || k < 1) BRATS_FAIL(BRATS_E_ARG, "ranger_advance: bad argument");
+  // (lr < 0 = read dyn->lr: a captured hipGraph then follows a learning-rate schedule without being re-captured)
   hipLaunchKernelGGL(ranger_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, dyn, lr, beta1, beta2, k, nsma_threshold);
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -50,8 +50,9 @@ class GraphedTrainStep:
 
     Requirements: fixed input shapes, an optimizer whose step is capturable (brats21_amd.optim.Ranger2020(capturable=
     True), or a torch optimizer constructed with capturable=True).  ``warmup`` eager steps run on the first batch before
-    the capture (lazy initialisation, allocator warm-up): they are real steps.  The learning rate is baked into the
-    graph: re-create the object after changing it.
+    the capture (lazy initialisation, allocator warm-up): they are real steps.  With brats21_amd.optim.Ranger2020 the
+    learning rate is a device scalar that is refreshed before every replay, so LR schedulers (the reference steps
+    its scheduler once per epoch, learning/engine.py:151-155) work without a re-capture; a torch optimizer bakes lr in.
 
     Data parallel: with ``step.buckets`` (brats21_amd.ddp.GradientBuckets over the RCCL backend) the bucketed all-reduces
     are captured too -- the backward program pushes gradients into the buckets, each bucket's collective is forked onto
@@ -98,6 +99,9 @@ class GraphedTrainStep:
                 self.static_image.copy_(image, non_blocking=True)
             if target.data_ptr() != self.static_target.data_ptr():
                 self.static_target.copy_(target, non_blocking=True)
+            sync_lr = getattr(self.step.optimizer, "sync_lr", None)
+            if sync_lr is not None:
+                sync_lr()  # (a scheduler may have changed group["lr"] since the last replay)
         self.graph.replay()
         ops.invalidate_packed_weights()  # the replayed optimizer kernels changed the weights behind autograd's back
         return self.static_loss

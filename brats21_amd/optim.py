@@ -56,7 +56,8 @@ class Ranger2020(Optimizer):
         self.use_gcnorm = use_gcnorm
         # capturable (extension, like torch.optim.Adam's): the step counter and the RAdam scalars live on the device,
         # so a step captured into a hipGraph (engine.GraphedTrainStep) replays without host-side changes.  All
-        # parameters of a group then share one step count, and lr is baked into the captured graph.
+        # parameters of a group then share one step count; the learning rate is a device scalar too (sync_lr() rewrites
+        # it when an LR scheduler changed group["lr"]: no re-capture).
         self.capturable = capturable
         self._plans = {}
 
@@ -101,6 +102,19 @@ class Ranger2020(Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._plans = {}  # the state tensors were replaced: cached pointer tables are stale
+
+    def sync_lr(self):
+        """capturable mode: copy every group's current lr into its device scalar (call between graph replays after an LR
+        scheduler stepped; GraphedTrainStep does).  A no-op while nothing changed."""
+        for (gi, _), plan in self._plans.items():
+            dyn = plan.get("dyn")
+            if dyn is not None:
+                lr = float(self.param_groups[gi]["lr"])
+                if plan.get("lr_dev") != lr:
+                    if torch.cuda.is_current_stream_capturing():
+                        raise _lib.BratsHipError("Ranger2020: the learning rate changed inside a hipGraph capture")
+                    dyn[4:6].view(torch.float64).fill_(lr)
+                    plan["lr_dev"] = lr
 
     def sync_steps(self):
         """capturable mode: graph replays advance only the device-side step counters; copy them into state['step']."""
@@ -203,9 +217,15 @@ class Ranger2020(Optimizer):
                 if len(cache) != 1:
                     raise _lib.BratsHipError("Ranger2020(capturable=True): all parameters of a group must share one step count")
                 dyn = plan.get("dyn")
-                if dyn is None:  # {step, flags, neg_step, reserved}; starts at the step count BEFORE this step
-                    dyn = plan["dyn"] = torch.tensor([steps[0] - 1, 0, 0, 0], dtype=torch.int32, device=dev)
-                _lib.check(lib.brats_ranger_advance(dyn.data_ptr(), float(lr), float(beta1), float(beta2), int(k),
+                if dyn is None:  # brats_ranger_dyn {step, flags, neg_step, reserved, double lr}; step = the count BEFORE this step
+                    if capturing:
+                        raise _lib.BratsHipError("Ranger2020(capturable=True): run one eager step before capturing (state allocation)")
+                    dyn = plan["dyn"] = torch.tensor([steps[0] - 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+                if not capturing:
+                    self.sync_lr()
+                elif plan.get("lr_dev") != float(lr):
+                    raise _lib.BratsHipError("Ranger2020: the learning rate changed between the warm-up steps and the capture")
+                _lib.check(lib.brats_ranger_advance(dyn.data_ptr(), -1.0, float(beta1), float(beta2), int(k),
                                                     float(self.N_sma_threshhold), stream), "ranger_advance")
             elif capturing:
                 raise _lib.BratsHipError("Ranger2020.step() inside a hipGraph capture needs capturable=True")

@@ -324,12 +324,15 @@ typedef struct {
 /* Graph-capturable stepping: `dyn` (device) holds the step counter and the two step-dependent scalars;
  * brats_ranger_advance increments the counter and recomputes them on the device (f64), and
  * brats_ranger_step with dyn != NULL reads them instead of the table's neg_step / flags -- a captured
- * hipGraph of (advance, step) replays without host-side changes.  dyn == NULL: host-computed scalars. */
+ * hipGraph of (advance, step) replays without host-side changes.  dyn == NULL: host-computed scalars.
+ * brats_ranger_advance(lr < 0) reads the learning rate from dyn->lr instead of the argument: the host rewrites those
+ * 8 bytes between replays when an LR scheduler (the reference's --decay_type, learning/engine.py:151-155) changed it. */
 typedef struct {
   int step;
   int flags;
   float neg_step;
   int reserved;
+  double lr;
 } brats_ranger_dyn;
 int brats_ranger_chunk(void);
 int brats_ranger_advance(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k,

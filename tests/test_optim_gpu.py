@@ -113,3 +113,39 @@ def test_graphed_train_step_matches_eager():
     worst = max(float((a - b).abs().max()) for a, b in zip(p0, p1))
     assert worst < 1e-5, worst
     assert o1.state_dict()["state"][0]["step"] == 10 == o0.state_dict()["state"][0]["step"]
+
+
+def test_graphed_train_step_follows_a_learning_rate_schedule():
+    """An LR scheduler changes group["lr"] between steps (the reference steps its scheduler once per epoch,
+    learning/engine.py:151-155): the captured graph must follow without a re-capture (device-side lr scalar)."""
+    from brats21_amd import get_model
+    from brats21_amd.engine import GraphedTrainStep, TrainStep
+    from brats21_amd.optim import Ranger2020
+    from oracle import synth
+    ns = argparse.Namespace(model="equiunet", width=8, norm="group", act="relu", num_classes=3, dropout=0)
+    x = synth.random_image(1, 4, (16, 16, 16), seed=31).to(DEV)
+    t = synth.nested_spheres(1, (16, 16, 16)).to(DEV)
+    lrs = [1e-2] * 4 + [4e-3] * 3 + [5e-4] * 3     # steps 1..10; the graph is captured at step 3
+    outs = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = get_model(ns).to(DEV).train()
+        opt = Ranger2020(m.parameters(), lr=lrs[0], use_gc=True, capturable=graphed)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 1.0)  # (a real scheduler object drives group["lr"])
+        step = TrainStep(m, opt, amp=True)
+        if graphed:
+            step = GraphedTrainStep(step, warmup=2)
+        done = 0
+        while done < len(lrs):
+            for g in opt.param_groups:
+                g["lr"] = lrs[done]
+            sched.last_epoch += 1
+            step(x, t)
+            done += 3 if (graphed and done == 0) else 1   # first graphed call = 2 warm-ups + capture replay
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for p in m.parameters()])
+    worst = max(float((a - b).abs().max()) for a, b in zip(*outs))
+    assert worst < 1e-5, worst
+    # and the schedule mattered: a constant-lr run ends elsewhere
+    assert lrs[0] != lrs[-1]
