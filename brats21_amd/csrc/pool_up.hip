@@ -195,6 +195,91 @@ __global__ void __launch_bounds__(256) upsample_fwd_kernel(const T* __restrict__
   }
 }
 
+// scale 2 (the decoder's up-sampling): one block = 2 output z-planes x 4 output y-rows of one sample, a thread = one (xo,
+// channel vector) column of that 2 x 4 patch.  The 8 outputs read the same 3 input planes x 4 input rows, so a thread does
+// 24 gathers for 8 outputs instead of 64 (the row-per-block kernel above is bound by its 8 gathers per 16-byte store), and
+// every store instruction still writes a contiguous x-row.  Weights of absent (plane, row) pairs are zero; same f32
+// coefficients as lerp_coef, summed x first, then y, then z.
+template <typename T, bool NT = false>
+__global__ void __launch_bounds__(256) upsample2_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch,
+                                                            int C, int D, int H, int W, float sd, float sh, float sw) {
+  constexpr int VW = 16 / sizeof(T);
+  const int cv = C / VW, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const int yq = blockIdx.x, zp = blockIdx.y, n = blockIdx.z;
+  const int zo0 = 2 * zp, yo0 = 4 * yq;
+  Lerp lz[2], ly[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) lz[a] = lerp_coef(zo0 + a, D, sd);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) ly[b] = lerp_coef(yo0 + b, H, sh);
+  const int zb = lz[0].i0, yb = ly[0].i0;
+  float wz[2][3], wy[4][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) wz[a][pz] = (lz[a].i0 == zb + pz ? lz[a].w0 : 0.f) + (lz[a].i1 == zb + pz ? lz[a].w1 : 0.f);
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wy[b][r] = (ly[b].i0 == yb + r ? ly[b].w0 : 0.f) + (ly[b].i1 == yb + r ? ly[b].w1 : 0.f);
+  const T* xb = x + (size_t)n * D * H * W * xpitch;
+  T* yb_ = y + (size_t)n * Do * Ho * Wo * ypitch;
+  // pairs of channels through explicit v_pk_fma_f32: with separate multiplies and adds (the build's -ffp-contract=off) the
+  // ~1400 packed ops per 8 outputs made this kernel VALU-bound at 2.3 TB/s
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  auto fma2 = [](float w, f2 v, f2 acc) { return __builtin_elementwise_fma(f2{w, w}, v, acc); };
+  constexpr int V2 = VW / 2;
+  for (int it = threadIdx.x; it < Wo * cv; it += blockDim.x) {
+    const int xo = it / cv, c0 = (it % cv) * VW;
+    const Lerp lx = lerp_coef(xo, W, sw);
+    f2 o[2][4][V2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < V2; ++j) o[a][b][j] = f2{0.f, 0.f};
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) {
+      const int zi = zb + pz < D ? zb + pz : D - 1;   // (a clamped plane / row carries zero weight)
+      f2 t[4][V2];                                    // y-interpolated rows of this plane, per output row b
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < V2; ++j) t[b][j] = f2{0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yi = yb + r < H ? yb + r : H - 1;
+        const T* row = xb + (size_t)(zi * H + yi) * W * xpitch + c0;
+        float v0[VW], v1[VW];
+        Vec<T, VW>::load(row + (size_t)lx.i0 * xpitch, v0);
+        Vec<T, VW>::load(row + (size_t)lx.i1 * xpitch, v1);
+#pragma unroll
+        for (int j = 0; j < V2; ++j) {
+          const f2 xl = fma2(lx.w1, f2{v1[2 * j], v1[2 * j + 1]}, lx.w0 * f2{v0[2 * j], v0[2 * j + 1]});
+#pragma unroll
+          for (int b = 0; b < 4; ++b) t[b][j] = fma2(wy[b][r], xl, t[b][j]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int j = 0; j < V2; ++j) o[a][b][j] = fma2(wz[a][pz], t[b][j], o[a][b][j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        float of[VW];
+#pragma unroll
+        for (int j = 0; j < V2; ++j) { of[2 * j] = o[a][b][j][0]; of[2 * j + 1] = o[a][b][j][1]; }
+        vstore<T, VW, NT>(yb_ + ((size_t)((zo0 + a) * Ho + yo0 + b) * Wo + xo) * ypitch + c0, of);
+      }
+  }
+}
+
 extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
                                   int W, int scale, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
@@ -203,6 +288,20 @@ extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch
   const size_t rows = (size_t)N * D * scale * H * scale;
   const unsigned grid = (unsigned)(rows > 65536 ? 65536 : rows);
   const float sd = ac_scale(D, D * scale), sh = ac_scale(H, H * scale), sw = ac_scale(W, W * scale);
+  if (scale == 2 && H % 2 == 0 && N <= 65535 && D <= 65535) {
+    const dim3 g2(H / 2, D, N);  // (Ho / 4, Do / 2, N)
+    if (dtype == BRATS_BF16 && stream_nt((size_t)N * D * H * W * 8 * C * 2))  // output beyond the Infinity Cache: non-temporal stores
+      hipLaunchKernelGGL((upsample2_fwd_kernel<bf16_t, true>), g2, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch,
+                         C, D, H, W, sd, sh, sw);
+    else if (dtype == BRATS_BF16)
+      hipLaunchKernelGGL(upsample2_fwd_kernel<bf16_t>, g2, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch,
+                         C, D, H, W, sd, sh, sw);
+    else
+      hipLaunchKernelGGL(upsample2_fwd_kernel<float>, g2, dim3(256), 0, (hipStream_t)s, (const float*)x, xpitch, (float*)y, ypitch,
+                         C, D, H, W, sd, sh, sw);
+    BRATS_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, xpitch,
                        (bf16_t*)y, ypitch, N, C, D, H, W, scale, sd, sh, sw);

@@ -174,7 +174,7 @@ def test_pool_fwd_bwd(dtype, with_avg):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("size,scale", [((4, 4, 4), 2), ((2, 6, 4), 2), ((4, 4, 4), 4)])
+@pytest.mark.parametrize("size,scale", [((4, 4, 4), 2), ((2, 6, 4), 2), ((4, 4, 4), 4), ((3, 5, 6), 2), ((8, 10, 12), 2)])
 def test_upsample_fwd_bwd(dtype, size, scale):
     from brats21_amd import ops
     dev = _dev()
