@@ -358,6 +358,14 @@ __global__ void lerp_adjoint_kernel(const TI* __restrict__ in, int in_pitch, TO*
 int brats_lerp_adjoint_f32_planes(const float* in, float* out, size_t outer, int Lout, int Lin, size_t inner,
                                   hipStream_t st) {
   const size_t total = outer * Lin * inner;
+  if (inner % 4 == 0 && (((size_t)in | (size_t)out) & 15) == 0) {
+    // four neighbouring inner elements per thread (16-byte loads): these planes are bound by the NUMBER of vector-memory
+    // instructions (one per candidate l per thread), not by their bytes
+    hipLaunchKernelGGL((lerp_adjoint_kernel<float, float, 4>), dim3(stream_grid(total / 4, 256)), dim3(256), 0, st, in, 4, out, 4,
+                       outer, Lout, Lin, inner / 4, 4, ac_scale(Lin, Lout));
+    BRATS_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL((lerp_adjoint_kernel<float, float, 1>), dim3(stream_grid(total, 256)), dim3(256), 0, st, in, 1, out, 1,
                      outer, Lout, Lin, inner, 1, ac_scale(Lin, Lout));
   BRATS_CHECK_LAUNCH();
