@@ -490,19 +490,40 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
 //    tiles at 128^3) costs ONE v_add per piece instead of ~20 VALU instructions of unpack / range tests / multiply-adds,
 //    which used to run in both waves of every SIMD at the same time, with the matrix pipe idle;
 //  * the freed registers carry one more B fragment in flight (prefetch distance 3).
-struct Wg3b {
+// a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop
+// into registers the accumulators need.  (The host pass of hipcc instantiates the kernel template's generic lambdas too
+// and silently drops the kernel stub when it meets a "v" constraint there, hence the device-pass guard.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OPAQUE_V(x) asm volatile("" : "+v"(x))
+#else
+#define OPAQUE_V(x) do { } while (0)
+#endif
+
+// one LDS-DMA instruction: lane l's 16 bytes at buffer offset `off` (out of range: zeros) land at dst + 16 l; dst wave-uniform.
+// (A function of its own: called directly inside the kernel TEMPLATE's generic lambdas the builtin makes hipcc's host pass
+// drop the kernel stub without a diagnostic.)
+DEVI void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, int off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+}
+
+// Two block shapes: 48 co x 48 ci (COF, CIF = 3, 3: widths 48 / 96 / ...) and 64 co x 32 ci (4, 2: widths that are multiples
+// of 64 but not of 48 -- EquiUnetASSPEvo-64; 54 (tap, ci-fragment) pairs, 7 x 4 accumulators per lane, X 2 x 48 KB + dY 32 KB).
+template <int COF, int CIF> struct Wg3b {
   static constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, HVOX = HZ * HY * HX;   // 6 x 6 x 18
-  static constexpr int SX = 96, SY = 96, XPPV = 6, YPPV = 6;
-  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;   // 3888, 1536
-  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;   // 8, 3 per thread
-  static constexpr int XB = XI * 512 * 16;                               // 65536: a whole number of 1-KB DMA rows per wave
-  static constexpr int LDS = 2 * XB + WG_VOX * SY;                       // 155648
-  static constexpr int PAIRS = 81, PPW = 11;
+  static constexpr int CO = 16 * COF, CI = 16 * CIF;
+  static constexpr int SX = 2 * CI, SY = 2 * CO, XPPV = CI / 8, YPPV = CO / 8;
+  static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;   // 3888, 1536 | 2592, 2048
+  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;   // 8, 3 | 6, 4 per thread
+  static constexpr int XB = XI * 512 * 16;                               // 65536 | 49152: a whole number of 1-KB DMA rows per wave
+  static constexpr int LDS = 2 * XB + WG_VOX * SY;                       // 155648 | 131072
+  static constexpr int PAIRS = 27 * CIF, PPW = (PAIRS + 7) / 8;          // 81, 11 | 54, 7
+  static_assert(YPIECES % 512 == 0, "");
 };
 
+template <int COF, int CIF>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const WgradParams p) {
   typedef bf16_t T;
-  using G = Wg3b;
+  using G = Wg3b<COF, CIF>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldy = lds + 2 * G::XB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -512,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
   const int split = blockIdx.x;
   const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
   const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
-  const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 48;
+  const int co0 = blockIdx.y * G::CO, ci0 = blockIdx.z * G::CI;
   const T* xsrc;
   int xpitch;
   if (ci0 < p.c1) { xsrc = (const T*)p.x1 + ci0; xpitch = p.p1; }
@@ -538,14 +559,14 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
 #pragma unroll
   for (int jj = 0; jj < G::PPW; ++jj) {
     const int pid = wave + 8 * jj;
-    const int t = pid / 3, nn = pid % 3;
+    const int t = pid / CIF, nn = pid % CIF;
     poff[jj] = pid < G::PAIRS ? (((t / 9) * G::HY + (t / 3) % 3) * G::HX + t % 3) * G::SX + nn * 32 : 0;
   }
-  f32x4 acc[G::PPW][3];
+  f32x4 acc[G::PPW][COF];
 #pragma unroll
   for (int jj = 0; jj < G::PPW; ++jj)
 #pragma unroll
-    for (int m = 0; m < 3; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < COF; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 ry[G::YI];
   // The loads of a tile -- X -> LDS buffer `buf` by 8 LDS-DMA instructions per wave, dY -> 3 register loads -- as a
@@ -586,8 +607,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
     constexpr int i = i_;
     const int c = xcode[i];
     const unsigned ok = (unsigned)(c >> 14) & (L.inter | ((L.zm >> (c & 7)) & (L.ym >> ((c >> 3) & 7)) & (L.xm >> ((c >> 6) & 31)))) & 1u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(L.xrs, (__attribute__((address_space(3))) void*)(L.xdst + i * 8192), 16,
-                                             (L.xorg + xoffs[i]) | ((int)ok - 1), 0, 0, 0);
+    lds_dma16(L.xrs, L.xdst + i * 8192, (L.xorg + xoffs[i]) | ((int)ok - 1));
   };
   auto issue_y = [&](const TileLoads& L, auto i_) {
     constexpr int i = i_;
@@ -635,12 +655,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
     WG_STAMP(3);
     const char* ldx = lds + cur * G::XB;
     constexpr int PD = 3;
-    bf16x8 a[2][3], b[PD + 1];
+    bf16x8 a[2][COF], b[PD + 1];
     auto read_a = [&](auto s_) {
       constexpr int s = s_;
       const int yoff = ybase + (32 * s) * G::SY;
 #pragma unroll
-      for (int m = 0; m < 3; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
+      for (int m = 0; m < COF; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
     };
     auto read_b = [&](auto u_) {
       constexpr int u = u_;
@@ -666,7 +686,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
       if constexpr (jj == 0 && s + 1 < 8) read_a(std::integral_constant<int, s + 1>{});
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+      for (int m = 0; m < COF; ++m)
         acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -684,11 +704,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
   for (int jj = 0; jj < G::PPW; ++jj) {
     const int pid = wave + 8 * jj;
     if (pid < G::PAIRS) {
-      const int t = pid / 3, nn = pid % 3;
+      const int t = pid / CIF, nn = pid % CIF;
       float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
       const int ci = ci0 + nn * 16 + v;
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+      for (int m = 0; m < COF; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
     }
@@ -732,22 +752,6 @@ template <int STRIDE> DEVI i32x8 tr8_frag(const char* base, int o0, int o1) {
   const v2i a2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(base + o1));
   const v2i a3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lp)(base + o1 + 8 * STRIDE));
   return i32x8{a0[0], a0[1], a1[0], a1[1], a2[0], a2[1], a3[0], a3[1]};
-}
-
-// a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop
-// into registers the accumulators need.  (The host pass of hipcc instantiates the kernel template's generic lambdas too
-// and silently drops the kernel stub when it meets a "v" constraint there, hence the device-pass guard.)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define OPAQUE_V(x) asm volatile("" : "+v"(x))
-#else
-#define OPAQUE_V(x) do { } while (0)
-#endif
-
-// one LDS-DMA instruction: lane l's 16 bytes at buffer offset `off` (out of range: zeros) land at dst + 16 l; dst wave-uniform.
-// (A function of its own: called directly inside the kernel TEMPLATE's generic lambdas the builtin makes hipcc's host pass
-// drop the kernel stub without a diagnostic.)
-DEVI void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, int off) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
 }
 
 struct WgradF8Params { WgradParams w; const float* amax_x1; const float* amax_x2; const float* amax_dy; };
@@ -1006,7 +1010,7 @@ static void wgrad_tiles(int dtype, int c1, int c2, int cout, int* cof, int* cif)
 
 // all-taps kernel: 48 x 48 channel blocks only, one persistent workgroup per CU in total (8 XCD ranges x g8)
 int g_wgrad_alltaps_mode = -1;  // brats_conv3d_set_wgrad_alltaps(): -1 = environment / default (on), 0 = off, 1 = on
-static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int ntiles, int* g8_out) {
+static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int ntiles, int* g8_out, int* wide_out = nullptr) {
   static int env_mode = -1, ncu = 0;
   if (env_mode < 0) {
     const char* e = getenv("BRATS_WGRAD_ALLTAPS");
@@ -1018,13 +1022,20 @@ static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int n
   const int mode = g_wgrad_alltaps_mode >= 0 ? g_wgrad_alltaps_mode : env_mode;
   const int cin = c1 + (c2 > 0 ? c2 : 0);
   const bool narrow = c2 <= 0 && c1 <= 16;  // the first layer: one 16-channel ci block
-  if (!mode || dtype != BRATS_BF16 || dil != 1 || cout % 48 || (!narrow && (c1 % 48 || (c2 > 0 && c2 % 48)))) return false;
-  const int blocks = (cout / 48) * (narrow ? 1 : cin / 48);
+  if (!mode || dtype != BRATS_BF16 || dil != 1) return false;
+  // block shape: 48 co x 48 ci, or 64 co x 32 ci for widths that are multiples of 64 but not of 48 (LDS-DMA form only)
+  bool wide = false;
+  if (cout % 48 || (!narrow && (c1 % 48 || (c2 > 0 && c2 % 48)))) {
+    if (narrow || cout % 64 || c1 % 32 || (c2 > 0 && c2 % 32)) return false;
+    wide = true;
+  }
+  const int blocks = wide ? (cout / 64) * (cin / 32) : (cout / 48) * (narrow ? 1 : cin / 48);
   const int nl = wgrad_nlane(ntiles);
   int g8 = ceil_div(ncu, nl * blocks);
   if (g8 < 1) g8 = 1;
   if (ntiles < 4 * nl * g8) return false;  // too few tiles per workgroup to amortise 132 accumulators x 27 taps of slab
   *g8_out = g8;
+  if (wide_out) *wide_out = wide ? 1 : 0;
   return true;
 }
 extern "C" int brats_conv3d_set_wgrad_alltaps(int mode) {
@@ -1101,8 +1112,8 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
   hipStream_t st = (hipStream_t)s;
-  int g8a = 0;
-  const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a);
+  int g8a = 0, wide = 0;
+  const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a, &wide);
   // tap-plane kernel: slab entries of padded ci / co lanes are never written: clear the slab
   if (!alltaps && ((c1 + c2) % 16 || cout % 16)) {
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * 27 * cout * p.cin * sizeof(float), st);
@@ -1119,20 +1130,24 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
       if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3<3>::LDS, hipGetErrorString(e));
       done = true;
     }
+    constexpr int lds_48 = Wg3b<3, 3>::LDS, lds_wide = Wg3b<4, 2>::LDS;
     static int form = -1;  // BRATS_WGRAD_ALLTAPS=1: the round-1 form (register staging, one X buffer) for same-box A/B runs
     if (form < 0) {
       const char* e = getenv("BRATS_WGRAD_ALLTAPS");
       form = (e && atoi(e) == 1) ? 1 : 2;
-      hipError_t e2 = hipFuncSetAttribute((const void*)conv_wgrad_alltaps2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3b::LDS);
-      if (e2 != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3b::LDS, hipGetErrorString(e2));
+      hipError_t e2 = hipFuncSetAttribute((const void*)conv_wgrad_alltaps2_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_48);
+      if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)conv_wgrad_alltaps2_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_wide);
+      if (e2 != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", lds_48, hipGetErrorString(e2));
     }
-    if (c2 <= 0 && c1 <= 16) {
+    if (wide) {
+      hipLaunchKernelGGL((conv_wgrad_alltaps2_kernel<4, 2>), dim3(p.nsplit, cout / 64, p.cin / 32), dim3(512), lds_wide, st, p);
+    } else if (c2 <= 0 && c1 <= 16) {
       // the slab columns of the padded ci lanes (c1 < 16) are never written and never read (cin = c1)
       hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<1>, dim3(p.nsplit, cout / 48, 1), dim3(512), Wg3<1>::LDS, st, p);
     } else if (form == 1) {
       hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<3>, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3<3>::LDS, st, p);
     } else {
-      hipLaunchKernelGGL(conv_wgrad_alltaps2_kernel, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3b::LDS, st, p);
+      hipLaunchKernelGGL((conv_wgrad_alltaps2_kernel<3, 3>), dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), lds_48, st, p);
     }
     rc = 0;
   } else if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
