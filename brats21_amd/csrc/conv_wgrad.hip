@@ -505,6 +505,24 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
 DEVI void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, int off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
 }
+// The same instruction as inline assembly.  Why: hipcc treats every LDS-DMA as a store to ALL of LDS and puts
+// s_waitcnt vmcnt(<everything issued so far>) in front of the next LDS read -- the transfers of the NEXT tile, issued right
+// before the MFMA phase, were waited for before its first operand read, i.e. never overlapped with it (found in the ISA:
+// vmcnt(0) between the last buffer_load ... lds and the first ds_read_b64_tr).  An asm statement is opaque to that pass;
+// the kernels wait themselves (s_waitcnt vmcnt(0) at the top of the tile loop, before the buffer is read).
+// rs = buffer descriptor words {base lo, base hi (stride 0), bytes, 0x00020000}; dst wave-uniform.
+typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+DEVI rsrc4_t make_rsrc4(const void* base, unsigned bytes) {
+  const size_t p = (size_t)base;
+  return rsrc4_t{__builtin_amdgcn_readfirstlane((int)(unsigned)p), __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu)),
+                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+}
+DEVI void lds_dma16_async(rsrc4_t rs, char* dst, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m), "v"(off), "s"(rs) : "memory", "m0");
+#endif
+}
 
 // Two block shapes: 48 co x 48 ci (COF, CIF = 3, 3: widths 48 / 96 / ...) and 64 co x 32 ci (4, 2: widths that are multiples
 // of 64 but not of 48 -- EquiUnetASSPEvo-64; 54 (tap, ci-fragment) pairs, 7 x 4 accumulators per lane, X 2 x 48 KB + dY 32 KB).
@@ -576,7 +594,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
   // all pieces of the NEXT tile are issued in one batch right before the MFMA phase (alternatives: see the call site).
   // Range tests are branch-free (an interior tile ORs an all-ones mask in).
   struct TileLoads {
-    __amdgpu_buffer_rsrc_t xrs, yrs;
+    rsrc4_t xrs;                  // (X: asynchronous LDS-DMA, see lds_dma16_async)
+    __amdgpu_buffer_rsrc_t yrs;
     int xorg, yorg;
     unsigned zm, ym, xm, inter;  // bit h: halo plane / row / column h is inside the volume; inter = all ones for an interior tile
     char* xdst;
@@ -589,7 +608,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
     const int z0 = (bt % p.tz) * WG_TZ;
     const int n = bt / p.tz;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
-    L.xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0, (int)xsample_bytes, 0x00020000);
+    L.xrs = make_rsrc4(xsrc + sample_vox * xpitch, xsample_bytes);
     L.yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0), (short)0, (int)ysample_bytes, 0x00020000);
     L.xorg = (((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * xpb;  // byte offset of the halo corner (negative at the low faces)
     L.yorg = ((z0 * p.H + y0) * p.W + x0) * ypb;
@@ -607,7 +626,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
     constexpr int i = i_;
     const int c = xcode[i];
     const unsigned ok = (unsigned)(c >> 14) & (L.inter | ((L.zm >> (c & 7)) & (L.ym >> ((c >> 3) & 7)) & (L.xm >> ((c >> 6) & 31)))) & 1u;
-    lds_dma16(L.xrs, L.xdst + i * 8192, (L.xorg + xoffs[i]) | ((int)ok - 1));
+    lds_dma16_async(L.xrs, L.xdst + i * 8192, (L.xorg + xoffs[i]) | ((int)ok - 1));
   };
   auto issue_y = [&](const TileLoads& L, auto i_) {
     constexpr int i = i_;
@@ -673,7 +692,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
     // 0.48 ms): one piece every 10 u-steps inside the MFMA loop 0.53 ms (a lone LDS-DMA among MFMAs stalls its wave ~3x
     // longer than one in a batch, and both waves of a SIMD reach it together); waves 4-7 issuing theirs in the middle of
     // the phase 0.75 ms; only waves 4-7 issuing (16 pieces each) while waves 0-3 compute 0.71 ms.  The issue rate IS
-    // the CU's load bandwidth (~25 GB/s: 61 KB take >= 2400 cycles whoever issues them).
+    // the CU's load bandwidth (~25 GB/s: 61 KB take >= 2400 cycles whoever issues them).  (Those three were measured while
+    // hipcc still waited for every LDS-DMA before the next LDS read -- see lds_dma16_async; with the asynchronous form,
+    // one load every 4 u-steps inside the loop: 48 -> 48 unchanged (0.445 ms), 96 -> 48 +4 %, every 7 u-steps: -3 %.)
     static_for<0, G::XI>([&](auto i_) { issue_x(L, i_); });
     static_for<0, G::YI>([&](auto i_) { issue_y(L, i_); });
     __builtin_amdgcn_sched_barrier(0);
@@ -808,7 +829,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_f8_kernel(const Wgr
     for (int m = 0; m < COF; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   struct TileLoads {
-    __amdgpu_buffer_rsrc_t xrs, yrs;
+    rsrc4_t xrs, yrs;
     int xorg, yorg;
     unsigned zm, ym, xm, inter;
   };
@@ -820,8 +841,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_f8_kernel(const Wgr
     const int z0 = (bt % p.tz) * WG_TZ;
     const int n = bt / p.tz;
     const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
-    T_.xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + sample_vox * xpitch), (short)0, (int)xsample_bytes, 0x00020000);
-    T_.yrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)p.dy + sample_vox * p.dyp + co0), (short)0, (int)ysample_bytes, 0x00020000);
+    T_.xrs = make_rsrc4(xsrc + sample_vox * xpitch, xsample_bytes);
+    T_.yrs = make_rsrc4((const T*)p.dy + sample_vox * p.dyp + co0, ysample_bytes);
     T_.xorg = (((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * xpb;
     T_.yorg = ((z0 * p.H + y0) * p.W + x0) * ypb;
     auto inside = [](int o, int size, int hn) {
@@ -838,7 +859,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_f8_kernel(const Wgr
     int c = xcode[i];
     OPAQUE_V(c);  // (decoded per tile: the hoisted fields would cost 3 registers per piece)
     const unsigned ok = (unsigned)(c >> 14) & (T_.inter | ((T_.zm >> (c & 7)) & (T_.ym >> ((c >> 3) & 7)) & (T_.xm >> ((c >> 6) & 31)))) & 1u;
-    lds_dma16(T_.xrs, xdst + i * 8192, (T_.xorg + xoffs[i]) | ((int)ok - 1));
+    lds_dma16_async(T_.xrs, xdst + i * 8192, (T_.xorg + xoffs[i]) | ((int)ok - 1));
   };
   auto issue_y = [&](const TileLoads& T_, auto i_) {
     constexpr int i = i_;
@@ -849,7 +870,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_f8_kernel(const Wgr
     const int z = vox >> 6, y = (vox >> 4) & 3, x = vox & 15;
     const int yo = ((z * p.H + y) * p.W + x) * ypb + part * 16;
     const unsigned ok = (T_.inter | ((T_.zm >> (z + 1)) & (T_.ym >> (y + 1)) & (T_.xm >> (x + 1)))) & 1u;
-    lds_dma16(T_.yrs, xdst + G::XB + i * 8192, (T_.yorg + yo) | ((int)ok - 1));
+    lds_dma16_async(T_.yrs, xdst + G::XB + i * 8192, (T_.yorg + yo) | ((int)ok - 1));
   };
 
   // per-lane offsets of the transposing reads: lane (kq, L) owns k = 32 kq .. 32 kq + 31 of a k-step = tile rows 2 kq + e
