@@ -124,6 +124,8 @@ extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N
 // ---- z = act(y*scale + shift) ------------------------------------------------------------------
 // HEAVY = false instantiations contain only relu / leakyrelu (the transcendental activations cost the streaming kernels
 // ~10-20 % through code size and registers even when not selected)
+// negative-side slope of leakyrelu: a host value, or -- nn.PReLU's learnable scalar -- read from device memory
+struct SlopeArg { float v; const float* p; };
 template <bool HEAVY>
 DEVI float act_fwd(float x, int act, float slope) {
   if (act == BRATS_ACT_RELU) return x > 0.f ? x : 0.f;
@@ -180,9 +182,10 @@ template <typename T> DEVI void record_absmax(float mx, uint32_t* amax) {
 // relu -- the published configuration -- is specialised so that the loop body is cvt, fma, max, cvt per element.
 template <typename T, bool HEAVY, bool NT = false>
 __global__ void __launch_bounds__(256) affine_act_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
-                                                         T* __restrict__ z, int zpitch, int act, float slope, int voxels, int C,
+                                                         T* __restrict__ z, int zpitch, int act, SlopeArg sl, int voxels, int C,
                                                          uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
+  const float slope = sl.p ? *sl.p : sl.v;
   const int n = blockIdx.y;
   const int cv = C / VW;
   const int vl_n = blockDim.x / cv;  // voxel lanes per block
@@ -241,7 +244,9 @@ static inline int stream_grid(size_t total, int block) {
 }
 
 extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
-                                    int dtype, int act, float slope, int N, int voxels, int C, float* amax, brats_stream_t s) {
+                                    int dtype, int act, float slope_value, const float* slope_dev, int N, int voxels, int C,
+                                    float* amax, brats_stream_t s) {
+  const SlopeArg slope{slope_value, slope_dev};
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!y || !z || !scale_shift || C % vw || ypitch % vw || zpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d (C <= %d)", vw, 256 * vw);
@@ -282,8 +287,9 @@ template <typename T, bool HEAVY, bool NT = false>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                             int ypitch, const float* __restrict__ scale_shift,
                                                             const float* __restrict__ mean_rstd, float* __restrict__ red, int act,
-                                                            float slope, int voxels, int C, int groups) {
+                                                            SlopeArg sl, int voxels, int C, int groups) {
   constexpr int VW = 16 / sizeof(T);
+  const float slope = sl.p ? *sl.p : sl.v;
   extern __shared__ float sm[];  // reduction scratch [vl_n][C][2]
   const int n = blockIdx.y;
   const int cpg = C / groups;
@@ -387,9 +393,10 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ red, T* __restrict__ dy, int dypitch,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int act,
-                                                           float slope, int N, int voxels, int C, int groups,
+                                                           SlopeArg sl, int N, int voxels, int C, int groups,
                                                            uint32_t* __restrict__ amax) {
   constexpr int VW = 16 / sizeof(T);
+  const float slope = sl.p ? *sl.p : sl.v;
   extern __shared__ float sm[];
   float* m12 = sm;  // [groups][2]: m1, m2 per group
   const int n = blockIdx.y;
@@ -474,8 +481,9 @@ extern "C" size_t brats_gn_bwd_ws_floats(int N, int C) { return (size_t)(1 + GN_
 
 extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                                 const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red,
-                                float* dgamma, float* dbeta, int dtype, int act, float slope, int N, int voxels,
-                                int C, int groups, float* amax, brats_stream_t s) {
+                                float* dgamma, float* dbeta, int dtype, int act, float slope_value, const float* slope_dev,
+                                int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
+  const SlopeArg slope{slope_value, slope_dev};
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: null pointer");
   if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
@@ -541,6 +549,63 @@ extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int 
 // in the unbiased variance.  `chansum` (optional) accumulates sum_v z per (n, c): the global average
 // pool of the following ResidualSELayer for free.
 // =================================================================================================
+// nn.PReLU (--act prelu, one learnable slope per ConvBnRelu): d loss / d slope = sum over (n, voxel, channel) of
+// dz * min(xhat, 0), xhat = y * scale + shift the normalised pre-activation.  One partial per block (part[b]), added in
+// block order by brats_ordered_sum: bitwise reproducible.
+template <typename T>
+__global__ void __launch_bounds__(256) prelu_slope_grad_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y, int ypitch,
+                                                               const float* __restrict__ scale_shift, float* __restrict__ part,
+                                                               int voxels, int C) {
+  constexpr int VW = 16 / sizeof(T);
+  const int n = blockIdx.y;
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  float acc = 0.f;
+  if (myvl < vl_n) {
+    float sc[VW], sh[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { sc[j] = scale_shift[((size_t)n * C + c0 + j) * 2]; sh[j] = scale_shift[((size_t)n * C + c0 + j) * 2 + 1]; }
+    const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
+    const T* yb = y + (size_t)n * voxels * ypitch + c0;
+    for (size_t vox = (size_t)blockIdx.x * vl_n + myvl; vox < (size_t)voxels; vox += (size_t)gridDim.x * vl_n) {
+      float g[VW], yy[VW];
+      Vec<T, VW>::load(dzb + vox * dzpitch, g);
+      Vec<T, VW>::load(yb + vox * ypitch, yy);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc += g[j] * fminf(yy[j] * sc[j] + sh[j], 0.f);
+    }
+  }
+  __shared__ float r[256];
+  r[threadIdx.x] = acc;
+  __syncthreads();
+  for (int m = 128; m > 0; m >>= 1) {
+    if ((int)threadIdx.x < m) r[threadIdx.x] += r[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[(size_t)n * gridDim.x + blockIdx.x] = r[0];
+}
+
+constexpr int PRELU_MAX_BLOCKS = 1024;
+extern "C" size_t brats_prelu_ws_floats(int N) { return (size_t)N * PRELU_MAX_BLOCKS; }
+extern "C" int brats_prelu_slope_grad(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift, float* ws,
+                                      float* dslope, int dtype, int N, int voxels, int C, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dz || !y || !scale_shift || !ws || !dslope || C % vw || dzpitch % vw || ypitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "prelu_slope_grad: bad argument");
+  hipStream_t st = (hipStream_t)s;
+  const int vl = 256 / (C / vw);
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  gx = gx < 1 ? 1 : (gx > PRELU_MAX_BLOCKS ? PRELU_MAX_BLOCKS : gx);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(prelu_slope_grad_kernel<bf16_t>, dim3((unsigned)gx, N), dim3(256), 0, st, (const bf16_t*)dz, dzpitch,
+                       (const bf16_t*)y, ypitch, scale_shift, ws, voxels, C);
+  else
+    hipLaunchKernelGGL(prelu_slope_grad_kernel<float>, dim3((unsigned)gx, N), dim3(256), 0, st, (const float*)dz, dzpitch,
+                       (const float*)y, ypitch, scale_shift, ws, voxels, C);
+  BRATS_CHECK_LAUNCH();
+  return brats_ordered_sum(ws, dslope, N * (int)gx, 1, st);
+}
+
 extern "C" int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
                                       double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
                                       brats_stream_t s) {

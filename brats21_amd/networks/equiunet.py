@@ -47,12 +47,15 @@ class _NormParams(nn.Module):
 class ConvBnRelu(nn.Module):
     """conv3x3x3 (no bias) -> norm -> act -> Dropout(p)   (networks/equiunet2020.py:51-75).  The norm is GroupNorm(8)
     (``--norm group``) or InstanceNorm3d(affine=True) (``--norm instance``, the CLI default; networks/factory.py:
-    179-188): the same kernels with 8 or ``planes`` statistics groups."""
+    179-188): the same kernels with 8 or ``planes`` statistics groups.  ``--act prelu``: MONAI's Act["prelu"] = nn.PReLU()
+    -- one learnable slope per unit, state-dict key ``<unit>.prelu.weight`` like the reference's nn.Sequential entry."""
 
-    def __init__(self, inplanes, planes, dilation=1, norm="group"):
+    def __init__(self, inplanes, planes, dilation=1, norm="group", act="relu"):
         super().__init__()
         self.conv = _ConvParams(inplanes, planes, 3, bias=False)
         self.bn = _NormParams(planes)
+        if act == "prelu":
+            self.prelu = nn.PReLU()
         self.dilation = dilation
         self.groups = 8 if norm == "group" else planes
 
@@ -60,10 +63,10 @@ class ConvBnRelu(nn.Module):
 class UBlock(nn.Module):
     """networks/equiunet2020.py:105-123"""
 
-    def __init__(self, inplanes, midplanes, outplanes, dilation=(1, 1), norm="group"):
+    def __init__(self, inplanes, midplanes, outplanes, dilation=(1, 1), norm="group", act="relu"):
         super().__init__()
-        self.ConvBnRelu1 = ConvBnRelu(inplanes, midplanes, dilation[0], norm)
-        self.ConvBnRelu2 = ConvBnRelu(midplanes, outplanes, dilation[1], norm)
+        self.ConvBnRelu1 = ConvBnRelu(inplanes, midplanes, dilation[0], norm, act)
+        self.ConvBnRelu2 = ConvBnRelu(midplanes, outplanes, dilation[1], norm, act)
 
 
 def _head(cin, k):
@@ -111,6 +114,13 @@ def _f8_ok(fp8, dtype, x, x2=None):
     return bool(fp8) and dtype == torch.bfloat16 and ops.conv_f8_chunk(x.shape[-1], x2.shape[-1] if x2 is not None else 0) > 0
 
 
+def _unit_act(unit, act):
+    """(kernel activation, device slope | None): PReLU = leakyrelu whose slope is the unit's learnable scalar."""
+    if act == "prelu":
+        return "leakyrelu", unit.prelu.weight.detach()
+    return act, None
+
+
 def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
     -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
@@ -129,7 +139,8 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
     n, d, h, wd, _ = y.shape
     mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
     amax = slots.take() if slots is not None else None
-    z = ops.affine_act(y, scale_shift, act, out=out, amax=amax)
+    kact, slope_t = _unit_act(unit, act)
+    z = ops.affine_act(y, scale_shift, kact, out=out, amax=amax, slope_t=slope_t)
     if amax is not None:
         z._amax = amax
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
@@ -149,7 +160,13 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     w8 = (all8 and unit.dilation == 1 and ax is not None and (x2 is None or ax2 is not None) and y.dtype == torch.bfloat16
           and ops.conv3d_wgrad_f8_ok(x, y, x2))
     amax = slots.take() if ((f8 or w8) and slots is not None) else None
-    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, act, amax=amax)
+    kact, slope_t = _unit_act(unit, act)
+    if slope_t is not None:
+        grads[names[unit.prelu.weight]] = ops.prelu_slope_grad(dz, y, scale_shift)
+        if sink is not None:
+            sink(names[unit.prelu.weight], grads[names[unit.prelu.weight]])
+    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
+                                       slope_t=slope_t)
     with ops.side_stream(side, dy, x, x2) as on_side:
         # (the weight gradient depends only on dy and the saved input and nobody but the optimizer waits for it: on the
         # side stream it fills the CUs that the tail of the input-gradient kernel and the small GroupNorm launches leave idle)
@@ -324,9 +341,8 @@ class EquiUnet(_PackedWeightsModule):
         super().__init__()
         if norm_layer not in ("group", "instance"):
             raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance (got {norm_layer!r})")
-        if act not in ("relu", "leakyrelu", "elu", "swish", "mish"):
-            raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu|elu|swish|mish (got {act!r}; "
-                                      "prelu has a learnable slope and is not built)")
+        if act not in ("relu", "leakyrelu", "elu", "prelu", "swish", "mish"):
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu|elu|prelu|swish|mish (got {act!r})")
         if dropout:
             raise NotImplementedError("dropout > 0 is not implemented (the published configs use 0)")
         if refinement:
@@ -353,15 +369,15 @@ class EquiUnet(_PackedWeightsModule):
         self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "0") != "0"
         f = self.features
         nl = norm_layer
-        self.encoder1 = UBlock(inplanes, f[0], f[0], norm=nl)
-        self.encoder2 = UBlock(f[0], f[1], f[1], norm=nl)
-        self.encoder3 = UBlock(f[1], f[2], f[2], norm=nl)
-        self.encoder4 = UBlock(f[2], f[3], f[3], norm=nl)
-        self.bottom = UBlock(f[3], f[3], f[3], (2, 2), norm=nl)
-        self.bottom_2 = ConvBnRelu(f[3] * 2, f[2], norm=nl)
-        self.decoder3 = UBlock(f[2] * 2, f[2], f[1], norm=nl)
-        self.decoder2 = UBlock(f[1] * 2, f[1], f[0], norm=nl)
-        self.decoder1 = UBlock(f[0] * 2, f[0], f[0], norm=nl)
+        self.encoder1 = UBlock(inplanes, f[0], f[0], norm=nl, act=act)
+        self.encoder2 = UBlock(f[0], f[1], f[1], norm=nl, act=act)
+        self.encoder3 = UBlock(f[1], f[2], f[2], norm=nl, act=act)
+        self.encoder4 = UBlock(f[2], f[3], f[3], norm=nl, act=act)
+        self.bottom = UBlock(f[3], f[3], f[3], (2, 2), norm=nl, act=act)
+        self.bottom_2 = ConvBnRelu(f[3] * 2, f[2], norm=nl, act=act)
+        self.decoder3 = UBlock(f[2] * 2, f[2], f[1], norm=nl, act=act)
+        self.decoder2 = UBlock(f[1] * 2, f[1], f[0], norm=nl, act=act)
+        self.decoder1 = UBlock(f[0] * 2, f[0], f[0], norm=nl, act=act)
         self.outconv = _ConvParams(f[0], num_classes, 1, bias=True)
         if deep_supervision:
             self.deep_bottom = _head(f[3], num_classes)

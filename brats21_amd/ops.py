@@ -570,19 +570,20 @@ def gn_finalize(stats, n, c, groups, voxels, gamma, beta, eps=1e-5):
     return mean_rstd, scale_shift
 
 
-def affine_act(y, scale_shift, act="relu", out=None, slope=0.01, amax=None):
-    """amax: optional zero-initialised 1-element f32 tensor that receives max|out| (scale source of conv3d_f8)."""
+def affine_act(y, scale_shift, act="relu", out=None, slope=0.01, amax=None, slope_t=None):
+    """amax: optional zero-initialised 1-element f32 tensor that receives max|out| (scale source of conv3d_f8).
+    slope_t: 1-element f32 device tensor overriding ``slope`` (nn.PReLU's learnable weight, act = "leakyrelu")."""
     ptr, c, p = _desc(y)
     n, d, h, w, _ = y.shape
     if out is None:
         out = new_act(n, d, h, w, c, y.dtype, y.device)
     optr, oc, op = _desc(out)
     _lib.check(_lib.lib().brats_affine_act_fwd(ptr, p, scale_shift.data_ptr(), optr, op, _code(y.dtype), ACTS[act], slope,
-                                               n, d * h * w, c, _f32(amax), _stream()), "affine_act_fwd")
+                                               _f32(slope_t), n, d * h * w, c, _f32(amax), _stream()), "affine_act_fwd")
     return out
 
 
-def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None):
+def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None, slope_t=None):
     """Returns (dy, dgamma, dbeta) for z = act(GroupNorm(y)); amax (optional, zero-initialised) receives max|dy|."""
     dzp, c, dzpitch = _desc(dz)
     yp, _, ypitch = _desc(y)
@@ -593,9 +594,21 @@ def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope
     dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
     _lib.check(_lib.lib().brats_gn_act_bwd(dzp, dzpitch, yp, ypitch, scale_shift.data_ptr(), mean_rstd.data_ptr(),
                                            _f32(gamma), dy.data_ptr(), c, red.data_ptr(), dgamma.data_ptr(),
-                                           dbeta.data_ptr(), _code(y.dtype), ACTS[act], slope, n, d * h * w, c, groups,
-                                           _f32(amax), _stream()), "gn_act_bwd")
+                                           dbeta.data_ptr(), _code(y.dtype), ACTS[act], slope, _f32(slope_t), n, d * h * w, c,
+                                           groups, _f32(amax), _stream()), "gn_act_bwd")
     return dy, dgamma, dbeta
+
+
+def prelu_slope_grad(dz, y, scale_shift):
+    """d loss / d slope [1] of z = PReLU(y * scale + shift) with one shared slope (nn.PReLU()): sum dz * min(pre, 0)."""
+    dzp, c, dzpitch = _desc(dz)
+    yp, _, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    ws = torch.empty(_lib.lib().brats_prelu_ws_floats(n), dtype=torch.float32, device=y.device)
+    out = torch.empty(1, dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().brats_prelu_slope_grad(dzp, dzpitch, yp, ypitch, scale_shift.data_ptr(), ws.data_ptr(), out.data_ptr(),
+                                                 _code(y.dtype), n, d * h * w, c, _stream()), "prelu_slope_grad")
+    return out
 
 
 # ------------------------------------------------------------------------------------------ pool / upsample

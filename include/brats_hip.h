@@ -154,8 +154,11 @@ int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, in
                       double* chan_ws /* f64 workspace of brats_gn_ws_doubles() elements */, brats_stream_t s);
 /* amax (optional, device scalar that is ZERO before the call): receives max|z|, the scale source of the fp8
  * convolutions (brats_conv3d_f8_fwd) */
+/* slope: the negative-side factor of BRATS_ACT_LEAKY; slope_dev (optional device scalar) overrides it -- nn.PReLU's
+ * learnable weight (--act prelu, networks/factory.py:195-200) is read where it lives, without a host round trip */
 int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
-                         int dtype, int act, float slope, int N, int voxels, int C, float* amax, brats_stream_t s);
+                         int dtype, int act, float slope, const float* slope_dev, int N, int voxels, int C, float* amax,
+                         brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
  * u = dz * act'(.) into `red` (workspace of brats_gn_bwd_ws_floats() elements); pass 2 writes dy and finishes
  * dgamma/dbeta [C]. */
@@ -165,8 +168,13 @@ size_t brats_gn_bwd_ws_floats(int N, int C);
 int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                      const float* mean_rstd, const float* gamma, void* dy, int dypitch,
                      float* red /* workspace */, float* dgamma, float* dbeta,
-                     int dtype, int act, float slope, int N, int voxels, int C, int groups,
+                     int dtype, int act, float slope, const float* slope_dev, int N, int voxels, int C, int groups,
                      float* amax /* optional, zero before the call: receives max|dy| */, brats_stream_t s);
+/* gradient of nn.PReLU's scalar slope: dslope[0] = sum dz * min(y*scale + shift, 0) over the whole tensor; ws = f32
+ * workspace of brats_prelu_ws_floats(N) elements (block partials, added in block order) */
+size_t brats_prelu_ws_floats(int N);
+int brats_prelu_slope_grad(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift, float* ws,
+                           float* dslope, int dtype, int N, int voxels, int C, brats_stream_t s);
 
 /* ---- EvoNorm-S0 (EvoNorm3D networks/equiunet2021.py:55-118, group_std :48-52; groups = 8) ---------
  * z = x*sigmoid(x) * rstd_g * gamma_c + beta_c with the UNBIASED group variance.  `stats` are the

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- EquiUnet (GN + act)
-def _act(x, act):
+def _act(x, act, slope=None):
     # networks/factory.py:195-200 -> MONAI Act lookup (src/arguments_train.py:49-50: elu, relu, leakyrelu, prelu, swish, mish)
     if act == "relu":
         return F.relu(x)
@@ -29,6 +29,8 @@ def _act(x, act):
         return F.leaky_relu(x, 0.01)
     if act == "elu":
         return F.elu(x)            # MONAI Act["elu"] = nn.ELU (alpha 1)
+    if act == "prelu":
+        return F.prelu(x, slope)   # MONAI Act["prelu"] = nn.PReLU(): one learnable slope, "<unit>.prelu.weight"
     if act == "swish":
         return x * torch.sigmoid(x)  # MONAI Swish(alpha=1.0): input * sigmoid(alpha * input)
     if act == "mish":
@@ -48,7 +50,7 @@ def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group"):
         y = F.instance_norm(y, None, None, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], True, 0.1, 1e-5)
     else:
         raise ValueError(norm)
-    return _act(y, act)
+    return _act(y, act, sd.get(pre + ".prelu.weight"))
 
 
 def ublock(sd, pre, x, dilation=(1, 1), act="relu", norm="group"):
@@ -90,9 +92,10 @@ def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group"):
     return out, deeps
 
 
-def equiunet_state_shapes(width, inplanes=4, num_classes=3):
+def equiunet_state_shapes(width, inplanes=4, num_classes=3, act="relu"):
     """Ordered {key: shape} of EquiUnet(features=[width*2**i]) with GroupNorm, deep supervision
-    (networks/equiunet2020.py:424-458). Checked against the reference in tests/golden."""
+    (networks/equiunet2020.py:424-458). Checked against the reference in tests/golden.  act "prelu" adds the unit's
+    nn.PReLU weight (the activation is a named entry of the reference's nn.Sequential, :51-65)."""
     f = [width * 2 ** i for i in range(4)]
     shapes = {}
 
@@ -100,6 +103,8 @@ def equiunet_state_shapes(width, inplanes=4, num_classes=3):
         shapes[pre + ".conv.weight"] = (cout, cin, 3, 3, 3)
         shapes[pre + ".bn.weight"] = (cout,)
         shapes[pre + ".bn.bias"] = (cout,)
+        if act == "prelu":
+            shapes[pre + ".prelu.weight"] = (1,)
 
     def ub(pre, cin, mid, cout):
         cbr(pre + ".ConvBnRelu1", cin, mid)

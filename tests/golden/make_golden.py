@@ -83,6 +83,13 @@ def equiunet_fixtures():
         _model_fixture(m, unet.equiunet_state_shapes, 8, size, fname, sub)
 
 
+def equiunet_prelu_fixture():
+    """--act prelu (MONAI Act["prelu"] = torch.nn.PReLU(): one learnable slope per ConvBnRelu) with --norm group."""
+    import functools
+    m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="group", act="prelu", deep_supervision=True, dropout=0)
+    _model_fixture(m, functools.partial(unet.equiunet_state_shapes, act="prelu"), 8, (16, 16, 16), "equiunet_w8_16_prelu.npz", 1)
+
+
 def equiunet_elu_fixture():
     """--act elu (MONAI Act["elu"] = torch.nn.ELU) with the default --norm instance."""
     m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="instance", act="elu", deep_supervision=True, dropout=0)
@@ -305,13 +312,15 @@ if __name__ == "__main__":
     m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
                                      t.Rotate90(angles=[0, 90, 180, 270])])
     sys.modules["src_definer_tta"] = m
-    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance", "equiunet_elu"]
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance", "equiunet_elu", "equiunet_prelu"]
     if "equiunet" in which:
         equiunet_fixtures()
     if "equiunet_instance" in which:
         equiunet_instance_fixture()
     if "equiunet_elu" in which:
         equiunet_elu_fixture()
+    if "equiunet_prelu" in which:
+        equiunet_prelu_fixture()
     if "assp" in which:
         assp_fixture()
     if "ops" in which:

@@ -3,6 +3,8 @@
 same closed-form inputs.  Bar (BASELINE.json north_star): logits within 1e-3 abs in the f32 mode;
 the bf16 mode's deviation is asserted at a stated looser bound."""
 import argparse
+import contextlib
+import io
 import json
 import os
 
@@ -261,6 +263,54 @@ def test_other_activations_f32_network_vs_oracle(golden_dir, act):
         g = _golden(golden_dir, "equiunet_w8_16_elu.npz")
         assert np.abs(out.detach().cpu().numpy() - g["logits"]).max() < LOGIT_ATOL
         assert abs(loss.item() - float(g["loss"])) < 1e-4
+
+
+def test_prelu_network_vs_reference_golden_and_oracle(golden_dir):
+    """--act prelu (nn.PReLU per ConvBnRelu; reference networks/factory.py:195-200): state-dict keys, logits, loss and every
+    gradient -- the 17 learnable slopes included -- against the reference's golden vectors (f32 mode) and the oracle; then
+    a bf16 step with the fused optimizer moves the slopes."""
+    import functools
+    from brats21_amd import get_model
+    from brats21_amd.engine import TrainStep
+    from brats21_amd.optim import Ranger2020
+    g = _golden(golden_dir, "equiunet_w8_16_prelu.npz")
+    sd = synth.fill_state_dict(functools.partial(unet.equiunet_state_shapes, act="prelu")(8))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = get_model(argparse.Namespace(model="equiunet", width=8, norm="group", act="prelu", num_classes=3, dropout=0))
+    assert list(m.state_dict().keys()) == list(sd.keys()) == json.loads(str(g["meta"]))["keys"]
+    m.load_state_dict(sd)
+    m.precision = "fp32"
+    m = m.cuda().train()
+    size = (16, 16, 16)
+    x, t = synth.closed_form_image(1, 4, size), synth.nested_spheres(1, size)
+    out, deeps = m(x.cuda())
+    loss = unet.deep_supervision_loss((out, deeps), t.cuda())
+    loss.backward()
+    assert np.abs(out.detach().cpu().numpy() - g["logits"]).max() < LOGIT_ATOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    params = dict(m.named_parameters())
+    nslopes = 0
+    for k in g.files:
+        if k.startswith("grad:"):
+            ref = g[k]
+            got = params[k[5:]].grad.cpu().numpy()
+            assert np.abs(got - ref).max() <= 5e-3 * np.abs(ref).max() + 1e-6, k
+            nslopes += k.endswith(".prelu.weight")
+    assert nslopes == 17
+    names = json.loads(str(g["grad_names"]))
+    norms = np.array([float(params[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-3, atol=1e-9)
+    # bf16 + fused optimizer: the slopes are ordinary parameters of the step
+    m.precision = "auto"
+    before = torch.stack([p.detach().clone().flatten()[0] for k, p in m.named_parameters() if k.endswith("prelu.weight")])
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = Ranger2020(m.parameters(), lr=1e-2)
+    step = TrainStep(m, opt, amp=True)
+    l0 = float(step(x.cuda(), t.cuda()).detach())
+    for _ in range(3):
+        l1 = float(step(x.cuda(), t.cuda()).detach())
+    after = torch.stack([p.detach().flatten()[0] for k, p in m.named_parameters() if k.endswith("prelu.weight")])
+    assert l1 < l0 and bool((after != before).all()) and bool(torch.isfinite(after).all())
 
 
 @pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])

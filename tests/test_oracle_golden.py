@@ -229,3 +229,21 @@ def test_equiunet_elu_oracle_matches_reference(golden_dir):
     names = json.loads(str(g["grad_names"]))
     norms = np.array([float(sd[k].grad.double().norm()) for k in names])
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+
+
+def test_equiunet_prelu_oracle_matches_reference(golden_dir):
+    """--act prelu: the reference's EquiUnet with nn.PReLU units (state-dict keys "<unit>.prelu.weight"), logits, loss,
+    gradient norms and the 17 slope gradients themselves."""
+    import functools
+    g = _load(golden_dir, "equiunet_w8_16_prelu.npz")
+    meta, sd, out, loss = _run(lambda sd, x: unet.equiunet_forward(sd, x, act="prelu", norm="group"),
+                               functools.partial(unet.equiunet_state_shapes, act="prelu"), g)
+    np.testing.assert_allclose(out[0].detach().numpy(), g["logits"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    assert sum(n.endswith(".prelu.weight") for n in names) == 17
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+    for k in g.files:
+        if k.startswith("grad:") and k.endswith(".prelu.weight"):
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=1e-6, rtol=1e-4)
