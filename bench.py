@@ -202,17 +202,17 @@ def main():
         step()
     timer = ops.KernelTimer() if rank == 0 and not args.graph and not os.environ.get("BRATS_BENCH_NO_TIMER") else None
     # per-kernel HIP events cost GPU time themselves (0.28 ms per step when every conv launch of every step is bracketed):
-    # they are recorded in every `stride`-th timed step only (3-4 sampled steps), inside the timed region
-    stride = max(1, args.steps // 3)
-    sampled = len(range(0, args.steps, stride))
+    # they are recorded in two of the timed steps only (at 1/3 and 2/3 of the run), inside the timed region
+    sample_at = sorted({args.steps // 3, (2 * args.steps) // 3})
+    sampled = len(sample_at)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ops.TIMER = timer if (timer is not None and i % stride == 0) else None
+        ops.TIMER = timer if (timer is not None and i in sample_at) else None
         if buckets is not None and not args.graph:
-            buckets.measure = i % stride == 0  # two HIP events around the collective waits of the sampled steps
+            buckets.measure = i in sample_at  # two HIP events around the collective waits of the sampled steps
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
