@@ -200,10 +200,14 @@ __global__ void __launch_bounds__(256) upsample_fwd_kernel(const T* __restrict__
 // 24 gathers for 8 outputs instead of 64 (the row-per-block kernel above is bound by its 8 gathers per 16-byte store), and
 // every store instruction still writes a contiguous x-row.  Weights of absent (plane, row) pairs are zero; same f32
 // coefficients as lerp_coef, summed x first, then y, then z.
-template <typename T, bool NT = false>
+// LDSX: the 3 planes x 4 rows the block reads are first copied into LDS with dense 16-byte loads (every input element
+// fetched once per block: 18 load instructions per thread instead of 72 gathers); 12 x W x C elements must fit (73.7 KB at
+// every decoder level of the bf16 networks: W x C = 3072).
+template <typename T, bool NT = false, bool LDSX = false>
 __global__ void __launch_bounds__(256) upsample2_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch,
                                                             int C, int D, int H, int W, float sd, float sh, float sw) {
   constexpr int VW = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char up_lds[];
   const int cv = C / VW, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
   const int yq = blockIdx.x, zp = blockIdx.y, n = blockIdx.z;
   const int zo0 = 2 * zp, yo0 = 4 * yq;
@@ -224,6 +228,16 @@ __global__ void __launch_bounds__(256) upsample2_fwd_kernel(const T* __restrict_
     for (int r = 0; r < 4; ++r) wy[b][r] = (ly[b].i0 == yb + r ? ly[b].w0 : 0.f) + (ly[b].i1 == yb + r ? ly[b].w1 : 0.f);
   const T* xb = x + (size_t)n * D * H * W * xpitch;
   T* yb_ = y + (size_t)n * Do * Ho * Wo * ypitch;
+  if constexpr (LDSX) {
+    const int row_pieces = W * cv;
+    for (int q = threadIdx.x; q < 12 * row_pieces; q += blockDim.x) {
+      const int rr = q / row_pieces, w = q % row_pieces;
+      const int zi = zb + rr / 4 < D ? zb + rr / 4 : D - 1, yi = yb + rr % 4 < H ? yb + rr % 4 : H - 1;
+      *(u32x4*)(up_lds + (size_t)q * 16) =
+          *(const u32x4*)(xb + ((size_t)(zi * H + yi) * W + w / cv) * xpitch + (w % cv) * VW);
+    }
+    __syncthreads();
+  }
   // pairs of channels through explicit v_pk_fma_f32: with separate multiplies and adds (the build's -ffp-contract=off) the
   // ~1400 packed ops per 8 outputs made this kernel VALU-bound at 2.3 TB/s
   typedef __attribute__((ext_vector_type(2))) float f2;
@@ -250,10 +264,16 @@ __global__ void __launch_bounds__(256) upsample2_fwd_kernel(const T* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int yi = yb + r < H ? yb + r : H - 1;
-        const T* row = xb + (size_t)(zi * H + yi) * W * xpitch + c0;
         float v0[VW], v1[VW];
-        Vec<T, VW>::load(row + (size_t)lx.i0 * xpitch, v0);
-        Vec<T, VW>::load(row + (size_t)lx.i1 * xpitch, v1);
+        if constexpr (LDSX) {
+          const T* row = (const T*)up_lds + (size_t)(pz * 4 + r) * W * C + c0;
+          Vec<T, VW>::load(row + (size_t)lx.i0 * C, v0);
+          Vec<T, VW>::load(row + (size_t)lx.i1 * C, v1);
+        } else {
+          const T* row = xb + (size_t)(zi * H + yi) * W * xpitch + c0;
+          Vec<T, VW>::load(row + (size_t)lx.i0 * xpitch, v0);
+          Vec<T, VW>::load(row + (size_t)lx.i1 * xpitch, v1);
+        }
 #pragma unroll
         for (int j = 0; j < V2; ++j) {
           const f2 xl = fma2(lx.w1, f2{v1[2 * j], v1[2 * j + 1]}, lx.w0 * f2{v0[2 * j], v0[2 * j + 1]});
@@ -290,6 +310,24 @@ extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch
   const float sd = ac_scale(D, D * scale), sh = ac_scale(H, H * scale), sw = ac_scale(W, W * scale);
   if (scale == 2 && H % 2 == 0 && N <= 65535 && D <= 65535) {
     const dim3 g2(H / 2, D, N);  // (Ho / 4, Do / 2, N)
+    const size_t ldsx = (size_t)12 * W * C * 2;
+    if (dtype == BRATS_BF16 && ldsx <= 80 * 1024) {  // two blocks per CU with their input rows in LDS
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)upsample2_fwd_kernel<bf16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)upsample2_fwd_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "upsample_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+      }
+      if (stream_nt((size_t)N * D * H * W * 8 * C * 2))
+        hipLaunchKernelGGL((upsample2_fwd_kernel<bf16_t, true, true>), g2, dim3(256), ldsx, (hipStream_t)s, (const bf16_t*)x, xpitch, (bf16_t*)y,
+                           ypitch, C, D, H, W, sd, sh, sw);
+      else
+        hipLaunchKernelGGL((upsample2_fwd_kernel<bf16_t, false, true>), g2, dim3(256), ldsx, (hipStream_t)s, (const bf16_t*)x, xpitch, (bf16_t*)y,
+                           ypitch, C, D, H, W, sd, sh, sw);
+      BRATS_CHECK_LAUNCH();
+      return 0;
+    }
     if (dtype == BRATS_BF16 && stream_nt((size_t)N * D * H * W * 8 * C * 2))  // output beyond the Infinity Cache: non-temporal stores
       hipLaunchKernelGGL((upsample2_fwd_kernel<bf16_t, true>), g2, dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch,
                          C, D, H, W, sd, sh, sw);
