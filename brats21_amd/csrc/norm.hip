@@ -710,7 +710,8 @@ extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rs
 // (the third sum gives the bias gradient of the preceding convolution without another pass over dx)
 template <typename T, bool NT = false>
 __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
-                                          float* __restrict__ red, int voxels, int C) {
+                                          float* __restrict__ red, int voxels, int C, const float* __restrict__ gscale,
+                                          const float* __restrict__ gadd) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   const int n = blockIdx.y;
@@ -722,13 +723,19 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
   if (myvl < vl_n) {
     const T* dzb = dz + (size_t)n * voxels * dzpitch;
     const T* xb = x + (size_t)n * voxels * xpitch;
-    auto body = [&](const float* g, const float* xx) {
+    // optional per-(n, channel) affine map of the incoming gradient (the SE layer's backward, dz = do * (1 + gate) + dgap / V,
+    // folded in instead of a separate channel_scale pass over the tensor)
+    float gs[VW], ga[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { gs[j] = gscale ? gscale[(size_t)n * C + c0 + j] : 1.f; ga[j] = gadd ? gadd[(size_t)n * C + c0 + j] : 0.f; }
+    auto body = [&](const float* g_, const float* xx) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
+        const float g = g_[j] * gs[j] + ga[j];
         const float sg = sigmoidf_(xx[j]);
-        a1[j] += g[j];
-        a2[j] += g[j] * xx[j] * sg;
-        a3[j] += g[j] * sg * (1.f + xx[j] * (1.f - sg));
+        a1[j] += g;
+        a2[j] += g * xx[j] * sg;
+        a3[j] += g * sg * (1.f + xx[j] * (1.f - sg));
       }
     };
     const size_t stride = (size_t)gridDim.x * vl_n;
@@ -774,7 +781,8 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
                                          const float* __restrict__ red, T* __restrict__ dx, int dxpitch,
                                          float* __restrict__ dgamma, float* __restrict__ dbeta, const double* __restrict__ chan,
                                          float* __restrict__ dconvbias, int N, int voxels, int C, int groups,
-                                         uint32_t* __restrict__ amax) {
+                                         uint32_t* __restrict__ amax, const float* __restrict__ gscale,
+                                         const float* __restrict__ gadd) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   float* gr = sm;          // [C] gamma * r
@@ -814,9 +822,13 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
   const bool live = myvl < vl_n;  // idle threads stay for the |max| reduction
-  float cg[VW], cm[VW], ck[VW];  // per-channel constants in registers (not re-read from LDS per element)
+  float cg[VW], cm[VW], ck[VW], gs[VW], ga[VW];  // per-channel constants in registers (not re-read from LDS per element)
 #pragma unroll
-  for (int j = 0; j < VW; ++j) { cg[j] = gr[c0 + j]; cm[j] = mu[c0 + j]; ck[j] = kk[c0 + j]; }
+  for (int j = 0; j < VW; ++j) {
+    cg[j] = gr[c0 + j]; cm[j] = mu[c0 + j]; ck[j] = kk[c0 + j];
+    gs[j] = gscale ? gscale[(size_t)n * C + c0 + j] : 1.f;
+    ga[j] = gadd ? gadd[(size_t)n * C + c0 + j] : 0.f;
+  }
   const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
   const T* xb = x + (size_t)n * voxels * xpitch + c0;
   T* dxb = dx + (size_t)n * voxels * dxpitch + c0;
@@ -826,7 +838,7 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
     for (int j = 0; j < VW; ++j) {
       const float sg = sigmoidf_(xx[j]);
       const float dnum = sg * (1.f + xx[j] * (1.f - sg));
-      o[j] = g[j] * cg[j] * dnum - ck[j] * (xx[j] - cm[j]);
+      o[j] = (g[j] * gs[j] + ga[j]) * cg[j] * dnum - ck[j] * (xx[j] - cm[j]);
     }
     if (amax) {
 #pragma unroll
@@ -859,7 +871,7 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
 extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
                                  const float* gamma, void* dx, int dxpitch, float* red, float* dgamma, float* dbeta,
                                  const double* chan_sums, float* dconvbias, int dtype, int N, int voxels, int C, int groups,
-                                 float* amax, brats_stream_t s) {
+                                 float* amax, const float* gscale, const float* gadd, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !x || !dx || !red || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: null pointer");
   if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd: dconvbias needs the forward per-channel sums");
@@ -876,22 +888,22 @@ extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int
   const size_t lds2 = (size_t)3 * C * sizeof(float);
   if (big) {
     hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, red, voxels, C);
+                       xpitch, red, voxels, C, gscale, gadd);
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL((evonorm_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax);
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
   } else if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, red, voxels, C);
+                       xpitch, red, voxels, C, gscale, gadd);
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax);
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
   } else {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)x,
-                       xpitch, red, voxels, C);
+                       xpitch, red, voxels, C, gscale, gadd);
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
-                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax);
+                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
   }
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -194,10 +194,10 @@ def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
     return z, cs, (conv, evo, saved, y, mr, chan)
 
 
-def _conv_evo_bwd(cx, rec, dz, need_dx=True):
+def _conv_evo_bwd(cx, rec, dz, need_dx=True, gscale=None, gadd=None):
     conv, evo, saved, y, mr, chan = rec
     amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
-    dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax)
+    dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax, gscale=gscale, gadd=gadd)
     if amax is not None:
         dy._amax = amax
     cx.put(evo.gamma, dgamma)
@@ -231,8 +231,8 @@ def _block_bwd(cx, rec, do, need_dx=True):
     dgap, dw1, db1, dw2, db2 = torch.autograd.grad(gate, [gap, fc1.weight, fc1.bias, fc2.weight, fc2.bias], dgate)
     for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2)):
         cx.put(prm, g)
-    dz2 = ops.channel_scale(do, 1.0 + gate.detach(), add=dgap / float(d * h * w))
-    dz1 = _conv_evo_bwd(cx, r2, dz2)
+    # d out / d z2 = do * (1 + gate) + dgap / V per (n, channel): read inside the EvoNorm backward instead of a pass of its own
+    dz1 = _conv_evo_bwd(cx, r2, do, gscale=(1.0 + gate.detach()).float(), gadd=(dgap / float(d * h * w)).float())
     return _conv_evo_bwd(cx, r1, dz1, need_dx)
 
 

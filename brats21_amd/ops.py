@@ -717,8 +717,9 @@ def evonorm(y, mean_rstd, gamma, beta, groups=8, out=None, want_chansum=False, a
     return out, (cs[:n * c].view(n, c) if cs is not None else None)
 
 
-def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None, amax=None):
-    """Returns (dy, dgamma, dbeta, dconvbias|None); dconvbias = sum_v dy needs the forward's `chan` sums."""
+def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None, amax=None, gscale=None, gadd=None):
+    """Returns (dy, dgamma, dbeta, dconvbias|None); dconvbias = sum_v dy needs the forward's `chan` sums.
+    gscale / gadd ([N, C] f32): the incoming gradient is read as dz * gscale + gadd (the SE layer's backward folded in)."""
     dzp, c, dzpitch = _desc(dz)
     yp, _, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
@@ -731,7 +732,8 @@ def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None, amax=None):
                                             red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                             chan.data_ptr() if chan is not None else None,
                                             dcb.data_ptr() if dcb is not None else None, _code(y.dtype), n,
-                                            d * h * w, c, groups, _f32(amax), _stream()), "evonorm_bwd")
+                                            d * h * w, c, groups, _f32(amax), _f32(gscale.contiguous()) if gscale is not None else None,
+                                            _f32(gadd.contiguous()) if gadd is not None else None, _stream()), "evonorm_bwd")
     return dy, dgamma, dbeta, dcb
 
 

@@ -197,7 +197,10 @@ int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, co
                       const float* gamma, void* dx, int dxpitch, float* red /*[N][C][3]*/,
                       float* dgamma, float* dbeta, const double* chan_sums, float* dconvbias,
                       int dtype, int N, int voxels, int C, int groups,
-                      float* amax /* optional, zero before the call: receives max|dx| */, brats_stream_t s);
+                      float* amax /* optional, zero before the call: receives max|dx| */,
+                      const float* gscale, const float* gadd /* optional [N][C]: dz is read as dz * gscale + gadd -- the
+                      ResidualSELayer backward (out = z + z * gate) folded in instead of a separate channel_scale pass */,
+                      brats_stream_t s);
 /* ---- squeeze-excite helpers (MONAI ResidualSELayer, equiunet2021.py:204-205): per-(n,channel)
  * reductions over voxels and per-(n,channel) scale(+add) passes; the two tiny FC layers stay in torch. */
 int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,
