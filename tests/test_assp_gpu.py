@@ -192,3 +192,26 @@ def test_assp_training_step_is_bitwise_reproducible():
         runs.append((losses, torch.cat([p.detach().flatten()[:500] for p in m.parameters()]).clone()))
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_evonorm_bwd_with_folded_se_gradient_map():
+    """evonorm_bwd(do, gscale, gadd) = evonorm_bwd(channel_scale(do, gscale, add=gadd)): bitwise in f32 (same arithmetic, no
+    intermediate rounding), within bf16 rounding of the intermediate for bf16."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    n, c, size = 2, 48, (6, 8, 16)
+    for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 2e-2)):
+        y = torch.randn((n, *size, c), generator=g).to(dev).to(dt)
+        do = (torch.randn((n, *size, c), generator=g) * 0.1).to(dev).to(dt)
+        mr = torch.stack([torch.randn((n, 8), generator=g) * 0.1, torch.rand((n, 8), generator=g) + 0.5], -1).to(dev).contiguous()
+        gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+        gs = (torch.rand((n, c), generator=g) + 0.5).to(dev)
+        ga = (torch.randn((n, c), generator=g) * 0.01).to(dev)
+        ref = ops.evonorm_bwd(ops.channel_scale(do, gs, add=ga), y, mr, gamma, 8)
+        got = ops.evonorm_bwd(do, y, mr, gamma, 8, gscale=gs, gadd=ga)
+        for a, b in zip(got[:3], ref[:3]):
+            if tol == 0.0:
+                assert torch.equal(a, b)
+            else:
+                torch.testing.assert_close(a.float(), b.float(), atol=tol * float(b.float().abs().max()), rtol=tol)
