@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <type_traits>
 #include "../../include/brats_hip.h"
 
@@ -110,6 +111,45 @@ DEVI float f8_scale_from_amax(float amax) {
 }
 
 
+// ---- LDS-DMA (buffer_load ... lds) helpers shared by the weight-gradient and the loader-wave convolution kernels ----
+// a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop
+// into registers the accumulators need.  (The host pass of hipcc instantiates the kernel template's generic lambdas too
+// and silently drops the kernel stub when it meets a "v" constraint there, hence the device-pass guard.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OPAQUE_V(x) asm volatile("" : "+v"(x))
+#else
+#define OPAQUE_V(x) do { } while (0)
+#endif
+
+// one LDS-DMA instruction: lane l's 16 bytes at buffer offset `off` (out of range: zeros) land at dst + 16 l; dst wave-uniform.
+// (A function of its own: called directly inside the kernel TEMPLATE's generic lambdas the builtin makes hipcc's host pass
+// drop the kernel stub without a diagnostic.)
+DEVI void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, int off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+}
+// The same instruction as inline assembly.  Why: hipcc treats every LDS-DMA as a store to ALL of LDS and puts
+// s_waitcnt vmcnt(<everything issued so far>) in front of the next LDS read -- the transfers of the NEXT tile, issued right
+// before the MFMA phase, were waited for before its first operand read, i.e. never overlapped with it (found in the ISA:
+// vmcnt(0) between the last buffer_load ... lds and the first ds_read_b64_tr).  An asm statement is opaque to that pass;
+// the kernels wait themselves (s_waitcnt vmcnt(0) before the barrier that precedes the first read of the buffer).
+// M0 (the LDS destination base) is compiler-reserved: it is saved, written and restored inside the ONE statement that
+// reads it (cdna_hip_programming.md 5.7) -- no "m0" clobber, which hipcc flags as undefined behaviour.
+// rs = buffer descriptor words {base lo, base hi (stride 0), bytes, 0x00020000}; dst wave-uniform.
+typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+DEVI rsrc4_t make_rsrc4(const void* base, unsigned bytes) {
+  const size_t p = (size_t)base;
+  return rsrc4_t{__builtin_amdgcn_readfirstlane((int)(unsigned)p), __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu)),
+                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+}
+DEVI void lds_dma16_async(rsrc4_t rs, char* dst, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(m), "v"(off), "s"(rs) : "memory");
+#endif
+}
+
 // compile-time loop with a constexpr index
 template <int I, int N, typename F> DEVI void static_for(F&& f) {
   if constexpr (I < N) {
@@ -123,6 +163,16 @@ void brats_set_error(const char* fmt, ...);
 #define BRATS_FAIL(code, ...) do { brats_set_error(__VA_ARGS__); return (code); } while (0)
 #define BRATS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
   BRATS_FAIL(BRATS_E_HIP, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): `flag` is a static std::atomic<uint64_t> of the
+// launch site, one bit per device ordinal (a racing second call sets the same value again: harmless).  The entry points
+// may be called from any host thread and on any device (include/brats_hip.h).
+#define BRATS_ENSURE_LDS_ATTR(kern, bytes, flag) do { \
+  int dev_ = 0; (void)hipGetDevice(&dev_); const uint64_t bit_ = 1ull << (dev_ & 63); \
+  if (!((flag).load(std::memory_order_acquire) & bit_)) { \
+    hipError_t e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+    if (e_ != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", (int)(bytes), hipGetErrorString(e_)); \
+    (flag).fetch_or(bit_, std::memory_order_release); } } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

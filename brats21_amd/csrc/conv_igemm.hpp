@@ -113,16 +113,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       constexpr int k = k_;
       constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
 #pragma unroll
-#ifdef BRATS_VS8_FAKEW  // ablation (diagnostic build only, wrong results): every step re-reads the first 3 KB -> L1-resident weights
-      for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)(ms & 0) * rows16 + f) * 64];
-#elif defined(BRATS_VS8_FAKEW4)  // ablation (wrong results): only every 4th macro-step loads weights -> 1/4 of the weight load instructions
-      for (int f = 0; f < NF; ++f) {
-        if constexpr (k % 4 == 0) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
-        else a[k % (WD + 1)][f] = a[(k + WD) % (WD + 1)][f];
-      }
-#else
       for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
-#endif
     };
     auto read_b = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
@@ -459,12 +450,8 @@ template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = fa
 int conv_launch_one(const ConvParams& p, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT, VS>();
   auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT, VS>::NFW));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   BRATS_CHECK_LAUNCH();

@@ -319,12 +319,8 @@ template <int CK, int DIL, int NF, bool VS>
 int conv_f8_launch_one(const ConvF8Params& p, hipStream_t st) {
   constexpr int lds = conv_f8_lds_bytes<CK, DIL, NF, VS>();
   auto kern = conv_igemm_f8_kernel<CK, DIL, NF, VS>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   dim3 grid((unsigned)(p.c.N * p.c.tz * p.c.ty * p.c.tx), (unsigned)(p.c.rows16 / F8Tile<NF, VS>::NFW));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   BRATS_CHECK_LAUNCH();

@@ -23,6 +23,122 @@ constexpr int conv_vs8_lds_bytes() {
   return (G::LDS_TILE + 15) / 16 * 16 + 4 * NF * 16 * 2 * 4;
 }
 
+// Epilogue of the 4 x 8 x 16-tile kernels (conv_igemm_vs8_kernel, conv_igemm_ld_kernel): bias, per-channel statistics of the
+// wave's 4x4x16 sub-tile half (DPP row sums -> sred[wm + 2 wn][NF*16][2]) and the NDHWC stores.  acc[f][i]: cout fragment f,
+// voxel fragment i = x-row (z = z0 + 2 wm + i / 4, y = y0 + 4 wn + i % 4).
+template <int NF>
+DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sred, int wm, int wn, int q, int v,
+                             int z0, int y0, int x0, int ct, int f0, size_t sample_vox) {
+  typedef bf16_t T;
+  constexpr int NB = 8, YB = 4;
+  const bool x_ok = x0 + v < p.W;
+  const bool second = p.y2 != nullptr && f0 * 16 >= p.ysplit;
+  T* const ydst = second ? (T*)p.y2 : (T*)p.y;
+  const int ypit = second ? p.y2pitch : p.ypitch;
+  const int csub = second ? p.ysplit : 0;
+  const int lane_o = (x0 + v) * ypit + 4 * q - csub;
+  float bias[NF][4], s1[NF][4], s2[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int cbase = (f0 + f) * 16 + 4 * q;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      bias[f][rr] = (p.bias && cbase < p.cout) ? p.bias[cbase + rr] : 0.f;
+      s1[f][rr] = 0.f;
+      s2[f][rr] = 0.f;
+    }
+  }
+  const bool full = z0 + CONV_TZ <= p.D && y0 + VS8_TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * NF * 16 <= p.cout;
+  if (full && ypit % 8 == 0 && csub % 8 == 0 && ((size_t)ydst & 15) == 0) {
+    // 16-byte stores: the lanes of MFMA rows q and q ^ 1 hold channels 4q..4q+3 and the next four of the SAME voxel;
+    // exchanging halves between two x-rows (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of
+    // the second) gives every lane 8 consecutive channels of ONE voxel: rows 0 / 2 keep x-row i, rows 1 / 3 take x-row
+    // i + 1.  Half the store instructions; worth ~1 % (the epilogue waits on the CU's ~10 B/clk store path, not on issue).
+    const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
+#pragma unroll
+    for (int i = 0; i < NB; i += 2) {
+      const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
+      T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float o[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            o[rr] = acc[f][i + e][rr] + bias[f][rr];
+            s1[f][rr] += o[rr];
+            s2[f][rr] += o[rr] * o[rr];
+          }
+          pk[e][0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+          pk[e][1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+        }
+        const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        *(u32x4*)(rowp + lane_w + (f0 + f) * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
+      const bool ok = z < p.D && y < p.H && x_ok;
+      const float mk = ok ? 1.f : 0.f;
+      T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const bool cok = (f0 + f) * 16 + 4 * q < p.cout;
+        const float mf = cok ? mk : 0.f;
+        float o[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          o[rr] = acc[f][i][rr] + bias[f][rr];
+          const float om = o[rr] * mf;
+          s1[f][rr] += om;
+          s2[f][rr] += om * o[rr];
+        }
+        if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        s1[f][rr] = row16_sum(s1[f][rr]);
+        s2[f][rr] = row16_sum(s2[f][rr]);
+      }
+      if (v == 0) {
+        const int cl = f * 16 + 4 * q;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 0] = s1[f][rr];
+          sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 1] = s2[f][rr];
+        }
+      }
+    }
+  }
+}
+
+// second half: one 4x4x16 statistics entry per y-half (wn), after a workgroup barrier behind vs8_epilogue_store
+template <int NF>
+DEVI void vs8_epilogue_stats(const ConvParams& p, int ty4, const float* sred, int tid, int n, int tzi, int tyi, int txi, int ct) {
+  if (tid < 2 * NF * 16) {
+    const int half = tid / (NF * 16), cl = tid % (NF * 16);
+    const int c = ct * NF * 16 + cl;
+    const int ty_i = tyi * 2 + half;
+    if (c < p.cout && ty_i < ty4) {
+      const size_t tps = (size_t)p.tz * ty4 * p.tx;
+      const size_t tile = ((size_t)tzi * ty4 + ty_i) * p.tx + txi;
+      float* dst = p.stats + (((size_t)n * tps + tile) * p.cout + c) * 2;
+      dst[0] = sred[((2 * half) * NF * 16 + cl) * 2] + sred[((2 * half + 1) * NF * 16 + cl) * 2];
+      dst[1] = sred[((2 * half) * NF * 16 + cl) * 2 + 1] + sred[((2 * half + 1) * NF * 16 + cl) * 2 + 1];
+    }
+  }
+}
+
 template <int CK, int DIL, int NF>
 __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
   using T = bf16_t;
@@ -126,97 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
   // --- epilogue: bias, statistics per 4x4x16 sub-tile, NDHWC store ---
   constexpr int LDS_MAIN = (G::LDS_TILE + 15) / 16 * 16;
   float* sred = (float*)(lds + LDS_MAIN);  // [4 (wm + 2 wn)][NF*16][2]
-  {
-    const bool x_ok = x0 + v < p.W;
-    const bool second = p.y2 != nullptr && f0 * 16 >= p.ysplit;
-    T* const ydst = second ? (T*)p.y2 : (T*)p.y;
-    const int ypit = second ? p.y2pitch : p.ypitch;
-    const int csub = second ? p.ysplit : 0;
-    const int lane_o = (x0 + v) * ypit + 4 * q - csub;
-    float bias[NF][4], s1[NF][4], s2[NF][4];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int cbase = (f0 + f) * 16 + 4 * q;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        bias[f][rr] = (p.bias && cbase < p.cout) ? p.bias[cbase + rr] : 0.f;
-        s1[f][rr] = 0.f;
-        s2[f][rr] = 0.f;
-      }
-    }
-    const bool full = z0 + CONV_TZ <= p.D && y0 + VS8_TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * NF * 16 <= p.cout;
-    if (full && ypit % 8 == 0 && csub % 8 == 0 && ((size_t)ydst & 15) == 0) {
-      // 16-byte stores: the lanes of MFMA rows q and q ^ 1 hold channels 4q..4q+3 and the next four of the SAME voxel;
-      // exchanging halves between two x-rows (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of
-      // the second) gives every lane 8 consecutive channels of ONE voxel: rows 0 / 2 keep x-row i, rows 1 / 3 take x-row
-      // i + 1.  Half the store instructions; worth ~1 % (the epilogue waits on the CU's ~10 B/clk store path, not on issue).
-      const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
-#pragma unroll
-      for (int i = 0; i < NB; i += 2) {
-        const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
-        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          uint32_t pk[2][2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            float o[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              o[rr] = acc[f][i + e][rr] + bias[f][rr];
-              s1[f][rr] += o[rr];
-              s2[f][rr] += o[rr] * o[rr];
-            }
-            pk[e][0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-            pk[e][1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-          }
-          const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-          const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-          *(u32x4*)(rowp + lane_w + (f0 + f) * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
-        const bool ok = z < p.D && y < p.H && x_ok;
-        const float mk = ok ? 1.f : 0.f;
-        T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const bool cok = (f0 + f) * 16 + 4 * q < p.cout;
-          const float mf = cok ? mk : 0.f;
-          float o[4];
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            o[rr] = acc[f][i][rr] + bias[f][rr];
-            const float om = o[rr] * mf;
-            s1[f][rr] += om;
-            s2[f][rr] += om * o[rr];
-          }
-          if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
-        }
-      }
-    }
-    if (p.stats) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          s1[f][rr] = row16_sum(s1[f][rr]);
-          s2[f][rr] = row16_sum(s2[f][rr]);
-        }
-        if (v == 0) {
-          const int cl = f * 16 + 4 * q;
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 0] = s1[f][rr];
-            sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 1] = s2[f][rr];
-          }
-        }
-      }
-    }
-  }
+  vs8_epilogue_store<NF>(p, acc, sred, wm, wn, q, v, z0, y0, x0, ct, f0, sample_vox);
 #ifdef BRATS_VS8_STAMPS
   VS8_STAMP(5);  // epilogue
   if (lane == 0 && p.stamps) {
@@ -226,18 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
 #endif
   if (p.stats) {
     __syncthreads();
-    if (tid < 2 * NF * 16) {  // one 4x4x16 statistics entry per y-half (wn)
-      const int half = tid / (NF * 16), cl = tid % (NF * 16);
-      const int c = ct * NF * 16 + cl;
-      const int ty_i = tyi * 2 + half;
-      if (c < p.cout && ty_i < ty4) {
-        const size_t tps = (size_t)p.tz * ty4 * p.tx;
-        const size_t tile = ((size_t)tzi * ty4 + ty_i) * p.tx + txi;
-        float* dst = p.stats + (((size_t)n * tps + tile) * p.cout + c) * 2;
-        dst[0] = sred[((2 * half) * NF * 16 + cl) * 2] + sred[((2 * half + 1) * NF * 16 + cl) * 2];
-        dst[1] = sred[((2 * half) * NF * 16 + cl) * 2 + 1] + sred[((2 * half + 1) * NF * 16 + cl) * 2 + 1];
-      }
-    }
+    vs8_epilogue_stats<NF>(p, ty4, sred, tid, n, tzi, tyi, txi, ct);
   }
 }
 
@@ -253,12 +268,8 @@ template <int CK, int DIL, int NF>
 int conv_launch_vs8(const ConvParams& p0, hipStream_t st) {
   constexpr int lds = conv_vs8_lds_bytes<CK, DIL, NF>();
   auto kern = conv_igemm_vs8_kernel<CK, DIL, NF>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   ConvParams p = p0;
   const int ty4 = p.ty;
   p.ty = ceil_div(p.H, VS8_TY);

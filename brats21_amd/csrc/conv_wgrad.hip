@@ -490,40 +490,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
 //    tiles at 128^3) costs ONE v_add per piece instead of ~20 VALU instructions of unpack / range tests / multiply-adds,
 //    which used to run in both waves of every SIMD at the same time, with the matrix pipe idle;
 //  * the freed registers carry one more B fragment in flight (prefetch distance 3).
-// a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop
-// into registers the accumulators need.  (The host pass of hipcc instantiates the kernel template's generic lambdas too
-// and silently drops the kernel stub when it meets a "v" constraint there, hence the device-pass guard.)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define OPAQUE_V(x) asm volatile("" : "+v"(x))
-#else
-#define OPAQUE_V(x) do { } while (0)
-#endif
-
-// one LDS-DMA instruction: lane l's 16 bytes at buffer offset `off` (out of range: zeros) land at dst + 16 l; dst wave-uniform.
-// (A function of its own: called directly inside the kernel TEMPLATE's generic lambdas the builtin makes hipcc's host pass
-// drop the kernel stub without a diagnostic.)
-DEVI void lds_dma16(__amdgpu_buffer_rsrc_t rs, char* dst, int off) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
-}
-// The same instruction as inline assembly.  Why: hipcc treats every LDS-DMA as a store to ALL of LDS and puts
-// s_waitcnt vmcnt(<everything issued so far>) in front of the next LDS read -- the transfers of the NEXT tile, issued right
-// before the MFMA phase, were waited for before its first operand read, i.e. never overlapped with it (found in the ISA:
-// vmcnt(0) between the last buffer_load ... lds and the first ds_read_b64_tr).  An asm statement is opaque to that pass;
-// the kernels wait themselves (s_waitcnt vmcnt(0) at the top of the tile loop, before the buffer is read).
-// rs = buffer descriptor words {base lo, base hi (stride 0), bytes, 0x00020000}; dst wave-uniform.
-typedef int rsrc4_t __attribute__((ext_vector_type(4)));
-DEVI rsrc4_t make_rsrc4(const void* base, unsigned bytes) {
-  const size_t p = (size_t)base;
-  return rsrc4_t{__builtin_amdgcn_readfirstlane((int)(unsigned)p), __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffu)),
-                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
-}
-DEVI void lds_dma16_async(rsrc4_t rs, char* dst, int off) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)dst);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m), "v"(off), "s"(rs) : "memory", "m0");
-#endif
-}
-
+// (OPAQUE_V, lds_dma16, lds_dma16_async, make_rsrc4: common.hpp)
 // Two block shapes: 48 co x 48 ci (COF, CIF = 3, 3: widths 48 / 96 / ...) and 64 co x 32 ci (4, 2: widths that are multiples
 // of 64 but not of 48 -- EquiUnetASSPEvo-64; 54 (tap, ci-fragment) pairs, 7 x 4 accumulators per lane, X 2 x 48 KB + dY 32 KB).
 template <int COF, int CIF> struct Wg3b {
@@ -1082,12 +1049,8 @@ template <typename T, int DIL, int COF, int CIF, int KS = 3>
 static int wgrad_launch(const WgradParams& p, dim3 grid, hipStream_t st) {
   using G = WgGeom<T, DIL, COF, CIF, KS>;
   auto kern = conv_wgrad_kernel<T, DIL, COF, CIF, KS>;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", G::LDS, hipGetErrorString(e));
-    done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  BRATS_ENSURE_LDS_ATTR(kern, G::LDS, attr_done);
   hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS, st, p);
   BRATS_CHECK_LAUNCH();
   return 0;
@@ -1145,21 +1108,16 @@ extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void
   int rc;
   if (alltaps) {
     p.nsplit = p.nlane * g8a;
-    static bool done = false;
-    if (!done) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3<3>::LDS);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_wgrad_alltaps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, Wg3<1>::LDS);
-      if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", Wg3<3>::LDS, hipGetErrorString(e));
-      done = true;
-    }
     constexpr int lds_48 = Wg3b<3, 3>::LDS, lds_wide = Wg3b<4, 2>::LDS;
+    static std::atomic<uint64_t> attr_a{0}, attr_b{0}, attr_c{0}, attr_d{0};
+    BRATS_ENSURE_LDS_ATTR(conv_wgrad_alltaps_kernel<3>, Wg3<3>::LDS, attr_a);
+    BRATS_ENSURE_LDS_ATTR(conv_wgrad_alltaps_kernel<1>, Wg3<1>::LDS, attr_b);
+    BRATS_ENSURE_LDS_ATTR((conv_wgrad_alltaps2_kernel<3, 3>), lds_48, attr_c);
+    BRATS_ENSURE_LDS_ATTR((conv_wgrad_alltaps2_kernel<4, 2>), lds_wide, attr_d);
     static int form = -1;  // BRATS_WGRAD_ALLTAPS=1: the round-1 form (register staging, one X buffer) for same-box A/B runs
     if (form < 0) {
       const char* e = getenv("BRATS_WGRAD_ALLTAPS");
       form = (e && atoi(e) == 1) ? 1 : 2;
-      hipError_t e2 = hipFuncSetAttribute((const void*)conv_wgrad_alltaps2_kernel<3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_48);
-      if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)conv_wgrad_alltaps2_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_wide);
-      if (e2 != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad: hipFuncSetAttribute(%d): %s", lds_48, hipGetErrorString(e2));
     }
     if (wide) {
       hipLaunchKernelGGL((conv_wgrad_alltaps2_kernel<4, 2>), dim3(p.nsplit, cout / 64, p.cin / 32), dim3(512), lds_wide, st, p);
@@ -1288,12 +1246,8 @@ template <int COF, int CIF>
 static int wgrad_f8_launch(const WgradF8Params& pp, hipStream_t st) {
   using G = Wg3f<COF, CIF>;
   auto kern = conv_wgrad_alltaps_f8_kernel<COF, CIF>;
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad_f8: hipFuncSetAttribute(%d): %s", G::LDS, hipGetErrorString(e));
-    done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  BRATS_ENSURE_LDS_ATTR(kern, G::LDS, attr_done);
   hipLaunchKernelGGL(kern, dim3(pp.w.nsplit, pp.w.cout / G::CO, pp.w.cin / G::CI), dim3(512), G::LDS, st, pp);
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -312,13 +312,9 @@ extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch
     const dim3 g2(H / 2, D, N);  // (Ho / 4, Do / 2, N)
     const size_t ldsx = (size_t)12 * W * C * 2;
     if (dtype == BRATS_BF16 && ldsx <= 80 * 1024) {  // two blocks per CU with their input rows in LDS
-      static bool attr_done = false;
-      if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)upsample2_fwd_kernel<bf16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)upsample2_fwd_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "upsample_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
-      }
+      static std::atomic<uint64_t> attr_a{0}, attr_b{0};
+      BRATS_ENSURE_LDS_ATTR((upsample2_fwd_kernel<bf16_t, true, true>), 80 * 1024, attr_a);
+      BRATS_ENSURE_LDS_ATTR((upsample2_fwd_kernel<bf16_t, false, true>), 80 * 1024, attr_b);
       if (stream_nt((size_t)N * D * H * W * 8 * C * 2))
         hipLaunchKernelGGL((upsample2_fwd_kernel<bf16_t, true, true>), g2, dim3(256), ldsx, (hipStream_t)s, (const bf16_t*)x, xpitch, (bf16_t*)y,
                            ypitch, C, D, H, W, sd, sh, sw);

@@ -59,14 +59,25 @@ class GraphedTrainStep:
     RCCL's stream inside the graph and joined before the optimizer kernels -- so the 8-GPU step of EquiUnetASSPEvo is one
     graph launch per rank instead of a host-bound eager step.  The capture then runs in "thread_local" error mode
     (ProcessGroupNCCL's watchdog thread polls events while the stream is capturing; probed on ROCm 7 / PyTorch 2.10:
-    scripts/probes/nccl_capture.py).  Needs >= 2 warm-up steps: the first one learns the bucket order."""
+    scripts/probes/nccl_capture.py).  Needs >= 2 warm-up steps: the first one learns the bucket order.
 
-    def __init__(self, step, warmup=2):
+    UNVERIFIED ON MORE THAN ONE GPU: capturing the collectives has only been exercised at world size 1 with forced
+    collectives (tests/test_ddp_gpu.py) -- this pool has 1-GPU boxes.  Cross-rank ordering of the bucket launches inside the
+    capture, the watchdog under real traffic and bf16 wire copies are untested, so world size > 1 must be asked for
+    explicitly: ``multi_rank_capture=True`` (or BRATS_GRAPH_DDP=1); otherwise use the eager TrainStep with buckets."""
+
+    def __init__(self, step, warmup=2, multi_rank_capture=None):
         if step.buckets is not None:
+            import os
             import torch.distributed as dist
             if dist.is_initialized() and dist.get_backend(step.buckets.group) != "nccl":
                 raise NotImplementedError("GraphedTrainStep with gradient buckets needs the nccl (RCCL) backend: a gloo "
                                           "all-reduce runs on the host and cannot be captured into a hipGraph")
+            if multi_rank_capture is None:
+                multi_rank_capture = os.environ.get("BRATS_GRAPH_DDP", "0") == "1"
+            if dist.is_initialized() and dist.get_world_size(step.buckets.group) > 1 and not multi_rank_capture:
+                raise NotImplementedError("GraphedTrainStep: capturing RCCL all-reduces at world size > 1 is unverified on "
+                                          "multi-GPU hardware; pass multi_rank_capture=True (or BRATS_GRAPH_DDP=1) to opt in")
             warmup = max(warmup, 2)
         if not getattr(step.optimizer, "capturable", False) and not all(
                 g.get("capturable", False) for g in step.optimizer.param_groups):

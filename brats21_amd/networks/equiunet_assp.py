@@ -209,30 +209,28 @@ def _block_fwd(cx, blk, x, out=None):
     s = blk.conv_conv_se
     z1, _, r1 = _conv_evo_fwd(cx, s[0], s[1], x)
     z2, cs, r2 = _conv_evo_fwd(cx, s[3], s[4], z1, want_chansum=True)
-    # ResidualSELayer: out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2); the two FCs are [N, C] GEMVs -> torch
+    # ResidualSELayer: out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2): the gate is one launch (csrc/se.hip)
     n, d, h, w, c = z2.shape
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
-    with torch.enable_grad(), torch.autocast("cuda", enabled=False):  # [N, C] GEMVs stay f32
-        gap = (cs / float(d * h * w)).detach().requires_grad_(True)
-        gate = torch.sigmoid(F.linear(F.relu(F.linear(gap, fc1.weight, fc1.bias)), fc2.weight, fc2.bias))
+    gate1p, hidden = ops.se_gate(cs, d * h * w, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
     amax = cx.slot(z2.device)
-    o = ops.channel_scale(z2, (1.0 + gate.detach()), out=out, amax=amax)
+    o = ops.channel_scale(z2, gate1p, out=out, amax=amax)
     if amax is not None:
         o._amax = amax
-    return o, (blk, r1, r2, z2, gap, gate)
+    return o, (blk, r1, r2, z2, cs, hidden, gate1p)
 
 
 def _block_bwd(cx, rec, do, need_dx=True):
-    blk, r1, r2, z2, gap, gate = rec
+    blk, r1, r2, z2, cs, hidden, gate1p = rec
     s = blk.conv_conv_se
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
     n, d, h, w, c = z2.shape
     dgate = ops.channel_dot(do, z2)  # [N, C] = sum_v do * z2
-    dgap, dw1, db1, dw2, db2 = torch.autograd.grad(gate, [gap, fc1.weight, fc1.bias, fc2.weight, fc2.bias], dgate)
+    gadd, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, cs, d * h * w, hidden, gate1p, fc1.weight, fc2.weight)
     for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2)):
         cx.put(prm, g)
     # d out / d z2 = do * (1 + gate) + dgap / V per (n, channel): read inside the EvoNorm backward instead of a pass of its own
-    dz1 = _conv_evo_bwd(cx, r2, do, gscale=(1.0 + gate.detach()).float(), gadd=(dgap / float(d * h * w)).float())
+    dz1 = _conv_evo_bwd(cx, r2, do, gscale=gate1p, gadd=gadd)
     return _conv_evo_bwd(cx, r1, dz1, need_dx)
 
 

@@ -762,6 +762,32 @@ def channel_scale(a, scale, add=None, out=None, amax=None):
     return out
 
 
+def se_gate(chansum, voxels, w1, b1, w2, b2):
+    """ResidualSELayer gate from the channel sums of z: -> (1 + gate [N, C], hidden [N, C/r]) in one launch."""
+    n, c = chansum.shape
+    ch = w1.shape[0]
+    gate1p = torch.empty((n, c), dtype=torch.float32, device=chansum.device)
+    hidden = torch.empty((n, ch), dtype=torch.float32, device=chansum.device)
+    _lib.check(_lib.lib().brats_se_fwd(_f32(chansum.contiguous()), 1.0 / float(voxels), _f32(w1.detach().contiguous()), _f32(b1.detach()),
+                                       _f32(w2.detach().contiguous()), _f32(b2.detach()), gate1p.data_ptr(), hidden.data_ptr(),
+                                       n, c, ch, _stream()), "se_fwd")
+    return gate1p, hidden
+
+
+def se_gate_bwd(dgate, chansum, voxels, hidden, gate1p, w1, w2):
+    """-> (gadd [N, C] = d loss / d gap / V, dW1, db1, dW2, db2) in one launch."""
+    n, c = chansum.shape
+    ch = w1.shape[0]
+    dev = chansum.device
+    gadd = torch.empty((n, c), dtype=torch.float32, device=dev)
+    dw1, db1 = torch.empty((ch, c), dtype=torch.float32, device=dev), torch.empty((ch,), dtype=torch.float32, device=dev)
+    dw2, db2 = torch.empty((c, ch), dtype=torch.float32, device=dev), torch.empty((c,), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().brats_se_bwd(_f32(dgate.contiguous()), _f32(chansum.contiguous()), 1.0 / float(voxels), _f32(hidden), _f32(gate1p),
+                                       _f32(w1.detach().contiguous()), _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(),
+                                       db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), n, c, ch, _stream()), "se_bwd")
+    return gadd, dw1, db1, dw2, db2
+
+
 _DCONV_JOB = np.dtype([("term", [("x", "<u8"), ("w", "<u8"), ("xpitch", "<i4"), ("cin", "<i4"), ("ksize", "<i4"), ("dil", "<i4")], (4,)),
                        ("nterms", "<i4"), ("rows", "<i4"), ("bias", "<u8"), ("y", "<u8"), ("ypitch", "<i4"), ("reserved", "<i4")])
 # == brats_dconv_job (include/brats_hip.h)

@@ -31,7 +31,8 @@ typedef void* brats_stream_t; /* hipStream_t */
 enum { BRATS_F32 = 0, BRATS_BF16 = 1 };
 enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
 /* --act of the reference (src/arguments_train.py:49-50; MONAI Act factory): relu, leakyrelu(slope), elu(alpha=1),
- * swish = x*sigmoid(x), mish = x*tanh(softplus(x)).  prelu (a learnable slope) is not built. */
+ * swish = x*sigmoid(x), mish = x*tanh(softplus(x)).  prelu = BRATS_ACT_LEAKY with the learnable slope read from device
+ * memory (`slope_dev` of brats_affine_act / brats_gn_bwd_apply) + brats_prelu_slope_grad for its gradient. */
 enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_ELU = 3, BRATS_ACT_SWISH = 4, BRATS_ACT_MISH = 5 };
 
 int brats_abi_version(void);
@@ -80,8 +81,10 @@ int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* block
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
 /* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
 int brats_conv3d_split_granule(int cout);
-/* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
- * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (1, or BRATS_CONV_VS8).  The setting
+/* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 2 = 16-channel chunks + the loader-wave kernel on the
+ * 4x8x16 tile (conv_igemm_ld.hpp: next chunk prefetched by LDS-DMA), 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
+ * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (BRATS_CONV_VS8).  Bits 4.. of a
+ * non-negative mode select a tuning variant of the mode-2 kernel (scripts/time_ld.py; 0 = the default).  The setting
  * changes brats_conv3d_chunk(), i.e. the packed-weight layout: weights must be packed under the same setting they are
  * used with (the Python side offers ops.set_vs8(), which also drops its packed-weight caches).  Returns the previous setting. */
 int brats_conv3d_set_vs8(int mode);
@@ -201,8 +204,18 @@ int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, co
                       const float* gscale, const float* gadd /* optional [N][C]: dz is read as dz * gscale + gadd -- the
                       ResidualSELayer backward (out = z + z * gate) folded in instead of a separate channel_scale pass */,
                       brats_stream_t s);
-/* ---- squeeze-excite helpers (MONAI ResidualSELayer, equiunet2021.py:204-205): per-(n,channel)
- * reductions over voxels and per-(n,channel) scale(+add) passes; the two tiny FC layers stay in torch. */
+/* ---- squeeze-excite (MONAI ResidualSELayer(3, C, r = 2, relu, sigmoid), equiunet2021.py:204-205): per-(n,channel)
+ * reductions over voxels, per-(n,channel) scale(+add) passes, and the gate itself (round 3: ONE launch forward, ONE launch
+ * backward instead of ~20 ATen launches per block):
+ *   gate1p[n][c] = 1 + sigmoid(b2 + W2 relu(b1 + W1 (chansum[n] * inv_vox)))      W1 [Ch][C], W2 [C][Ch] (nn.Linear layout)
+ *   hidden[n][j] = the post-ReLU hidden vector (saved for the backward)
+ * backward: dgate[n][c] = d loss / d gate (= brats_channel_dot(dout, z)) -> gadd[n][c] = (d loss / d gap) * inv_vox (the
+ * `gadd` of brats_evonorm_bwd) and the four parameter gradients (samples added in order: bitwise reproducible).  N <= 8. */
+int brats_se_fwd(const float* chansum, float inv_vox, const float* w1, const float* b1, const float* w2, const float* b2,
+                 float* gate1p /*[N][C]*/, float* hidden /*[N][Ch]*/, int N, int C, int Ch, brats_stream_t s);
+int brats_se_bwd(const float* dgate, const float* chansum, float inv_vox, const float* hidden, const float* gate1p,
+                 const float* w1, const float* w2, float* gadd /*[N][C]*/, float* dw1, float* db1, float* dw2, float* db2,
+                 int N, int C, int Ch, brats_stream_t s);
 int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,
                       int dtype, int N, int voxels, int C, brats_stream_t s);
 int brats_channel_scale(const void* a, int apitch, const float* scale /*[N][C]*/, const float* add /*[N][C] or NULL*/,

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
 python3 bench.py --steps 10 --warmup 3 --kernel-table > $out/bench.json 2> $out/conv_table.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline > $out/bench_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > $out/bench_profiled.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 bash scripts/pmc.sh final/pmc scripts/prof_conv.py all > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc > $out/pmc_conv.txt
@@ -13,13 +13,13 @@ bash scripts/pmc.sh final/pmc_dom scripts/prof_conv.py dom > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc_dom > $out/pmc_dominant.txt
 python3 scripts/pmc_report.py final/pmc_dom --json "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128" "conv_igemm_vs8_kernel<24, 1, 3>" > $out/pmc_dominant.json
 python3 bench.py --steps 10 --warmup 3 --fp8 all --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_fp8.json
-python3 bench.py --steps 10 --warmup 3 --fp8 all --graph --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_fp8_graph.json
-python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_assp.json
-python3 bench.py --model equiunet_assp_evo --graph --steps 10 --warmup 3 --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_assp_graph.json
-python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --graph --steps 10 --warmup 3 --no-infer --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_assp64_fp8_graph.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp -- python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline > /dev/null 2>&1
+python3 bench.py --steps 10 --warmup 3 --fp8 all --graph --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_fp8_graph.json
+python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp.json
+python3 bench.py --model equiunet_assp_evo --graph --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp_graph.json
+python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --graph --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp64_fp8_graph.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp -- python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > /dev/null 2>&1
 cp $out/stats_assp/*/*kernel_stats.csv $out/bench_assp_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp64 -- python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --steps 10 --warmup 3 --no-infer --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp64 -- python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > /dev/null 2>&1
 cp $out/stats_assp64/*/*kernel_stats.csv $out/bench_assp64_fp8_kernel_stats.csv
 PYTHONPATH=. python3 scripts/time_wgrad_f8.py > $out/wgrad_f8_table.txt 2>/dev/null
 tail -c 600 $out/bench.json; echo; cat $out/pmc_conv.txt | cut -c1-250

@@ -14,6 +14,17 @@ DDP_GPU_RESULT = os.path.join(ROOT, "gpurun_out", "ddp2_one_gpu.json")
 _ddp_proc = None
 
 
+def deselect_match(item, config):
+    """-k is applied by pytest AFTER this hook (it is a modifyitems hook of its own, ordering not guaranteed): evaluate it
+    here so that `-k something_else` does not start the two-rank worker."""
+    try:
+        from _pytest.mark import KeywordMatcher
+        from _pytest.mark.expression import Expression
+        return Expression.compile(config.getoption("-k")).evaluate(KeywordMatcher.from_item(item))
+    except Exception:
+        return True
+
+
 def _gpu_run_selected(config):
     expr = config.getoption("-m") or ""
     return "gpu" in expr and "not gpu" not in expr
@@ -21,11 +32,19 @@ def _gpu_run_selected(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
     # tests/test_ddp_gpu.py::test_two_ranks_on_one_gpu: the two ranks must be FRESH processes started before this process
     # touches the GPU (a process that has initialised HIP must not fork + exec on the GPU boxes), so they are launched
-    # here, at configure time, and run beside the other tests; the test only waits for their verdict file.
+    # here -- after collection (importing the test modules does not initialise HIP), before the first test runs, and only
+    # when that test is actually selected -- and run beside the other tests; the test only waits for their verdict file.
     global _ddp_proc
-    if not _gpu_run_selected(config):
+    if not _gpu_run_selected(config) or _ddp_proc is not None:
+        return
+    deselect = config.getoption("-k") or ""
+    wanted = [it for it in items if "test_two_ranks_on_one_gpu" in it.nodeid and it.get_closest_marker("gpu")]
+    if not wanted or (deselect and not any(deselect_match(it, config) for it in wanted)):
         return
     import subprocess
     import torch

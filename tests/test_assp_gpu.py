@@ -9,6 +9,7 @@ import warnings
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import synth, unet
 
@@ -215,3 +216,55 @@ def test_evonorm_bwd_with_folded_se_gradient_map():
                 assert torch.equal(a, b)
             else:
                 torch.testing.assert_close(a.float(), b.float(), atol=tol * float(b.float().abs().max()), rtol=tol)
+
+
+@pytest.mark.parametrize("n,c", [(2, 48), (1, 16), (4, 384), (3, 96)])
+def test_se_gate_kernels_vs_torch_autograd(n, c):
+    """csrc/se.hip (one launch forward, one backward) against the MONAI ResidualSELayer arithmetic in torch f64:
+    gate = sigmoid(W2 relu(W1 gap + b1) + b2) with gap = chansum / V, and the gradients of gap, W1, b1, W2, b2
+    (networks/equiunet2021.py:204-205)."""
+    from brats21_amd import ops
+    g = torch.Generator().manual_seed(100 + c)
+    ch, vox = c // 2, 4096
+    cs = torch.randn((n, c), generator=g) * 300.0
+    w1, b1 = torch.randn((ch, c), generator=g) * 0.3, torch.randn((ch,), generator=g) * 0.2
+    w2, b2 = torch.randn((c, ch), generator=g) * 0.3, torch.randn((c,), generator=g) * 0.2
+    dgate = torch.randn((n, c), generator=g)
+    r = [t.double().requires_grad_(True) for t in (cs, w1, b1, w2, b2)]
+    gap = r[0] / vox
+    gate = torch.sigmoid(F.linear(F.relu(F.linear(gap, r[1], r[2])), r[3], r[4]))
+    gate.backward(dgate.double())
+    d = [t.to(DEV) for t in (cs, w1, b1, w2, b2)]
+    gate1p, hidden = ops.se_gate(d[0], vox, d[1], d[2], d[3], d[4])
+    torch.testing.assert_close(gate1p.cpu().double() - 1.0, gate.detach(), atol=2e-6, rtol=1e-5)
+    gadd, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate.to(DEV), d[0], vox, hidden, gate1p, d[1], d[3])
+    # gadd = d loss / d gap / V = d loss / d chansum
+    for got, ref, name in ((gadd, r[0].grad, "gadd"), (dw1, r[1].grad, "dw1"), (db1, r[2].grad, "db1"), (dw2, r[3].grad, "dw2"),
+                           (db2, r[4].grad, "db2")):
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((got.cpu().double() - ref).abs().max()) <= 2e-5 * scale, name
+    # bitwise reproducible
+    again = ops.se_gate_bwd(dgate.to(DEV), d[0], vox, hidden, gate1p, d[1], d[3])
+    assert all(torch.equal(a, b) for a, b in zip(again, (gadd, dw1, db1, dw2, db2)))
+
+
+def test_conv_evo_block_matches_reference_golden(golden_dir):
+    """ConvEvoBlockCorrected (conv-EvoNorm-conv-EvoNorm-ResidualSE, networks/equiunet2021.py:192-209) through the unit
+    program _block_fwd with the native SE gate, against the reference's own output (tests/golden/ops.npz: block_y)."""
+    from brats21_amd.networks import equiunet_assp as ea
+    gold = np.load(os.path.join(golden_dir, "ops.npz"))
+    blk = ea.ConvEvoBlockCorrected(16, 16)
+    order = list(blk.state_dict().keys())
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(synth.fill_state_dict({k: shapes[k] for k in order}))
+    blk = blk.to(DEV)
+
+    class _M(torch.nn.Module):
+        def __init__(self, b):
+            super().__init__()
+            self.b = b
+            self._grad_sink = None
+    x = synth.closed_form_image(1, 16, (12, 12, 12), "opx")
+    cx = ea._Ctx(_M(blk), torch.float32)
+    y, _ = ea._block_fwd(cx, blk, _to_ndhwc(x))
+    np.testing.assert_allclose(_from_ndhwc(y).numpy(), gold["block_y"], atol=1e-4)

@@ -377,8 +377,10 @@ def test_groupnorm_other_activations_fwd_bwd(dtype, act):
     (48, 48, 48, 1, (12, 20, 40)),    # two-source input, ragged tiles in z, y (20 = 2.5 tiles of 8 rows) and x
     (96, 0, 144, 1, (8, 12, 16)),     # three cout blocks, four 24-channel chunks, y = 1.5 tiles
 ])
-def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size):
-    """The 4x8x16-tile kernel (24-channel chunks, conv_igemm_vs8.hpp) against the 4x4x16-tile kernel (48-channel chunks):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size, mode):
+    """The 4x8x16-tile kernels -- mode 1: 24-channel chunks, conv_igemm_vs8.hpp; mode 2: the loader-wave kernel with
+    16-channel chunks prefetched by LDS-DMA, conv_igemm_ld.hpp -- against the 4x4x16-tile kernel (48-channel chunks):
     same products in f32, a different summation order over K, so the bf16 outputs differ by at most one rounding step
     of the result; the tile statistics (f32, taken before that rounding) agree to 1e-5 relative."""
     from brats21_amd import ops, _lib
@@ -393,7 +395,8 @@ def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size):
     try:
         wpk = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
         y0, s0 = ops.conv3d(x, wpk, cout, 3, 1, bias=b, want_stats=True, x2=x2)
-        ops.set_vs8(1)
+        ops.set_vs8(mode)
+        assert ops.conv_chunk(dt, 3, 1, cin, cin2, cout) == (24 if mode == 1 else 16)
         wpk8 = ops.pack_weights(w, dt, ops.PACK_FWD, c1=cin if cin2 else None)
         assert wpk8.numel() != wpk.numel() or not torch.equal(wpk8, wpk)  # really the other layout
         y1, s1 = ops.conv3d(x, wpk8, cout, 3, 1, bias=b, want_stats=True, x2=x2)
@@ -404,3 +407,40 @@ def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size):
     t0, t1 = s0.sum(1), s1.sum(1)   # [n, cout, 2]: per-tile entries may be dealt differently only at ragged edges
     assert torch.allclose(t0, t1, rtol=1e-5, atol=1e-3)
     assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-3)  # and each 4x4x16 entry holds the same voxels
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cin,cin2,cout,n,size,pitch", [
+    (48, 48, 48, 1, (9, 21, 37), None),   # two-source, ragged in z, y and x (every boundary mask of the halo staging)
+    (48, 0, 48, 2, (16, 16, 32), 64),     # channel-slice input views (pitch 64 > 48 channels), batch 2
+    (32, 64, 48, 1, (4, 8, 16), None),    # sources of different widths (c1 = 32: the 16-channel chunks; 24 does not divide it)
+])
+def test_conv3d_cout48_kernels_vs_torch(cin, cin2, cout, n, size, pitch, mode):
+    """The Cout = 48 kernels of the 128^3 level straight against torch's CPU f32 convolution: forward with
+    bias + tile statistics, two-source (virtual concat) input, ragged volumes, channel-slice views."""
+    from brats21_amd import ops
+    dev = _dev()
+    dt = torch.bfloat16
+    if mode == 1 and (cin % 24 or cin2 % 24):
+        pytest.skip("24-channel chunks do not divide this layer")
+    x = _q(_rand((n, cin) + size, 41), dt)
+    x2 = _q(_rand((n, cin2) + size, 42), dt) if cin2 else None
+    w = _q(_rand((cout, cin + cin2, 3, 3, 3), 43, 0.05), dt)
+    b = _rand((cout,), 44, 0.1)
+    torch.set_num_threads(16)
+    y_ref = F.conv3d(torch.cat([x, x2], 1) if cin2 else x, w, b, 1, 1)
+    xd = _to_ndhwc(x, dt, dev, pitch, 8 if pitch else 0)
+    x2d = _to_ndhwc(x2, dt, dev) if cin2 else None
+    old = ops.set_vs8(mode)
+    try:
+        assert ops.conv_chunk(dt, 3, 1, cin, cin2, cout) == (24 if mode == 1 else 16)
+        wpk = ops.pack_weights(w.to(dev), dt, ops.PACK_FWD, c1=cin if cin2 else None)
+        y, stats = ops.conv3d(xd, wpk, cout, 3, 1, bias=b.to(dev), want_stats=True, x2=x2d)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_vs8(old)
+    torch.testing.assert_close(_from_ndhwc(y), y_ref, atol=2e-2, rtol=2e-2)
+    st = stats.double().sum(1).cpu()
+    ref1, ref2 = y_ref.double().sum((2, 3, 4)), (y_ref.double() ** 2).sum((2, 3, 4))
+    torch.testing.assert_close(st[..., 0], ref1, atol=1e-2 * float(ref2.max()) ** 0.5, rtol=1e-3)
+    torch.testing.assert_close(st[..., 1], ref2, atol=1e-3, rtol=1e-3)
