@@ -147,6 +147,7 @@ def inference_bench(model, dev, args):
     model.eval()
     model.skip_deep_heads_in_eval = True
     amp = args.precision != "fp32"
+    amp_dtype = torch.float16 if args.precision == "fp16" else torch.bfloat16
     vol = synth.random_image(1, 4, (240, 240, 155), seed=99, device=dev)
     vol = vol * (synth.nested_spheres(1, (240, 240, 155), device=dev)[:, 0:1] > 0)  # zero background outside the "brain"
     fwd_flop = 1995.7e9 if args.model == "equiunet" else 1689.8e9  # per 4x128^3 patch forward
@@ -155,7 +156,7 @@ def inference_bench(model, dev, args):
     def leg(name, transforms, roi, overlap, forwards, flop, what):
         transforms = list(transforms)
         ev = Evaluator(model, tta_transforms=transforms, sliding_window_size=roi, sw_batch_size=args.sw_batch, overlap=overlap,
-                       k_divisible=8, amp=amp, use_graph=True)
+                       k_divisible=8, amp=amp, use_graph=True, amp_dtype=amp_dtype)
         with torch.no_grad():
             ev(vol)  # warm-up: lazy init, allocator, graph capture of every patch / volume shape
             torch.cuda.synchronize()
@@ -172,7 +173,7 @@ def inference_bench(model, dev, args):
 
     roi = (128, 128, 128)
     with torch.no_grad():  # first touch outside any graph (allocator, lazy init)
-        Evaluator(model, tta_transforms=tta.flip8()[:1], sliding_window_size=roi, overlap=0.5, amp=amp, use_graph=False)(vol)
+        Evaluator(model, tta_transforms=tta.flip8()[:1], sliding_window_size=roi, overlap=0.5, amp=amp, use_graph=False, amp_dtype=amp_dtype)(vol)
     leg("inference", tta.flip8(), roi, 0.5, 144, 144 * fwd_flop,
         f"4x240x240x155 padded to 160 (learning/engine.py:217), window 128^3, overlap 0.5, 18 windows x 8-flip TTA = 144 patch "
         f"forwards ({args.sw_batch} windows per launch), {args.precision}, hipGraph patch step, on-GPU mean + threshold + "
@@ -201,7 +202,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="patches per GPU")
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--model", default="equiunet")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="fp16 = the reference's own autocast dtype (IEEE half storage) under its GradScaler loop; bf16 is the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 logit parity) timing leg")
     ap.add_argument("--no-infer", action="store_true", help="skip the sliding-window + TTA inference measurement")
@@ -239,7 +241,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         model = get_model(ns).to(dev).train()
     if args.fp8:
-        assert args.precision == "bf16", "--fp8 needs bf16 activations"
+        assert args.precision in ("bf16", "fp16"), "--fp8 needs 16-bit activations"
         model.conv_fp8 = args.fp8
     crit = DiceLoss().to(dev)
     if args.optimizer == "ranger":  # src/definer.py:316-331 + the CLI defaults lr 1e-4, weight_decay 1e-5
@@ -252,8 +254,10 @@ def main():
     size = (args.patch,) * 3
     x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
     t = synth.nested_spheres(args.batch, size, device=dev)
-    use_amp = args.precision == "bf16"
-    train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets)
+    use_amp = args.precision != "fp32"
+    amp_dtype = torch.float16 if args.precision == "fp16" else torch.bfloat16
+    assert not (args.graph and args.precision == "fp16"), "--graph: the GradScaler's inf check reads the device every step; use bf16"
+    train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets, amp_dtype=amp_dtype)
 
     if args.graph:  # (with N > 1 the bucketed RCCL all-reduces are captured into the graph too)
         assert args.optimizer == "ranger", "--graph: ranger optimizer (capturable)"

@@ -1,4 +1,10 @@
 // Shared device/host helpers for libbrats_hip.so (gfx950 only).
+//
+// 16-bit storage comes in two flavours built from the SAME sources: every translation unit that touches 16-bit activations
+// is compiled twice -- once as is (bf16: BRATS_BF16) and once with -DBRATS_FP16 (IEEE half: BRATS_F16, the reference's own
+// autocast dtype, learning/engine.py:304), where bf16_t / bf2f / f2bf / the MFMA macros below mean fp16 and everything lives
+// in namespace brats_f16 with its extern "C" entry points renamed name##_f16 (twin_begin.hpp / twin_end.hpp).  The normal
+// entry points forward dtype == BRATS_F16 calls to their twins (BRATS_F16_FORWARD).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -7,9 +13,14 @@
 #include <type_traits>
 #include "../../include/brats_hip.h"
 
-typedef uint16_t bf16_t;  // raw bf16 storage
+typedef uint16_t bf16_t;  // raw 16-bit storage (bf16; fp16 in the -DBRATS_FP16 twin)
+#ifdef BRATS_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;  // (names kept: "the 16-bit MFMA fragment")
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -17,11 +28,22 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define DEVI __device__ __forceinline__
 
+#ifdef BRATS_FP16
+DEVI float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+DEVI bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }  // v_cvt_f16_f32 (RNE; > 65504 -> inf)
+DEVI void unpack2(uint32_t w, float& lo, float& hi) { lo = bf2f((bf16_t)(w & 0xffffu)); hi = bf2f((bf16_t)(w >> 16)); }
+#define MFMA16_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MFMA16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
 DEVI float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 DEVI bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
   return __builtin_bit_cast(bf16_t, b);
 }
+DEVI void unpack2(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+#define MFMA16_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 
 template <typename T> DEVI float to_f(T v);
 template <> DEVI float to_f<float>(float v) { return v; }
@@ -39,8 +61,8 @@ template <> struct Vec<float, 4> {
 template <> struct Vec<bf16_t, 4> {
   static DEVI void load(const bf16_t* p, float* o) {
     u32x2 v = *(const u32x2*)p;
-    o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xffff0000u);
-    o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xffff0000u);
+    unpack2(v[0], o[0], o[1]);
+    unpack2(v[1], o[2], o[3]);
   }
   static DEVI void store(bf16_t* p, const float* o) {
     u32x2 v;
@@ -53,7 +75,7 @@ template <> struct Vec<bf16_t, 8> {
   static DEVI void load(const bf16_t* p, float* o) {
     u32x4 v = *(const u32x4*)p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) unpack2(v[i], o[2 * i], o[2 * i + 1]);
   }
   static DEVI void store(bf16_t* p, const float* o) {
     u32x4 v;
@@ -66,7 +88,7 @@ template <> struct Vec<bf16_t, 8> {
   static DEVI void load_nt(const bf16_t* p, float* o) {
     u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) unpack2(v[i], o[2 * i], o[2 * i + 1]);
   }
   static DEVI void store_nt(bf16_t* p, const float* o) {
     u32x4 v;
@@ -90,16 +112,22 @@ static inline bool stream_nt(size_t bytes) { return bytes >= ((size_t)256 << 20)
 // ---- e4m3 helpers shared by the fp8 convolution (conv_igemm_f8.hpp) and the fp8 weight gradient (conv_wgrad.hip) ----
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
+#ifdef BRATS_FP16
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
+#define CVT_SCALE_PK_FP8_H __builtin_amdgcn_cvt_scalef32_pk_fp8_f16
+#else
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define CVT_SCALE_PK_FP8_H __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16
+#endif
 DEVI u32x2 f8_quant8(u32x4 v, float scale) {  // 8 bf16 -> 8 e4m3 (value / scale), channel order kept
   // the elements go through scalars first: __builtin_bit_cast applied to a vector-element lvalue (v[1]) reads element 0
   // with this hipcc
   const uint32_t e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
   s16x2 lo = {0, 0}, hi = {0, 0};
-  lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, e0), scale, false);
-  lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_bit_cast(bf16x2, e1), scale, true);
-  hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, e2), scale, false);
-  hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_bit_cast(bf16x2, e3), scale, true);
+  lo = CVT_SCALE_PK_FP8_H(lo, __builtin_bit_cast(bf16x2, e0), scale, false);
+  lo = CVT_SCALE_PK_FP8_H(lo, __builtin_bit_cast(bf16x2, e1), scale, true);
+  hi = CVT_SCALE_PK_FP8_H(hi, __builtin_bit_cast(bf16x2, e2), scale, false);
+  hi = CVT_SCALE_PK_FP8_H(hi, __builtin_bit_cast(bf16x2, e3), scale, true);
   return u32x2{__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi)};
 }
 
@@ -159,7 +187,25 @@ template <int I, int N, typename F> DEVI void static_for(F&& f) {
 }
 
 // ---- host side ------------------------------------------------------------------------------
-void brats_set_error(const char* fmt, ...);
+// entry points of the 16-bit translation units are DEFINED as BRATS_API(brats_x) = brats_x_bf16 in the normal build and
+// brats_x_f16 in the -DBRATS_FP16 twin; the public brats_x (include/brats_hip.h) is generated into twin_dispatch.cpp by
+// gen_twin_dispatch.py: it picks the build by its dtype argument (BRATS_F16 -> the twin, called with BRATS_BF16)
+#ifdef BRATS_FP16
+#define BRATS_API(name) name##_f16
+#else
+#define BRATS_API(name) name##_bf16
+#endif
+#ifdef BRATS_FP16
+}  // shared, non-twinned host helpers are declared outside namespace brats_f16
+#endif
+void brats_set_error(const char* fmt, ...);  // abi.hip
+// out[i] = sum_{b < nb} part[b * total + i] in a fixed order (bitwise reproducible reductions without float atomics);
+// implemented in dice.hip
+int brats_ordered_sum(const float* part, float* out, int nb, int total, hipStream_t st);
+int brats_ordered_sum2(const float* part, float* out1, int n1, float* out2, int nb, int total, hipStream_t st);
+#ifdef BRATS_FP16
+namespace brats_f16 {
+#endif
 #define BRATS_FAIL(code, ...) do { brats_set_error(__VA_ARGS__); return (code); } while (0)
 #define BRATS_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
   BRATS_FAIL(BRATS_E_HIP, "%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
@@ -176,7 +222,3 @@ void brats_set_error(const char* fmt, ...);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// out[i] = sum_{b < nb} part[b * total + i] in a fixed order (bitwise reproducible reductions without float atomics);
-// implemented in dice.hip
-int brats_ordered_sum(const float* part, float* out, int nb, int total, hipStream_t st);
-int brats_ordered_sum2(const float* part, float* out1, int n1, float* out2, int nb, int total, hipStream_t st);

@@ -1,5 +1,6 @@
 // explicit instantiation unit: bf16, 3x3x3, dilation 1 (see conv_igemm.hpp)
 #include <stdlib.h>
+#include "twin_begin.hpp"
 #include "conv_igemm_ld.hpp"
 template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream_t st) {
   // loader-wave kernel: brats_conv3d_chunk() hands out 16 for the Cout = 48 (mod 96) layers in mode 2 (>= 2 chunks: with a
@@ -19,3 +20,4 @@ template <> int conv_launch<bf16_t, 3, 1>(const ConvParams& p, int ck, hipStream
   }
   BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv bf16: unsupported channel chunk %d", ck);
 }
+#include "twin_end.hpp"

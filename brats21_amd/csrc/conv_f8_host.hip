@@ -1,11 +1,12 @@
 // C-ABI entry points of the fp8 (e4m3) convolution path: weight packing with per-row scales, |max| reduction,
 // forward / dgrad launch (kernels: conv_igemm_f8.hpp).
+#include "twin_begin.hpp"
 #include "conv_igemm_f8.hpp"
 
 template <> int conv_f8_launch<1>(const ConvF8Params& p, int ck, hipStream_t st);
 template <> int conv_f8_launch<2>(const ConvF8Params& p, int ck, hipStream_t st);
 
-extern "C" int brats_conv3d_f8_chunk(int c1, int c2) {
+extern "C" int BRATS_API(brats_conv3d_f8_chunk)(int c1, int c2) {
   static const int cand[] = {48, 32, 16};
   for (int i = 0; i < 3; ++i)
     if (c1 > 0 && c1 % cand[i] == 0 && (c2 <= 0 || c2 % cand[i] == 0)) return cand[i];
@@ -14,7 +15,7 @@ extern "C" int brats_conv3d_f8_chunk(int c1, int c2) {
 
 static int f8_macro_steps(int ck) { return (27 * (ck / 16) + 7) / 8; }
 
-extern "C" size_t brats_conv3d_f8_packed_bytes(int cin, int cout, int ck) {
+extern "C" size_t BRATS_API(brats_conv3d_f8_packed_bytes)(int cin, int cout, int ck) {
   if (ck <= 0 || ck % 16 || cin % ck) return 0;
   const int rows16 = ceil_div(cout, 16);
   return (size_t)rows16 * 16 * 4 + (size_t)(cin / ck) * f8_macro_steps(ck) * rows16 * 64 * 32;
@@ -71,7 +72,7 @@ __global__ void f8_pack_kernel(const float* __restrict__ w, const float* __restr
   out[idx] = __builtin_bit_cast(uint32_t, r);
 }
 
-extern "C" int brats_conv3d_f8_pack_weights(const float* w, void* packed, int mode, int cout_w, int cin_w, int cin_off,
+extern "C" int BRATS_API(brats_conv3d_f8_pack_weights)(const float* w, void* packed, int mode, int cout_w, int cin_w, int cin_off,
                                             int cin_cnt, int ck, brats_stream_t s) {
   if (!w || !packed || ck <= 0 || ck % 16) BRATS_FAIL(BRATS_E_ARG, "f8_pack_weights: bad argument");
   const int rows = mode == BRATS_PACK_FWD ? cout_w : cin_cnt;
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) absmax_kernel(const T* __restrict__ x, in
   if (threadIdx.x == 0 && __float_as_uint(red[0]) > *(volatile uint32_t*)out) atomicMax(out, __float_as_uint(red[0]));
 }
 
-extern "C" int brats_absmax(const void* x, int pitch, int dtype, size_t rows, int C, float* out, brats_stream_t s) {
+extern "C" int BRATS_API(brats_absmax)(const void* x, int pitch, int dtype, size_t rows, int C, float* out, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !out || C % vw || pitch % vw) BRATS_FAIL(BRATS_E_ARG, "absmax: C and pitch must be multiples of %d", vw);
   hipStream_t st = (hipStream_t)s;
@@ -128,7 +129,7 @@ extern "C" int brats_absmax(const void* x, int pitch, int dtype, size_t rows, in
 }
 
 // ---- forward / dgrad ---------------------------------------------------------------------------
-extern "C" int brats_conv3d_f8_fwd(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+extern "C" int BRATS_API(brats_conv3d_f8_fwd)(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
                                    const float* amax2, float xscale, const void* packed_w, const float* bias, void* y, int ypitch,
                                    void* y2, int y2pitch, int ysplit, float* stats, int dil, int N, int D, int H, int W, int cout,
                                    brats_stream_t s) {
@@ -146,7 +147,7 @@ extern "C" int brats_conv3d_f8_fwd(const void* x1, int c1, int pitch1, const flo
     if ((double)D * H * W * mp * 2 >= 2147483648.0)
       BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_f8_fwd: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
   }
-  const int ck = brats_conv3d_f8_chunk(c1, c2);
+  const int ck = BRATS_API(brats_conv3d_f8_chunk)(c1, c2);
   if (!ck) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_f8_fwd: channel counts c1=%d c2=%d must be multiples of 16", c1, c2);
   ConvF8Params pp;
   ConvParams& p = pp.c;
@@ -169,3 +170,4 @@ extern "C" int brats_conv3d_f8_fwd(const void* x1, int c1, int pitch1, const flo
   if (dil == 2) return conv_f8_launch<2>(pp, ck, (hipStream_t)s);
   BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_f8_fwd: unsupported dilation %d", dil);
 }
+#include "twin_end.hpp"

@@ -1,22 +1,12 @@
 // C-ABI entry points for the implicit-GEMM convolution: weight packing + forward/dgrad launch.
-#include <stdarg.h>
 #include <stdlib.h>
+#include "twin_begin.hpp"
 #include "conv_igemm.hpp"
-
-static thread_local char g_err[512] = "";
-void brats_set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-extern "C" const char* brats_last_error(void) { return g_err; }
-extern "C" int brats_abi_version(void) { return 1; }
 
 // ---- chunk selection ---------------------------------------------------------------------------
 int g_conv_vs8_mode = -1;
 int g_conv_ld_variant = -1;  // tuning only (scripts/time_ld.py): bits 4.. of the mode pick a template variant of conv_igemm_ld
-extern "C" int brats_conv3d_set_vs8(int mode) {
+extern "C" int BRATS_API(brats_conv3d_set_vs8)(int mode) {
   const int old = g_conv_vs8_mode;
   g_conv_vs8_mode = mode < 0 ? -1 : ((mode & 15) > 2 ? 2 : (mode & 15));  // 0 one-tile kernels, 1 conv_igemm_vs8, 2 conv_igemm_ld
   g_conv_ld_variant = mode < 0 ? -1 : (mode >> 4);
@@ -29,7 +19,7 @@ static int conv_vs8_enabled() {
   return v;
 }
 
-extern "C" int brats_conv3d_chunk(int dtype, int ksize, int dil, int c1, int c2, int cout) {
+extern "C" int BRATS_API(brats_conv3d_chunk)(int dtype, int ksize, int dil, int c1, int c2, int cout) {
   // Cout = 48 (mod 96), bf16, 3x3x3 dilation 1: 24-channel chunks for the 4x8x16-tile kernel (conv_igemm_vs8.hpp)
   if (dtype == BRATS_BF16 && ksize == 3 && dil == 1 && cout > 0 && conv_vs8_enabled() && conv_vsplit_enabled()) {
     const int rows16 = ceil_div(cout, 16);
@@ -55,7 +45,7 @@ static int macro_steps(int dtype, int ksize, int ck) {
   return (taps * ck / 4 + 3) / 4;
 }
 
-extern "C" size_t brats_conv3d_packed_bytes(int dtype, int ksize, int cin, int cout, int ck) {
+extern "C" size_t BRATS_API(brats_conv3d_packed_bytes)(int dtype, int ksize, int cin, int cout, int ck) {
   if (ck <= 0 || cin % ck) return 0;
   const int rows16 = ceil_div(cout, 16);
   return (size_t)(cin / ck) * macro_steps(dtype, ksize, ck) * rows16 * 64 * 16;
@@ -99,7 +89,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   out[idx] = from_f<T>(val);
 }
 
-extern "C" int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize,
+extern "C" int BRATS_API(brats_conv3d_pack_weights)(const float* w, void* packed, int dtype, int mode, int ksize,
                                          int cout_w, int cin_w, int cin_off, int cin_cnt, int ck,
                                          brats_stream_t s) {
   if (!w || !packed || (ksize != 1 && ksize != 3) || ck <= 0) BRATS_FAIL(BRATS_E_ARG, "pack_weights: bad argument");
@@ -189,8 +179,8 @@ __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const brats_pac
       if (base + i < J.total) pack_one<float>(J, base + i);
   }
 }
-extern "C" int brats_conv3d_pack_block(void) { return PACK_BLOCK; }
-extern "C" int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* blocks, int nblocks, brats_stream_t s) {
+extern "C" int BRATS_API(brats_conv3d_pack_block)(void) { return PACK_BLOCK; }
+extern "C" int BRATS_API(brats_conv3d_pack_weights_multi)(const brats_pack_job* jobs, const int* blocks, int nblocks, brats_stream_t s) {
   if (!jobs || !blocks || nblocks <= 0) BRATS_FAIL(BRATS_E_ARG, "pack_weights_multi: empty job / block table");
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)s, jobs, blocks);
   BRATS_CHECK_LAUNCH();
@@ -198,13 +188,13 @@ extern "C" int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const
 }
 
 // ---- forward / dgrad ---------------------------------------------------------------------------
-extern "C" int brats_conv3d_split_granule(int cout) { return conv_choose_tile(ceil_div(cout, 16)).nf * 16; }
+extern "C" int BRATS_API(brats_conv3d_split_granule)(int cout) { return conv_choose_tile(ceil_div(cout, 16)).nf * 16; }
 
-extern "C" int brats_conv3d_tiles_per_sample(int D, int H, int W) {
+extern "C" int BRATS_API(brats_conv3d_tiles_per_sample)(int D, int H, int W) {
   return ceil_div(D, CONV_TZ) * ceil_div(H, CONV_TY) * ceil_div(W, CONV_TX);
 }
 
-extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
+extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
                                 const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
                                 int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
                                 int cout, brats_stream_t s) {
@@ -221,7 +211,7 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
     if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
       BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
   }
-  const int ck = brats_conv3d_chunk(dtype, ksize, dil, c1, c2, cout);
+  const int ck = BRATS_API(brats_conv3d_chunk)(dtype, ksize, dil, c1, c2, cout);
   if (!ck) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: no channel chunk divides c1=%d c2=%d", c1, c2);
   ConvParams p;
   p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
@@ -245,7 +235,10 @@ extern "C" int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* 
   if (ksize == 3 && dil == 2) return conv_launch<T, 3, 2>(p, ck, st); \
   if (ksize == 1) return conv_launch<T, 1, 1>(p, ck, st);
   if (dtype == BRATS_BF16) { GO(bf16_t) }
+#ifndef BRATS_FP16  // (the f32 kernels live in translation units of their own that are not built twice)
   else if (dtype == BRATS_F32) { GO(float) }
+#endif
 #undef GO
   BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: unsupported dtype=%d ksize=%d dilation=%d", dtype, ksize, dil);
 }
+#include "twin_end.hpp"

@@ -136,7 +136,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       for (int i = YB * half; i < YB * half + YB; ++i)
 #pragma unroll
         for (int f = 0; f < NF; ++f)
-          acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[i], acc[f][i], 0, 0, 0);
+          acc[f][i] = MFMA16_16x16x32(a[k % (WD + 1)][f], b[i], acc[f][i]);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;

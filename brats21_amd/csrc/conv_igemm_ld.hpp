@@ -68,7 +68,7 @@ DEVI void conv_mma_ring(const char* ldsb, int lane_b, int q, const void* wpk_chu
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int f = 0; f < NF; ++f)
-      acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k % (WD + 1)][f], b[j % RB], acc[f][i], 0, 0, 0);
+      acc[f][i] = MFMA16_16x16x32(a[k % (WD + 1)][f], b[j % RB], acc[f][i]);
     __builtin_amdgcn_sched_barrier(0);
   });
 }

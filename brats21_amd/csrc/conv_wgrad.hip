@@ -11,6 +11,7 @@
 // Split-K over workgroups writes f32 slabs ws[split][tap][co][ci]; a second kernel reduces them in a
 // fixed order (bitwise reproducible, no float atomics) into torch's [co][ci][tap] layout.
 #include <stdlib.h>
+#include "twin_begin.hpp"
 #include "common.hpp"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < COF; ++m)
-          acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
+          acc[jj][m] = MFMA16_16x16x32(a[s & 1][m], b[u % (PD + 1)], acc[jj][m]);
         __builtin_amdgcn_sched_barrier(0);
       });
     } else {
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < 3; ++m)
-        acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
+        acc[jj][m] = MFMA16_16x16x32(a[s & 1][m], b[u % (PD + 1)], acc[jj][m]);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m = 0; m < COF; ++m)
-        acc[jj][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s & 1][m], b[u % (PD + 1)], acc[jj][m], 0, 0, 0);
+        acc[jj][m] = MFMA16_16x16x32(a[s & 1][m], b[u % (PD + 1)], acc[jj][m]);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
@@ -1027,13 +1028,13 @@ static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int n
   if (wide_out) *wide_out = wide ? 1 : 0;
   return true;
 }
-extern "C" int brats_conv3d_set_wgrad_alltaps(int mode) {
+extern "C" int BRATS_API(brats_conv3d_set_wgrad_alltaps)(int mode) {
   const int old = g_wgrad_alltaps_mode;
   g_wgrad_alltaps_mode = mode < 0 ? -1 : (mode ? 1 : 0);
   return old;
 }
 
-extern "C" size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout) {
+extern "C" size_t BRATS_API(brats_conv3d_wgrad_ws_bytes)(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout) {
   if (ksize != 3) return 0;
   int cof, cif;
   wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
@@ -1067,7 +1068,7 @@ static int wgrad_dispatch(const WgradParams& p, int cof, int cif, dim3 grid, hip
   BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: unsupported tile %dx%d", cof, cif);
 }
 
-extern "C" int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy,
+extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy,
                                   int dypitch, float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N,
                                   int D, int H, int W, int cout, brats_stream_t s) {
   if (!x1 || !dy || !ws || !dw || c1 <= 0 || cout <= 0) BRATS_FAIL(BRATS_E_ARG, "wgrad: null pointer / bad size");
@@ -1164,7 +1165,7 @@ static int wgrad_shift_geometry(int dtype, int ksize, int N, int D, int H, int W
   return 0;
 }
 
-extern "C" size_t brats_conv3d_wgrad_shift_ws_bytes(int dtype, int ksize, int N, int D, int H, int W, int cin, int cout) {
+extern "C" size_t BRATS_API(brats_conv3d_wgrad_shift_ws_bytes)(int dtype, int ksize, int N, int D, int H, int W, int cin, int cout) {
   if (ksize != 1 && ksize != 3) return 0;
   WgradParams p;
   int cof, cif, cot, cit;
@@ -1172,7 +1173,7 @@ extern "C" size_t brats_conv3d_wgrad_shift_ws_bytes(int dtype, int ksize, int N,
   return (size_t)p.nsplit * p.ntaps * cout * cin * sizeof(float);
 }
 
-extern "C" int brats_conv3d_wgrad_shift(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
+extern "C" int BRATS_API(brats_conv3d_wgrad_shift)(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
                                         float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                                         brats_stream_t s) {
   if (!x || !dy || !ws || !dw || cin <= 0 || cout <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0)
@@ -1236,7 +1237,7 @@ static bool wgrad_f8_shape(int N, int D, int H, int W, int c1, int c2, int cout,
   return true;
 }
 
-extern "C" size_t brats_conv3d_wgrad_f8_ws_bytes(int N, int D, int H, int W, int c1, int c2, int cout) {
+extern "C" size_t BRATS_API(brats_conv3d_wgrad_f8_ws_bytes)(int N, int D, int H, int W, int c1, int c2, int cout) {
   int cof, cif, g8, nl, nt;
   if (!wgrad_f8_shape(N, D, H, W, c1, c2, cout, &cof, &cif, &g8, &nl, &nt)) return 0;  // 0 = not supported: use brats_conv3d_wgrad
   return (size_t)nl * g8 * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
@@ -1253,7 +1254,7 @@ static int wgrad_f8_launch(const WgradF8Params& pp, hipStream_t st) {
   return 0;
 }
 
-extern "C" int brats_conv3d_wgrad_f8(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+extern "C" int BRATS_API(brats_conv3d_wgrad_f8)(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
                                      const float* amax2, const void* dy, int dypitch, const float* amax_dy, float* ws, float* dw,
                                      int N, int D, int H, int W, int cout, brats_stream_t s) {
   if (!x1 || !dy || !ws || !dw || !amax1 || !amax_dy || c1 <= 0 || cout <= 0) BRATS_FAIL(BRATS_E_ARG, "wgrad_f8: null pointer / bad size");
@@ -1288,3 +1289,4 @@ extern "C" int brats_conv3d_wgrad_f8(const void* x1, int c1, int pitch1, const f
   BRATS_CHECK_LAUNCH();
   return 0;
 }
+#include "twin_end.hpp"

@@ -16,6 +16,7 @@
 // Workgroup = 4 waves, wave = NF row-fragments (32 output channels each) x NB voxel-fragments (32 voxels each);
 // the (tap, 16-channel step) loop is flattened and software-pipelined three steps deep.
 // f32 (parity mode): v_mfma_f32_32x32x2_f32, a 16-byte load = 4 channels = 4 MFMA k-steps.
+#include "twin_begin.hpp"
 #include "common.hpp"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(const DconvParams p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           if constexpr (std::is_same<T, bf16_t>::value) {
-            acc[f][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[st][f], B[st][b], acc[f][b], 0, 0, 0);
+            acc[f][b] = MFMA16_32x32x16(A[st][f], B[st][b], acc[f][b]);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[f][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st][f][j], B[st][b][j], acc[f][b], 0, 0, 0);
@@ -190,13 +191,13 @@ __global__ void dconv_pack_kernel(const float* __restrict__ w, T* __restrict__ o
 
 static int dconv_kch(int dtype) { return dtype == BRATS_BF16 ? 16 : 8; }
 
-extern "C" size_t brats_dconv_packed_bytes(int dtype, int ksize, int kdim, int rows) {
+extern "C" size_t BRATS_API(brats_dconv_packed_bytes)(int dtype, int ksize, int kdim, int rows) {
   const int kch = dconv_kch(dtype);
   if (kdim <= 0 || kdim % kch || rows <= 0 || (ksize != 1 && ksize != 3)) return 0;
   return (size_t)ksize * ksize * ksize * (kdim / kch) * ceil_div(rows, 32) * 1024;
 }
 
-extern "C" int brats_dconv_pack_weights(const float* w, void* packed, int dtype, int mode, int ksize, int cout_w, int cin_w,
+extern "C" int BRATS_API(brats_dconv_pack_weights)(const float* w, void* packed, int dtype, int mode, int ksize, int cout_w, int cin_w,
                                         int cin_off, int cin_cnt, brats_stream_t s) {
   if (!w || !packed || (ksize != 1 && ksize != 3)) BRATS_FAIL(BRATS_E_ARG, "dconv_pack_weights: bad argument");
   const int taps = ksize * ksize * ksize;
@@ -217,7 +218,7 @@ extern "C" int brats_dconv_pack_weights(const float* w, void* packed, int dtype,
   return 0;
 }
 
-extern "C" int brats_dconv_run(const brats_dconv_job* jobs, int njobs, int dtype, int N, int D, int H, int W, brats_stream_t s) {
+extern "C" int BRATS_API(brats_dconv_run)(const brats_dconv_job* jobs, int njobs, int dtype, int N, int D, int H, int W, brats_stream_t s) {
   if (!jobs || njobs < 1 || njobs > 4 || N <= 0 || D <= 0 || H <= 0 || W <= 0) BRATS_FAIL(BRATS_E_ARG, "dconv_run: bad argument");
   if (dtype != BRATS_BF16 && dtype != BRATS_F32) BRATS_FAIL(BRATS_E_UNSUPPORTED, "dconv_run: dtype %d", dtype);
   const int kch = dconv_kch(dtype), esz = dtype == BRATS_BF16 ? 2 : 4, align = 16 / esz;
@@ -250,3 +251,4 @@ extern "C" int brats_dconv_run(const brats_dconv_job* jobs, int njobs, int dtype
   BRATS_CHECK_LAUNCH();
   return 0;
 }
+#include "twin_end.hpp"

@@ -2,6 +2,7 @@
 // full resolution, emitted as NCDHW f32 logits for the PyTorch Dice loss (learning/engine.py:312-333).
 // Reference: conv1x1 networks/equiunet2020.py:37-41 (outconv :441, deep heads :443-458).
 // Pure HBM-bound kernels (AI <= 3 FLOP/B): no MFMA on purpose.
+#include "twin_begin.hpp"
 #include "common.hpp"
 
 int brats_lerp_adjoint_f32_planes(const float* in, float* out, size_t outer, int Lout, int Lin, size_t inner, hipStream_t st);
@@ -108,8 +109,8 @@ __global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __res
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int part = 2; part >= 0; --part) {  // small terms first
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[part][0], xb0[i], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[part][1], xb1[i], acc, 0, 0, 0);
+        acc = MFMA16_16x16x32(wa[part][0], xb0[i], acc);
+        acc = MFMA16_16x16x32(wa[part][1], xb1[i], acc);
       }
       const size_t vv = v0 + 16 * i + v;
       if (q == 0 && vv < voxels) {
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) upsample_planes_kernel(const float* __res
   }
 }
 
-extern "C" int brats_head_fwd(const void* x, int xpitch, const float* w, const float* b, float* lowres, float* out,
+extern "C" int BRATS_API(brats_head_fwd)(const void* x, int xpitch, const float* w, const float* b, float* lowres, float* out,
                               int dtype, int N, int C, int K, int D, int H, int W, int scale, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !w || !out || K < 1 || K > HEAD_KMAX || C % vw || xpitch % vw || scale < 1)
@@ -302,11 +303,11 @@ static size_t head_lerp_floats(int N, int K, int D, int H, int W, int scale) {
   return dlow + t1 + t2;
 }
 // workspace = up-sampling adjoint temporaries (scale > 1) + per-block partial sums of dw / db + the [K*C + K] totals
-extern "C" size_t brats_head_bwd_ws_bytes(int N, int C, int K, int D, int H, int W, int scale) {
+extern "C" size_t BRATS_API(brats_head_bwd_ws_bytes)(int N, int C, int K, int D, int H, int W, int scale) {
   return (head_lerp_floats(N, K, D, H, W, scale) + (size_t)(N * HEAD_MAX_BLOCKS + 1) * (K * C + K)) * sizeof(float);
 }
 
-extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const float* dout, float* ws, void* dx, int dxpitch,
+extern "C" int BRATS_API(brats_head_bwd)(const void* x, int xpitch, const float* w, const float* dout, float* ws, void* dx, int dxpitch,
                               float* dw, float* db, int dtype, int N, int C, int K, int D, int H, int W, int scale,
                               brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
@@ -344,3 +345,4 @@ extern "C" int brats_head_bwd(const void* x, int xpitch, const float* w, const f
   BRATS_CHECK_LAUNCH();
   return 0;
 }
+#include "twin_end.hpp"

@@ -1,4 +1,5 @@
 // NCDHW f32 (the reference's tensor layout, learning/engine.py:89-90) <-> NDHWC (library layout).
+#include "twin_begin.hpp"
 #include "common.hpp"
 
 template <typename T>
@@ -27,7 +28,7 @@ static inline int lgrid(size_t total) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-extern "C" int brats_ncdhw_to_ndhwc(const float* src, void* dst, int dtype, int N, int C, int cpad, int dst_pitch, int D,
+extern "C" int BRATS_API(brats_ncdhw_to_ndhwc)(const float* src, void* dst, int dtype, int N, int C, int cpad, int dst_pitch, int D,
                                     int H, int W, brats_stream_t s) {
   if (!src || !dst || cpad < C || dst_pitch < cpad) BRATS_FAIL(BRATS_E_ARG, "ncdhw_to_ndhwc: bad argument");
   const size_t vox = (size_t)D * H * W;
@@ -40,7 +41,7 @@ extern "C" int brats_ncdhw_to_ndhwc(const float* src, void* dst, int dtype, int 
   return 0;
 }
 
-extern "C" int brats_ndhwc_to_ncdhw(const void* src, int src_pitch, float* dst, int dtype, int N, int C, int D, int H, int W,
+extern "C" int BRATS_API(brats_ndhwc_to_ncdhw)(const void* src, int src_pitch, float* dst, int dtype, int N, int C, int D, int H, int W,
                                     brats_stream_t s) {
   if (!src || !dst || src_pitch < C) BRATS_FAIL(BRATS_E_ARG, "ndhwc_to_ncdhw: bad argument");
   const size_t vox = (size_t)D * H * W;
@@ -52,3 +53,4 @@ extern "C" int brats_ndhwc_to_ncdhw(const void* src, int src_pitch, float* dst, 
   BRATS_CHECK_LAUNCH();
   return 0;
 }
+#include "twin_end.hpp"

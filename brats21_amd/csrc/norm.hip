@@ -3,6 +3,7 @@
 // Reference semantics: nn.GroupNorm(8, C) networks/factory.py:179-182 (biased var, eps 1e-5),
 // activations networks/factory.py:195-200; EvoNorm3D S0 networks/equiunet2021.py:95-103 (unbiased
 // group variance, x*sigmoid(x) numerator).
+#include "twin_begin.hpp"
 #include "common.hpp"
 
 // ---- statistics finalize ---------------------------------------------------------------------------
@@ -107,9 +108,9 @@ __global__ void gn_finalize_kernel(double* __restrict__ chan, int splits, int N,
   }
 }
 
-extern "C" size_t brats_gn_ws_doubles(int N, int C) { return (size_t)(1 + GN_MAX_SPLITS) * N * C * 2; }
+extern "C" size_t BRATS_API(brats_gn_ws_doubles)(int N, int C) { return (size_t)(1 + GN_MAX_SPLITS) * N * C * 2; }
 
-extern "C" int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
+extern "C" int BRATS_API(brats_gn_finalize)(const float* stats, int tiles_per_sample, int N, int C, int groups,
                                  double count_per_channel, float eps, const float* gamma, const float* beta,
                                  float* mean_rstd, float* scale_shift, double* chan_ws, brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
@@ -243,7 +244,7 @@ static inline int stream_grid(size_t total, int block) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-extern "C" int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
+extern "C" int BRATS_API(brats_affine_act_fwd)(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
                                     int dtype, int act, float slope_value, const float* slope_dev, int N, int voxels, int C,
                                     float* amax, brats_stream_t s) {
   const SlopeArg slope{slope_value, slope_dev};
@@ -477,9 +478,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 }
 
 constexpr int GN_BWD_MAX_BLOCKS = 2048;
-extern "C" size_t brats_gn_bwd_ws_floats(int N, int C) { return (size_t)(1 + GN_BWD_MAX_BLOCKS) * N * C * 2; }
+extern "C" size_t BRATS_API(brats_gn_bwd_ws_floats)(int N, int C) { return (size_t)(1 + GN_BWD_MAX_BLOCKS) * N * C * 2; }
 
-extern "C" int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
+extern "C" int BRATS_API(brats_gn_act_bwd)(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                                 const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red,
                                 float* dgamma, float* dbeta, int dtype, int act, float slope_value, const float* slope_dev,
                                 int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
@@ -586,8 +587,8 @@ __global__ void __launch_bounds__(256) prelu_slope_grad_kernel(const T* __restri
 }
 
 constexpr int PRELU_MAX_BLOCKS = 1024;
-extern "C" size_t brats_prelu_ws_floats(int N) { return (size_t)N * PRELU_MAX_BLOCKS; }
-extern "C" int brats_prelu_slope_grad(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift, float* ws,
+extern "C" size_t BRATS_API(brats_prelu_ws_floats)(int N) { return (size_t)N * PRELU_MAX_BLOCKS; }
+extern "C" int BRATS_API(brats_prelu_slope_grad)(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift, float* ws,
                                       float* dslope, int dtype, int N, int voxels, int C, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !y || !scale_shift || !ws || !dslope || C % vw || dzpitch % vw || ypitch % vw || C / vw > 256)
@@ -606,7 +607,7 @@ extern "C" int brats_prelu_slope_grad(const void* dz, int dzpitch, const void* y
   return brats_ordered_sum(ws, dslope, N * (int)gx, 1, st);
 }
 
-extern "C" int brats_evonorm_finalize(const float* stats, int tiles_per_sample, int N, int C, int groups,
+extern "C" int BRATS_API(brats_evonorm_finalize)(const float* stats, int tiles_per_sample, int N, int C, int groups,
                                       double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
                                       brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "evonorm_finalize: bad argument");
@@ -679,9 +680,9 @@ __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const fl
 // per-(n, channel) sums over voxels are produced as per-block partials [blocks][N][C*vals] after the [N][C*vals] totals and
 // added in block order (brats_ordered_sum): no float atomics, bitwise reproducible
 constexpr int CHAN_MAX_BLOCKS = 1024;
-extern "C" size_t brats_chan_ws_floats(int N, int C, int vals) { return (size_t)(1 + CHAN_MAX_BLOCKS) * N * C * vals; }
+extern "C" size_t BRATS_API(brats_chan_ws_floats)(int N, int C, int vals) { return (size_t)(1 + CHAN_MAX_BLOCKS) * N * C * vals; }
 
-extern "C" int brats_evonorm_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
+extern "C" int BRATS_API(brats_evonorm_fwd)(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
                                  void* z, int zpitch, float* chansum, int dtype, int N, int voxels, int C, int groups,
                                  float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
@@ -868,7 +869,7 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
   if (amax) record_absmax<T>(mx, amax);
 }
 
-extern "C" int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
+extern "C" int BRATS_API(brats_evonorm_bwd)(const void* dz, int dzpitch, const void* x, int xpitch, const float* mean_rstd,
                                  const float* gamma, void* dx, int dxpitch, float* red, float* dgamma, float* dbeta,
                                  const double* chan_sums, float* dconvbias, int dtype, int N, int voxels, int C, int groups,
                                  float* amax, const float* gscale, const float* gadd, brats_stream_t s) {
@@ -977,7 +978,7 @@ __global__ void channel_dot_kernel(const T* __restrict__ a, int apitch, const T*
   }
 }
 
-extern "C" int brats_channel_dot(const void* a, int apitch, const void* b, int bpitch, float* out, int dtype, int N, int voxels,
+extern "C" int BRATS_API(brats_channel_dot)(const void* a, int apitch, const void* b, int bpitch, float* out, int dtype, int N, int voxels,
                                  int C, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!a || !out || C % vw || apitch % vw || (b && bpitch % vw) || C / vw > 256) BRATS_FAIL(BRATS_E_ARG, "channel_dot: bad argument");
@@ -1049,7 +1050,7 @@ __global__ void channel_scale_kernel(const T* __restrict__ a, int apitch, const 
   if (amax) record_absmax<T>(mx, amax);
 }
 
-extern "C" int brats_channel_scale(const void* a, int apitch, const float* scale, const float* add, void* dst, int dpitch,
+extern "C" int BRATS_API(brats_channel_scale)(const void* a, int apitch, const float* scale, const float* add, void* dst, int dpitch,
                                    int dtype, int N, int voxels, int C, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!a || !scale || !dst || C % vw || apitch % vw || dpitch % vw) BRATS_FAIL(BRATS_E_ARG, "channel_scale: bad argument");
@@ -1067,3 +1068,4 @@ extern "C" int brats_channel_scale(const void* a, int apitch, const float* scale
   BRATS_CHECK_LAUNCH();
   return 0;
 }
+#include "twin_end.hpp"

@@ -2,6 +2,7 @@
 // All HBM-bound: 16-byte channel vectors per thread, coalesced along the channel-minor layout.
 // Reference: nn.MaxPool3d(2,2) networks/equiunet2020.py:433; MONAI MaxAvgPool networks/equiunet2021.py:261
 // (cat([max, avg], dim=1)); nn.Upsample(trilinear, align_corners=True) networks/equiunet2020.py:439.
+#include "twin_begin.hpp"
 #include "common.hpp"
 
 static inline int stream_grid(size_t total, int block) {
@@ -101,7 +102,7 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xpitch, const T
   }
 }
 
-extern "C" int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
+extern "C" int BRATS_API(brats_maxpool2_fwd)(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
                                   int W, int with_avg, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !y || C % vw || xpitch % vw || ypitch % vw || (D | H | W) & 1)
@@ -117,7 +118,7 @@ extern "C" int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch
   return 0;
 }
 
-extern "C" int brats_maxpool2_bwd(const void* x, int xpitch, const void* y, int ypitch, const void* dy, int dypitch,
+extern "C" int BRATS_API(brats_maxpool2_bwd)(const void* x, int xpitch, const void* y, int ypitch, const void* dy, int dypitch,
                                   const void* dx_skip, int dxskip_pitch, void* dx, int dxpitch, int dtype, int N, int C,
                                   int D, int H, int W, int with_avg, brats_stream_t s) {
   (void)y; (void)ypitch;  // arg-max is recomputed from x
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(256) upsample2_fwd_kernel(const T* __restrict_
   }
 }
 
-extern "C" int brats_upsample_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
+extern "C" int BRATS_API(brats_upsample_fwd)(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
                                   int W, int scale, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !y || C % vw || xpitch % vw || ypitch % vw || scale < 1)
@@ -406,7 +407,7 @@ int brats_lerp_adjoint_f32_planes(const float* in, float* out, size_t outer, int
   return 0;
 }
 
-extern "C" size_t brats_upsample_bwd_ws_bytes(int dtype, int N, int C, int D, int H, int W, int scale) {
+extern "C" size_t BRATS_API(brats_upsample_bwd_ws_bytes)(int dtype, int N, int C, int D, int H, int W, int scale) {
   const size_t esz = dtype == BRATS_BF16 ? 2 : 4;
   const size_t a = (size_t)N * D * (H * scale) * (W * scale) * C;  // after the D pass
   const size_t b = (size_t)N * D * H * (W * scale) * C;            // after the H pass
@@ -437,7 +438,7 @@ static int upsample_bwd_t(const T* dy, int dypitch, T* dx, int dxpitch, char* tm
   return 0;
 }
 
-extern "C" int brats_upsample_bwd(const void* dy, int dypitch, void* dx, int dxpitch, void* tmp, int dtype, int N, int C,
+extern "C" int BRATS_API(brats_upsample_bwd)(const void* dy, int dypitch, void* dx, int dxpitch, void* tmp, int dtype, int N, int C,
                                   int D, int H, int W, int scale, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dy || !dx || !tmp || C % vw || dypitch % vw || dxpitch % vw) BRATS_FAIL(BRATS_E_ARG, "upsample_bwd: bad argument");
@@ -447,3 +448,4 @@ extern "C" int brats_upsample_bwd(const void* dy, int dypitch, void* dx, int dxp
   return upsample_bwd_t<float>((const float*)dy, dypitch, (float*)dx, dxpitch, (char*)tmp, N, C, D, H, W, scale,
                                (hipStream_t)s);
 }
+#include "twin_end.hpp"

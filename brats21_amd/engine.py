@@ -13,15 +13,23 @@ class TrainStep:
     """One training iteration: zero_grad -> autocast forward -> deep-supervision Dice -> backward ->
     [bucketed gradient all-reduce] -> [clip] -> optimizer step.
 
-    amp=True is the reference's default (``--no_amp`` off): bf16 MFMA kernels under autocast; bf16 needs no
-    GradScaler (the reference's fp16 scaler, learning/engine.py:117-122, has nothing to scale here).
+    amp=True is the reference's default (``--no_amp`` off).  ``amp_dtype``:
+      * torch.bfloat16 (default): bf16 MFMA kernels under autocast; bf16 needs no GradScaler;
+      * torch.float16: the reference's own arithmetic (autocast fp16 + GradScaler, learning/engine.py:304,117-122,
+        src/main_train.py:110): fp16 MFMA kernels (same rate, three more mantissa bits), the loss is scaled before
+        backward, gradients are unscaled / checked for inf and the step is skipped on overflow by ``scaler``
+        (a torch.amp.GradScaler, created here when none is passed) exactly as in the reference's loop.
     ``buckets`` is a brats21_amd.ddp.GradientBuckets when world_size > 1."""
 
     def __init__(self, model, optimizer, criterion=None, amp=True, buckets=None, fused_dice=True, jaccard=False,
-                 max_grad_norm=None):
+                 max_grad_norm=None, amp_dtype=torch.bfloat16, scaler=None):
         self.model, self.optimizer, self.amp, self.buckets = model, optimizer, amp, buckets
         self.fused, self.jaccard, self.max_grad_norm = fused_dice and criterion is None, jaccard, max_grad_norm
         self.criterion = criterion if criterion is not None else DiceLoss(jaccard=jaccard)
+        self.amp_dtype = amp_dtype
+        self.scaler = scaler
+        if amp and amp_dtype == torch.float16 and scaler is None:
+            self.scaler = torch.amp.GradScaler("cuda")  # src/main_train.py:110
 
     def loss(self, outputs, target):
         """Engine._compute_loss (learning/engine.py:312-333): mean of the criterion over main + deep heads."""
@@ -31,9 +39,19 @@ class TrainStep:
 
     def __call__(self, image, target):
         self.model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+        with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp):
             outputs = self.model(image)
             loss = self.loss(outputs, target)
+        if self.scaler is not None and self.amp:  # learning/engine.py:117-122
+            self.scaler.scale(loss).backward()
+            if self.buckets is not None:
+                self.buckets.finish()
+            if self.max_grad_norm is not None:  # Engine._unscale_and_clip (learning/engine.py:442-452)
+                self.scaler.unscale_(self.optimizer)
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+            return loss
         loss.backward()
         if self.buckets is not None:
             self.buckets.finish()

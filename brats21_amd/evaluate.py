@@ -126,10 +126,10 @@ class Evaluator:
     it runs eagerly unless use_graph=True is passed explicitly (then at most ``max_graphs`` shapes stay captured)."""
 
     def __init__(self, models, tta_transforms=None, sliding_window_size=None, sw_batch_size=1, overlap=0.25,
-                 k_divisible=8, thresh=0.5, amp=True, use_graph=None, max_graphs=4):
+                 k_divisible=8, thresh=0.5, amp=True, use_graph=None, max_graphs=4, amp_dtype=torch.bfloat16):
         self.models = list(models) if isinstance(models, (list, tuple)) else [models]
         self.tta, self.roi, self.swb, self.overlap = tta_transforms, sliding_window_size, sw_batch_size, overlap
-        self.k, self.thresh, self.amp = k_divisible, thresh, amp
+        self.k, self.thresh, self.amp, self.amp_dtype = k_divisible, thresh, amp, amp_dtype
         if use_graph is None:
             use_graph = sliding_window_size is not None
         self.predictors = [GraphedPredictor(self._amp(m), modules=m, max_graphs=max_graphs) if use_graph else self._amp(m)
@@ -137,7 +137,7 @@ class Evaluator:
 
     def _amp(self, model):
         def run(x):
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+            with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp):
                 return model(x)
         return run
 

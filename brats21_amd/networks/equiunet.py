@@ -111,7 +111,7 @@ def _inherit_amax(dst, src):
 
 
 def _f8_ok(fp8, dtype, x, x2=None):
-    return bool(fp8) and dtype == torch.bfloat16 and ops.conv_f8_chunk(x.shape[-1], x2.shape[-1] if x2 is not None else 0) > 0
+    return bool(fp8) and ops.is16(dtype) and ops.conv_f8_chunk(x.shape[-1], x2.shape[-1] if x2 is not None else 0) > 0
 
 
 def _unit_act(unit, act):
@@ -153,11 +153,11 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     the layer input recorded in the forward pass)."""
     unit, x, x2, y, mean_rstd, scale_shift = rec
     cin = unit.conv.weight.shape[1]
-    all8 = fp8 == "all" and dtype == torch.bfloat16
+    all8 = fp8 == "all" and ops.is16(dtype)
     f8 = all8 and need_dx and ops.conv_f8_chunk(y.shape[-1]) > 0
     # e4m3 weight gradient: where the all-taps kernel is built for the layer and the producers of x (x2) recorded |max|
     ax, ax2 = getattr(x, "_amax", None), (getattr(x2, "_amax", None) if x2 is not None else None)
-    w8 = (all8 and unit.dilation == 1 and ax is not None and (x2 is None or ax2 is not None) and y.dtype == torch.bfloat16
+    w8 = (all8 and unit.dilation == 1 and ax is not None and (x2 is None or ax2 is not None) and ops.is16(y.dtype)
           and ops.conv3d_wgrad_f8_ok(x, y, x2))
     amax = slots.take() if ((f8 or w8) and slots is not None) else None
     kact, slope_t = _unit_act(unit, act)
@@ -229,7 +229,7 @@ class _EquiUnetFn(torch.autograd.Function):
         dev = x.device
         tape = []
 
-        fp8 = m.conv_fp8 if dtype == torch.bfloat16 else None
+        fp8 = m.conv_fp8 if ops.is16(dtype) else None
         slots = _AmaxSlots(32, dev) if fp8 else None
 
         def cgr(unit, xin, x2=None):
@@ -243,7 +243,7 @@ class _EquiUnetFn(torch.autograd.Function):
         def up(t):
             return _inherit_amax(ops.upsample(t, 2), t)
 
-        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
+        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if ops.is16(dtype) else 4)
         # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
         # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
         down1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0))
@@ -278,7 +278,7 @@ class _EquiUnetFn(torch.autograd.Function):
         down1, down2, down3, down4, bottom, bottom_2, up3, up2, up1 = ctx.bufs
         rec = {r[0]: r for r in tape}
 
-        fp8 = m.conv_fp8 if dtype == torch.bfloat16 else None
+        fp8 = m.conv_fp8 if ops.is16(dtype) else None
         slots = _AmaxSlots(32, douts[0].device) if fp8 == "all" else None
 
         # weight gradients on a side stream (model.wgrad_stream); with gradient buckets they stay on the main stream: the
@@ -393,9 +393,13 @@ class EquiUnet(_PackedWeightsModule):
     def _dtype(self):
         if self.precision == "bf16":
             return torch.bfloat16
+        if self.precision == "fp16":
+            return torch.float16
         if self.precision == "fp32":
             return torch.float32
-        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if torch.is_autocast_enabled():  # the reference's switch (learning/engine.py:304): its autocast dtype is fp16
+            return torch.float16 if torch.get_autocast_dtype("cuda") == torch.float16 else torch.bfloat16
+        return torch.float32
 
     def forward(self, x):
         if not x.is_cuda:

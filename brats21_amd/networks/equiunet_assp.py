@@ -81,7 +81,7 @@ class _Ctx:
         self.m, self.dtype = model, dtype
         # e4m3 convolutions (EquiUnet.conv_fp8 semantics): the EvoNorm / SE kernels record the |max| of what they write
         # into slots taken here; a tensor without a recorded |max| falls back to ops.absmax inside ops.conv3d_f8
-        self.fp8 = getattr(model, "conv_fp8", None) if dtype == torch.bfloat16 else None
+        self.fp8 = getattr(model, "conv_fp8", None) if ops.is16(dtype) else None
         self.slots = None
         self.names = {p: i for i, p in enumerate(model.parameters())}
         self.grads = {}
@@ -255,7 +255,7 @@ class _AsspFn(torch.autograd.Function):
         n, _, d, h, w = x.shape
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
-        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if dtype == torch.bfloat16 else 4)
+        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if ops.is16(dtype) else 4)
         def pool(t):  # max and average of a 2x2x2 cell never exceed the |max| of the input
             return _inherit_amax(ops.maxpool2(t, with_avg=True), t)
 
@@ -391,9 +391,13 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
     def _dtype(self):
         if self.precision == "bf16":
             return torch.bfloat16
+        if self.precision == "fp16":
+            return torch.float16
         if self.precision == "fp32":
             return torch.float32
-        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if torch.is_autocast_enabled():  # the reference's switch (learning/engine.py:304): its autocast dtype is fp16
+            return torch.float16 if torch.get_autocast_dtype("cuda") == torch.float16 else torch.bfloat16
+        return torch.float32
 
     def forward(self, x):
         if not x.is_cuda:

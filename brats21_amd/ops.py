@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F32, PACK_DGRAD, PACK_FWD  # noqa: F401
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F16, F32, PACK_DGRAD, PACK_FWD  # noqa: F401
 
 ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "leakyrelu": ACT_LEAKY, "elu": _lib.ACT_ELU, "swish": _lib.ACT_SWISH,
         "mish": _lib.ACT_MISH}
@@ -111,7 +111,19 @@ def _code(dtype):
         return BF16
     if dtype == torch.float32:
         return F32
+    if dtype == torch.float16:
+        return F16
     raise _lib.BratsHipError(f"unsupported activation dtype {dtype}")
+
+
+def is16(dtype):
+    """16-bit storage (bf16 or fp16): the MFMA kernels with f32 accumulation; fp16 is the reference's autocast dtype."""
+    return dtype in (torch.bfloat16, torch.float16)
+
+
+def _fn16(name, dtype):
+    """Entry points that move 16-bit data but have no dtype argument exist twice: brats_x (bf16) and brats_x_f16."""
+    return getattr(_lib.lib(), name + ("_f16" if dtype == torch.float16 else ""))
 
 
 def _desc(t):
@@ -241,7 +253,9 @@ class PackPlan:
             self.dirty = True
 
     def _build(self, device):
-        jobs, blocks, entries, off = [], [], {}, 0
+        # one job / block table per library flavour: fp16 jobs go to brats_conv3d_pack_weights_multi_f16 (where the job's
+        # dtype code BF16 means "the 16-bit type"), everything else to the plain entry point
+        jobs, blocks, entries, off = {False: [], True: []}, {False: [], True: []}, {}, 0
         pb = _lib.lib().brats_conv3d_pack_block()
         for key, (wref, (dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1)) in self.recorded.items():
             w = wref()
@@ -256,17 +270,23 @@ class PackPlan:
             nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
             rows16 = (rows + 15) // 16
             ms_n = nbytes // ((kdim // ck) * rows16 * 1024)
-            total = nbytes // (2 if code == BF16 else 4)
+            total = nbytes // (2 if code in (BF16, F16) else 4)
             entries[key] = [wref, w.data_ptr(), off, nbytes, -1]
-            jobs.append((w.data_ptr(), off, code, mode, k ** 3, cin_w, cin_real, cin_off, rows, rows16, kdim, ck, ms_n, 0, total))
-            j = len(jobs) - 1
-            blocks.extend((j, b) for b in range((total + pb - 1) // pb))
+            fl = code == F16
+            jobs[fl].append((w.data_ptr(), off, BF16 if fl else code, mode, k ** 3, cin_w, cin_real, cin_off, rows, rows16, kdim, ck,
+                             ms_n, 0, total))
+            j = len(jobs[fl]) - 1
+            blocks[fl].extend((j, b) for b in range((total + pb - 1) // pb))
             off += (nbytes + 255) // 256 * 256
         self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=device)
-        rec = np.array(jobs, dtype=_PACK_JOB)
-        rec["out"] += self.buf.data_ptr()
-        self.jobs = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
-        self.blocks = torch.tensor(blocks, dtype=torch.int32, device=device).reshape(-1, 2).contiguous()
+        self.tables = []
+        for fl in (False, True):
+            if not jobs[fl]:
+                continue
+            rec = np.array(jobs[fl], dtype=_PACK_JOB)
+            rec["out"] += self.buf.data_ptr()
+            self.tables.append((fl, torch.from_numpy(rec.view(np.uint8).copy()).to(device),
+                                torch.tensor(blocks[fl], dtype=torch.int32, device=device).reshape(-1, 2).contiguous()))
         self.entries = entries
         self.dirty = False
 
@@ -281,10 +301,9 @@ class PackPlan:
                     break
         if self.dirty or self.entries is None:
             self._build(device)
-        if self.blocks.numel() == 0:
-            return
-        _lib.check(_lib.lib().brats_conv3d_pack_weights_multi(self.jobs.data_ptr(), self.blocks.data_ptr(), self.blocks.shape[0],
-                                                              _stream()), "conv3d_pack_weights_multi")
+        for fl, jobs, blocks in self.tables:
+            fn = _lib.lib().brats_conv3d_pack_weights_multi_f16 if fl else _lib.lib().brats_conv3d_pack_weights_multi
+            _lib.check(fn(jobs.data_ptr(), blocks.data_ptr(), blocks.shape[0], _stream()), "conv3d_pack_weights_multi")
         for e in self.entries.values():
             e[4] = e[0]()._version
 
@@ -473,7 +492,7 @@ def conv3d_f8(x, packed_w, cout, dil=1, bias=None, out=None, want_stats=False, x
     """conv3d() with the e4m3 MFMA kernel (bf16 tensors in and out).  amax / amax2: 1-element f32 tensors holding
     max|x| / max|x2| (from affine_act / gn_act_bwd / absmax); when missing they are computed here (one extra pass)
     unless a static power-of-two ``xscale`` is given."""
-    if x.dtype != torch.bfloat16:
+    if not is16(x.dtype):
         raise _lib.BratsHipError("conv3d_f8: bf16 activations only")
     ptr, c, p = _desc(x)
     n, d, h, w, _ = x.shape
@@ -500,7 +519,7 @@ def conv3d_f8(x, packed_w, cout, dil=1, bias=None, out=None, want_stats=False, x
     if want_stats:
         stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
     with _span("conv_igemm_f8", c + c2, cout, 3, dil, n, d, h, w, "e4m3"):
-        _lib.check(_lib.lib().brats_conv3d_f8_fwd(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2),
+        _lib.check(_fn16("brats_conv3d_f8_fwd", x.dtype)(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2),
                                                   float(xscale) if xscale is not None else 0.0, packed_w.data_ptr(),
                                                   _f32(bias), optr, op, y2.data_ptr() if y2 is not None else None,
                                                   (cout - split) if y2 is not None else 0, split or 0,
@@ -532,7 +551,7 @@ def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
 def conv3d_wgrad_f8_ok(x, dy, x2=None):
     """Is the e4m3 weight-gradient kernel built for this layer (3x3x3, dilation 1, 48 x 48 / 64 x 32 channel blocks)?"""
     n, d, h, w, c = x.shape
-    return (x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and
+    return (is16(x.dtype) and dy.dtype == x.dtype and
             _lib.lib().brats_conv3d_wgrad_f8_ws_bytes(n, d, h, w, c, x2.shape[-1] if x2 is not None else 0, dy.shape[-1]) > 0)
 
 
@@ -546,7 +565,7 @@ def conv3d_wgrad_f8(x, dy, amax, amax_dy, x2=None, amax2=None):
         ptr2, c2, p2 = _desc(x2)
     dptr, cout, dp = _desc(dy)
     n, d, h, w, _ = x.shape
-    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+    if not is16(x.dtype) or dy.dtype != x.dtype:
         raise _lib.BratsHipError("conv3d_wgrad_f8: bf16 activations only")
     nbytes = _lib.lib().brats_conv3d_wgrad_f8_ws_bytes(n, d, h, w, c, c2, cout)
     if nbytes == 0:
@@ -554,7 +573,7 @@ def conv3d_wgrad_f8(x, dy, amax, amax_dy, x2=None, amax2=None):
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, c + c2, 3, 3, 3), dtype=torch.float32, device=x.device)
     with _span("conv_wgrad_f8", c + c2, cout, 3, 1, n, d, h, w, "e4m3"):
-        _lib.check(_lib.lib().brats_conv3d_wgrad_f8(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2), dptr, dp, _f32(amax_dy),
+        _lib.check(_fn16("brats_conv3d_wgrad_f8", x.dtype)(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2), dptr, dp, _f32(amax_dy),
                                                     ws.data_ptr(), dw.data_ptr(), n, d, h, w, cout, _stream()), "conv3d_wgrad_f8")
     return dw
 
@@ -808,7 +827,7 @@ def pack_weights_direct(w, dtype, mode, cin_off=0, cin_cnt=None):
     code = _code(dtype)
     nbytes = _lib.lib().brats_dconv_packed_bytes(code, k, kdim, rows)
     if nbytes == 0:
-        raise _lib.BratsHipError(f"pack_weights_direct: K channels {kdim} must be a multiple of {16 if code == BF16 else 8}")
+        raise _lib.BratsHipError(f"pack_weights_direct: K channels {kdim} must be a multiple of {16 if code in (BF16, F16) else 8}")
     wd = w.detach()
     if wd.dtype != torch.float32 or not wd.is_contiguous():
         wd = wd.contiguous().float()

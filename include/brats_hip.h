@@ -11,7 +11,12 @@
  *     channel pitch P lives at ((((n*D+d)*H+h)*W+w)*P + c).  A pitch larger than the channel count
  *     lets producers write straight into a channel slice of a concat buffer (torch.cat removed).
  *   - dtype: BRATS_F32 = 0 (exact-f32 MFMA, the parity mode), BRATS_BF16 = 1 (bf16 storage, f32
- *     accumulate, the throughput mode).  Statistics / gradients of parameters are always f32.
+ *     accumulate, the throughput mode), BRATS_F16 = 2 (IEEE half storage, f32 accumulate: the
+ *     reference's own autocast dtype, learning/engine.py:304 -- same kernels, same rates, three more
+ *     mantissa bits and a 65504 range: train it under a GradScaler like the reference does).
+ *     Statistics / gradients of parameters are always f32.  Every entry point with a `dtype`
+ *     argument accepts all three; the few that move 16-bit data WITHOUT a dtype argument exist
+ *     twice: brats_x (bf16) and brats_x_f16.
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library never
  *     allocates, never synchronises, launches only on the stream passed in (graph-capturable).
  *   - return 0 on success; <0 = BRATS_E_* (message via brats_last_error()).  Never throws.
@@ -28,7 +33,7 @@ extern "C" {
 
 typedef void* brats_stream_t; /* hipStream_t */
 
-enum { BRATS_F32 = 0, BRATS_BF16 = 1 };
+enum { BRATS_F32 = 0, BRATS_BF16 = 1, BRATS_F16 = 2 };
 enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
 /* --act of the reference (src/arguments_train.py:49-50; MONAI Act factory): relu, leakyrelu(slope), elu(alpha=1),
  * swish = x*sigmoid(x), mish = x*tanh(softplus(x)).  prelu = BRATS_ACT_LEAKY with the learnable slope read from device
@@ -78,6 +83,8 @@ typedef struct {
 int brats_conv3d_pack_block(void);
 int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* blocks /* [nblocks][2] */, int nblocks,
                                     brats_stream_t s);
+int brats_conv3d_pack_weights_multi_f16(const brats_pack_job* jobs, const int* blocks /* [nblocks][2] */, int nblocks,
+                                    brats_stream_t s);  /* the same on fp16 activations (job dtype BRATS_BF16 = 16-bit) */
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
 /* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
 int brats_conv3d_split_granule(int cout);
@@ -111,6 +118,10 @@ int brats_conv3d_f8_fwd(const void* x1, int c1, int pitch1, const float* amax1, 
                         const float* amax2, float xscale, const void* packed_w, const float* bias, void* y, int ypitch,
                         void* y2, int y2pitch, int ysplit, float* stats, int dil, int N, int D, int H, int W, int cout,
                         brats_stream_t s);
+int brats_conv3d_f8_fwd_f16(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+                        const float* amax2, float xscale, const void* packed_w, const float* bias, void* y, int ypitch,
+                        void* y2, int y2pitch, int ysplit, float* stats, int dil, int N, int D, int H, int W, int cout,
+                        brats_stream_t s);  /* the same on fp16 activations (job dtype BRATS_BF16 = 16-bit) */
 /* out[0] = max |x| over `rows` voxels x C channels of an NDHWC tensor (channel pitch `pitch`) */
 int brats_absmax(const void* x, int pitch, int dtype, size_t rows, int C, float* out, brats_stream_t s);
 /* wgrad: dW[co][ci][tap] = sum_v dy[v][co] * x[v + off(tap)][ci]  (x = virtual concat as above).
@@ -135,6 +146,9 @@ size_t brats_conv3d_wgrad_f8_ws_bytes(int N, int D, int H, int W, int c1, int c2
 int brats_conv3d_wgrad_f8(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
                           const float* amax2, const void* dy, int dypitch, const float* amax_dy, float* ws, float* dw,
                           int N, int D, int H, int W, int cout, brats_stream_t s);
+int brats_conv3d_wgrad_f8_f16(const void* x1, int c1, int pitch1, const float* amax1, const void* x2, int c2, int pitch2,
+                          const float* amax2, const void* dy, int dypitch, const float* amax_dy, float* ws, float* dw,
+                          int N, int D, int H, int W, int cout, brats_stream_t s);  /* the same on fp16 activations (job dtype BRATS_BF16 = 16-bit) */
 /* Weight gradient in the "shifted-tap" form: ksize = 1 (ConvEvo / bridge / upconv / ASPP k1 convolutions,
  * networks/equiunet2021.py:212-222 -- a GEMM over the voxels) and ksize = 3 at ANY dilation >= 1 (the ASPP branches with
  * dilation 4 and 6, :121-189, whose halo does not fit LDS): one workgroup per (tap, channel block, voxel range), its X tile

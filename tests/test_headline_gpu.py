@@ -150,3 +150,106 @@ def test_assp_full_size_step_is_deterministic_and_learns(width, fp8):
     print(f"\nASSP-{width} fp8={fp8} 2x4x128^3 losses {runs[0][0]}")
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert runs[0][0][2] < runs[0][0][0]
+
+
+def test_equiunet48_fp16_storage_vs_oracle():
+    """model.precision = "fp16" (IEEE half storage: the reference's own autocast dtype, learning/engine.py:304) at 1x4x64^3
+    with the bench's weights and image: deviation from the f32 CPU oracle printed beside bf16's (fp16 carries three more
+    mantissa bits: expected ~8x closer), hard Dice within the 1e-3 north-star bar, and the torch.autocast(float16) switch
+    picks the same kernels."""
+    _cpu_threads()
+    m = _get("equiunet", 48)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    s3 = (64, 64, 64)
+    x = synth.random_image(1, 4, s3, seed=1234)
+    t = synth.nested_spheres(1, s3)
+    with torch.no_grad():
+        ref, _ = unet.equiunet_forward(sd, x)
+        outs = {}
+        for prec in ("bf16", "fp16"):
+            m.precision = prec
+            outs[prec] = m(x.to(DEV))[0].float().cpu()
+        m.precision = "auto"
+        with torch.autocast("cuda", dtype=torch.float16):
+            auto16 = m(x.to(DEV))[0].float().cpu()
+    assert torch.equal(auto16, outs["fp16"])
+    dev = {k: (v - ref).abs() for k, v in outs.items()}
+    d_ref = unet.hard_dice(ref, t)
+    d16 = unet.hard_dice(outs["fp16"], t)
+    flips = float(((outs["fp16"] > 0) != (ref > 0)).float().mean())
+    print(f"\nEquiUnet-48 @64^3 vs f32 oracle: fp16 max {float(dev['fp16'].max()):.3e} mean {float(dev['fp16'].mean()):.3e} | "
+          f"bf16 max {float(dev['bf16'].max()):.3e} mean {float(dev['bf16'].mean()):.3e}; fp16 thresholded voxels that differ {flips:.3e}; "
+          f"hard Dice oracle {d_ref.flatten().tolist()} fp16 {d16.flatten().tolist()}")
+    assert torch.isfinite(outs["fp16"]).all()
+    assert float(dev["fp16"].mean()) < 0.25 * float(dev["bf16"].mean())   # three more mantissa bits
+    assert float(dev["fp16"].mean()) < 0.01 and float(dev["fp16"].max()) < 0.25
+    assert float((d_ref - d16).abs().max()) <= DICE_ATOL
+
+
+def test_fp16_gradscaler_training_loop():
+    """The reference's AMP loop (autocast fp16 + GradScaler, learning/engine.py:117-122) through TrainStep(amp_dtype=float16):
+    EquiUnet width 8 at 32^3; the first step's unscaled gradients against the oracle's f32 gradients, the scaler stays
+    finite, the loss falls, and a forced overflow (huge loss scale) skips the step and halves the scale like the reference."""
+    from brats21_amd.engine import TrainStep
+    from brats21_amd.optim import Ranger2020
+    _cpu_threads()
+    m = _get("equiunet", 8)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    size = (32, 32, 32)
+    x, t = synth.random_image(2, 4, size, seed=7), synth.nested_spheres(2, size)
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    unet.deep_supervision_loss(unet.equiunet_forward(sd_ref, x), t).backward()
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = Ranger2020(m.parameters(), lr=1e-3, use_gc=False)
+    step = TrainStep(m, opt, amp=True, amp_dtype=torch.float16)
+    assert step.scaler is not None
+    xd, td = x.to(DEV), t.to(DEV)
+    # gradients of one scaled backward, unscaled by the scaler
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss0 = step.loss(m(xd), td)
+    step.scaler.scale(loss0).backward()
+    step.scaler.unscale_(opt)
+    rel = []
+    for k, p in m.named_parameters():
+        g = sd_ref[k].grad
+        rel.append(float((p.grad.cpu() - g).norm() / (g.norm() + 1e-12)))
+    print(f"\nfp16 + GradScaler: per-parameter gradient rel err vs f32 oracle median {sorted(rel)[len(rel) // 2]:.3e} worst {max(rel):.3e}")
+    assert sorted(rel)[len(rel) // 2] < 0.02 and max(rel) < 0.2
+    step.scaler.step(opt)
+    step.scaler.update()
+    losses = [float(step(xd, td).detach()) for _ in range(6)]
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert losses[-1] < float(loss0.detach())
+    # overflow: a loss scale of 2^100 puts inf into the fp16 gradients -> the step is skipped, the scale halves
+    before = [p.detach().clone() for p in m.parameters()]
+    step.scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 100)
+    step(xd, td)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters()))
+    assert step.scaler.get_scale() == 2.0 ** 99
+
+
+def test_config4_assp64_fp16_fp8_four_patches():
+    """BASELINE.json configs[4] as stated: EquiUnetASSPEvo width 64, fp16 storage + e4m3 MFMA convolutions (conv_fp8 = "all"),
+    4 patches of 4x128^3 per GPU, under the reference's GradScaler loop: finite, bitwise deterministic, the loss falls."""
+    from brats21_amd.engine import TrainStep
+    from brats21_amd.optim import Ranger2020
+    x = synth.random_image(4, 4, (128, 128, 128), seed=1234).to(DEV)
+    t = synth.nested_spheres(4, (128, 128, 128)).to(DEV)
+    runs = []
+    for _ in range(2):
+        m = _get("equiunet_assp_evo", 64).to(DEV).train()
+        m.conv_fp8 = "all"
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = Ranger2020(m.parameters(), lr=1e-3, use_gc=False)
+        step = TrainStep(m, opt, amp=True, amp_dtype=torch.float16)
+        losses = [float(step(x, t).detach()) for _ in range(3)]
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+        runs.append((losses, torch.cat([p.detach().flatten()[:300] for p in m.parameters()]).clone(), step.scaler.get_scale()))
+        del m, opt, step
+        torch.cuda.empty_cache()
+    print(f"\nASSP-64 fp16 + e4m3, 4x4x128^3: losses {runs[0][0]}, loss scale {runs[0][2]}")
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][2] < runs[0][0][0]

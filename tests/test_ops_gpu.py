@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DT = [torch.float32, torch.bfloat16]
+DT = [torch.float32, torch.bfloat16, torch.float16]  # f32 (exact MFMA), bf16, fp16 (the -DBRATS_FP16 twin build of the same kernels)
 
 
 def _dev():
