@@ -91,8 +91,12 @@ __global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __res
 #pragma unroll
   for (int r = 0; r < 4; ++r) bias[r] = (b && r < K) ? b[r] : 0.f;
   const bf16_t* xb = x + (size_t)n * voxels * xpitch;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, (short)0, (int)(voxels * xpitch * 2), 0x00020000);
-  const int dead1 = 32 + 8 * q < C ? 0 : -1;  // channels 32 + 8q.. of the second k-step exist?
+  // (the range ends with the last voxel's C channels: a channel-slice view of a wider buffer must not be read past its slice)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, (short)0, (int)((voxels - 1) * xpitch * 2 + C * 2), 0x00020000);
+  // channels 8q.. of the first and 32 + 8q.. of the second k-step exist?  (C < 32: the lanes of the missing channel groups
+  // must not read the next voxel / the neighbouring slice -- zero weights do not neutralise an Inf or NaN there)
+  const int dead0 = 8 * q < C ? 0 : -1;
+  const int dead1 = 32 + 8 * q < C ? 0 : -1;
   const size_t wave_id = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
   float* lowp = low + (size_t)n * K * voxels;
   for (size_t v0 = wave_id * 64; v0 < voxels; v0 += nwaves * 64) {  // 4 chunks of 16 voxels per iteration: 8 loads in flight
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __res
     for (int i = 0; i < 4; ++i) {
       const size_t vv = v0 + 16 * i + v;
       const int off = vv < voxels ? (int)(vv * xpitch * 2) + 16 * q : -1;
-      xb0[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      xb0[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off | dead0, 0, 0));
       xb1[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + 64) | dead1 | (off >> 31), 0, 0));
     }
 #pragma unroll

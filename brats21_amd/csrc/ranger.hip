@@ -29,7 +29,10 @@ __global__ void __launch_bounds__(256) ranger_row_means_kernel(const brats_range
 
 // use_gcnorm (learning/optimizer.py:23-36,189-190): the (centralised) gradient of every tensor with more than two elements
 // is divided by its unbiased standard deviation + 1e-8.  Two small kernels in front of the update: per 2048-element chunk
-// the sums of x = g - row mean and of x^2 (fixed-order tree), then per tensor the chunk sums added in chunk order in f64.
+// the sums of x = g - row mean - pilot and of x^2 (fixed-order tree), then per tensor the chunk sums added in chunk order in
+// f64.  pilot = the tensor's first (centralised) element: the variance is shift-invariant, and with the shift the one-pass
+// formula (s2 - s1^2 / n) no longer cancels catastrophically when |mean| >> std (use_gc = False: the reference's torch.std
+// is two-pass); the f32 chunk partials stay well-conditioned.
 __global__ void __launch_bounds__(256) ranger_chunk_stats_kernel(const brats_ranger_tensor* __restrict__ tab,
                                                                  const int* __restrict__ chunks, const float* __restrict__ means,
                                                                  float* __restrict__ part /* [nchunks][2] */) {
@@ -39,10 +42,13 @@ __global__ void __launch_bounds__(256) ranger_chunk_stats_kernel(const brats_ran
   const float* __restrict__ g = (const float*)T.grad;
   const bool gc = T.rowlen > 0;
   const long end = base + RANGER_CHUNK < T.numel ? base + RANGER_CHUNK : T.numel;
+  float pilot = g[0];
+  if (gc) pilot = pilot + (-means[T.row_base]);
   float s1 = 0.f, s2 = 0.f;
   for (long i = base + threadIdx.x; i < end; i += 256) {
     float x = g[i];
     if (gc) x = x + (-means[T.row_base + (int)(i / T.rowlen)]);
+    x = x - pilot;
     s1 += x;
     s2 += x * x;
   }

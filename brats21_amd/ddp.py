@@ -77,8 +77,10 @@ class GradientBuckets:
         self._filled = None
         self._late = None          # buckets that must be gathered from p.grad in finish() (gradient accumulation)
         self._sync = True
+        self._copies = None        # per bucket: ([destination slices], [gradients]) of pushes that still have to be copied in
         if hasattr(model, "_grad_sink"):
             model._grad_sink = self.push
+            model._grad_dest = self.dest
 
     # -- planning ---------------------------------------------------------------------------------
     def _build_plan(self, order):
@@ -122,6 +124,7 @@ class GradientBuckets:
         self._filled = [0] * len(self._plan)
         self._handles = [None] * len(self._plan)
         self._late = set()
+        self._copies = [([], []) for _ in self._plan]
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -135,6 +138,11 @@ class GradientBuckets:
             self._sync = old
 
     def _launch(self, b):
+        if self._copies is not None and self._copies[b][0]:
+            # the small gradients of this bucket (norm weights, biases, heads): ONE multi-tensor copy instead of a copy_ launch
+            # per parameter; the weight gradients (> 99 % of the bytes) were written in place by their kernels (dest())
+            torch._foreach_copy_(self._copies[b][0], self._copies[b][1])
+            self._copies[b] = ([], [])
         if self.world > 1 or (self.force_collectives and dist.is_initialized()):
             buf = self._flat[b]
             if self._wire is not None:
@@ -143,6 +151,20 @@ class GradientBuckets:
             self._handles[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- producer side ----------------------------------------------------------------------------
+    def dest(self, param_index):
+        """Where parameter #param_index's gradient will live: its contiguous f32 slice of the bucket, for kernels that can
+        write their result anywhere (the weight-gradient slab reduce: ops.conv3d_wgrad(..., out=)) -- push() then finds the
+        gradient already in place and copies nothing.  None while that is not possible (first step: no plan yet; no_sync;
+        gradient accumulation into an existing p.grad)."""
+        if not self._sync or self._plan is None or param_index not in self._where:
+            return None
+        if self.params[param_index].grad is not None:
+            return None
+        b, off = self._where[param_index]
+        if self._handles and self._filled is not None and self._handles[b] is not None:
+            return None  # (this step's collective on that bucket is already in flight)
+        return self._flat[b][off:off + self.params[param_index].numel()]
+
     def push(self, param_index, grad):
         """Called by the backward program as soon as parameter #param_index's gradient exists."""
         if not self._sync:
@@ -159,7 +181,10 @@ class GradientBuckets:
             # as it stands in finish(), not `grad` -- this bucket is gathered and reduced there (no overlap, but right)
             self._late.add(b)
             return
-        self._flat[b][off:off + grad.numel()].copy_(grad.reshape(-1))
+        dst = self._flat[b][off:off + grad.numel()]
+        if grad.data_ptr() != dst.data_ptr():  # (a kernel that took dest() has written it in place)
+            self._copies[b][0].append(dst)
+            self._copies[b][1].append(grad.reshape(-1))
         self._filled[b] += 1
         if self._filled[b] == len(self._plan[b]) and b not in self._late:
             self._launch(b)
@@ -185,6 +210,7 @@ class GradientBuckets:
             if self._filled[b] != len(bucket) or b in self._late:  # not (only) produced through push(): gather from p.grad
                 if self._handles[b] is not None:  # an earlier micro-batch already sent this bucket off: let it land first
                     self._handles[b].wait()
+                self._copies[b] = ([], [])  # (partial pushes of this bucket: superseded by the gather below)
                 for idx, off, n in bucket:
                     g = self.params[idx].grad
                     dst = self._flat[b][off:off + n]
@@ -213,6 +239,7 @@ class GradientBuckets:
                 p.grad = self._flat[b][off:off + n].view_as(p)
         self._filled = None
         self._handles = []
+        self._copies = None
 
     def payload_bytes(self):
         """Bytes every rank contributes to the all-reduces of one step."""

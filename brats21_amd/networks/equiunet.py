@@ -146,7 +146,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
-def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None):
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
     fp8 == "all": the input gradient (dgrad) and -- for the dilation-1 layers the all-taps kernel covers -- the weight
     gradient run on the e4m3 kernels too, scaled by the |max| of dy that the GroupNorm backward records (and the |max| of
@@ -167,15 +167,17 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
             sink(names[unit.prelu.weight], grads[names[unit.prelu.weight]])
     dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
                                        slope_t=slope_t)
+    # data-parallel: the weight gradient is written straight into its slice of the all-reduce bucket
+    wdst = dest(names[unit.conv.weight]) if dest is not None else None
     with ops.side_stream(side, dy, x, x2) as on_side:
         # (the weight gradient depends only on dy and the saved input and nobody but the optimizer waits for it: on the
         # side stream it fills the CUs that the tail of the input-gradient kernel and the small GroupNorm launches leave idle)
         if w8 and amax is not None:
-            dw = ops.conv3d_wgrad_f8(x, dy, ax, amax, x2=x2, amax2=ax2)
+            dw = ops.conv3d_wgrad_f8(x, dy, ax, amax, x2=x2, amax2=ax2, out=wdst)
         elif x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
             dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
         else:
-            dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2)
+            dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2, out=wdst)
         dw = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
         on_side(dw)
     grads[names[unit.conv.weight]] = dw
@@ -286,7 +288,7 @@ class _EquiUnetFn(torch.autograd.Function):
         side = ops.get_side_stream(douts[0].device) if (m.wgrad_stream and m._grad_sink is None) else None
 
         def cbw(unit, dz, need_dx=True):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side)
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
@@ -363,6 +365,7 @@ class EquiUnet(_PackedWeightsModule):
         # each other, and the tails they could fill are shorter than the interference they add
         self.wgrad_stream = os.environ.get("BRATS_WGRAD_STREAM", "0") != "0"
         self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
+        self._grad_dest = None  # (ditto: parameter index -> its slice of an all-reduce bucket, or None)
         # training: one multi-tensor weight-packing launch per step (ops.PackPlan).  Off by default here: this network's
         # step is GPU-bound and the single gather-heavy launch (0.21 ms) saves only 0.05 ms of GPU time over the 34 small
         # ones while measuring 0.1 ms slower end to end (same-box A/B); EquiUnetASSPEvo (host-bound eager) gains 10 %.

@@ -93,6 +93,11 @@ class _Ctx:
             self.slots = _AmaxSlots(64, device)
         return self.slots.take()
 
+    def dest(self, param):
+        """The parameter's slice of a DDP all-reduce bucket (ddp.GradientBuckets.dest) for kernels that can write there."""
+        d = getattr(self.m, "_grad_dest", None)
+        return d(self.names[param]) if d is not None else None
+
     def put(self, param, grad):
         i = self.names[param]
         self.grads[i] = grad.reshape(param.shape)
@@ -121,14 +126,14 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     if db is None:
         db = ops.channel_dot(dy).sum(0)
     if k == 1:
-        dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1)  # a GEMM over the voxels: the shifted-tap weight-gradient kernel, 1 tap
+        dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1, out=cx.dest(conv.weight))  # a GEMM over the voxels: shifted-tap kernel, 1 tap
         cx.put(conv.weight, dw)
     else:
         ax, ady = getattr(xin, "_amax", None), getattr(dy, "_amax", None)
         if cx.fp8 == "all" and dil == 1 and ax is not None and ady is not None and ops.conv3d_wgrad_f8_ok(xin, dy):
-            dw = ops.conv3d_wgrad_f8(xin, dy, ax, ady)  # e4m3 operands, scales from the recorded |max| of both
+            dw = ops.conv3d_wgrad_f8(xin, dy, ax, ady, out=cx.dest(conv.weight))  # e4m3 operands, scales from the recorded |max|
         else:
-            dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil)
+            dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil, out=cx.dest(conv.weight))
         cx.put(conv.weight, dw[:, :cin].contiguous() if dw.shape[1] != cin else dw)
     cx.put(conv.bias, db)
     if not need_dx:
@@ -367,6 +372,7 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
         self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "1") != "0"  # training: one multi-tensor weight-packing launch per step (ops.PackPlan)
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None
+        self._grad_dest = None
         f = self.features
         self.encoder1 = ConvEvoBlockCorrected(inplanes, f[0])
         self.encoder2 = ConvEvoBlockCorrected(2 * f[0], f[1])

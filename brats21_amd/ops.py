@@ -528,7 +528,15 @@ def conv3d_f8(x, packed_w, cout, dil=1, bias=None, out=None, want_stats=False, x
     return ((out, y2) if y2 is not None else out), stats
 
 
-def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
+def _grad_out(out, shape, device):
+    """The f32 tensor a gradient kernel writes: `out` (e.g. the parameter's slice of a DDP bucket, ddp.GradientBuckets.dest)
+    when it is given and fits, otherwise a fresh allocation."""
+    if out is not None and out.numel() == int(np.prod(shape)) and out.dtype == torch.float32 and out.is_contiguous():
+        return out.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None, out=None):
     """dW [cout, cin (+cin2), k,k,k] f32 (and dbias) from the layer input [x | x2] and the output gradient dy."""
     ptr, c, p = _desc(x)
     ptr2, c2, p2 = (None, 0, 0)
@@ -539,7 +547,7 @@ def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None):
     code = _code(x.dtype)
     nbytes = _lib.lib().brats_conv3d_wgrad_ws_bytes(code, ksize, n, d, h, w, c, c2, cout)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty((cout, c + c2, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
+    dw = _grad_out(out, (cout, c + c2, ksize, ksize, ksize), x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
     with _span("conv_wgrad", c + c2, cout, ksize, dil, n, d, h, w, str(x.dtype)):
         _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, ptr2, c2, p2, dptr, dp, ws.data_ptr(), dw.data_ptr(),
@@ -555,7 +563,7 @@ def conv3d_wgrad_f8_ok(x, dy, x2=None):
             _lib.lib().brats_conv3d_wgrad_f8_ws_bytes(n, d, h, w, c, x2.shape[-1] if x2 is not None else 0, dy.shape[-1]) > 0)
 
 
-def conv3d_wgrad_f8(x, dy, amax, amax_dy, x2=None, amax2=None):
+def conv3d_wgrad_f8(x, dy, amax, amax_dy, x2=None, amax2=None, out=None):
     """dW [cout, cin (+cin2), 3, 3, 3] f32 of a dilation-1 layer with X and dY rounded to e4m3 on the way into the MFMA
     (v_mfma_scale_f32_16x16x128_f8f6f4).  amax* : 1-element f32 device tensors holding max|x|, max|x2|, max|dy| (recorded
     by the kernels that produced the tensors; absmax() otherwise).  Only where conv3d_wgrad_f8_ok()."""
@@ -571,7 +579,7 @@ def conv3d_wgrad_f8(x, dy, amax, amax_dy, x2=None, amax2=None):
     if nbytes == 0:
         raise _lib.BratsHipError(f"conv3d_wgrad_f8: not built for {c}+{c2} -> {cout} channels at {n}x{d}x{h}x{w} (use conv3d_wgrad)")
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty((cout, c + c2, 3, 3, 3), dtype=torch.float32, device=x.device)
+    dw = _grad_out(out, (cout, c + c2, 3, 3, 3), x.device)
     with _span("conv_wgrad_f8", c + c2, cout, 3, 1, n, d, h, w, "e4m3"):
         _lib.check(_fn16("brats_conv3d_wgrad_f8", x.dtype)(ptr, c, p, _f32(amax), ptr2, c2, p2, _f32(amax2), dptr, dp, _f32(amax_dy),
                                                     ws.data_ptr(), dw.data_ptr(), n, d, h, w, cout, _stream()), "conv3d_wgrad_f8")
@@ -861,7 +869,7 @@ def dconv_run(jobs, n, d, h, w, dtype):
     _lib.check(_lib.lib().brats_dconv_run(buf, len(jobs), _code(dtype), n, d, h, w, _stream()), "dconv_run")
 
 
-def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False):
+def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False, out=None):
     """dW [cout, cin, k, k, k] f32 (and dbias) of a 1x1x1 convolution, or of a 3x3x3 convolution at any dilation
     (shifted-tap form of the weight-gradient kernel: the ASPP branches with dilation 4 / 6)."""
     ptr, c, p = _desc(x)
@@ -870,7 +878,7 @@ def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False):
     code = _code(x.dtype)
     nbytes = _lib.lib().brats_conv3d_wgrad_shift_ws_bytes(code, ksize, n, d, h, w, c, cout)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty((cout, c, ksize, ksize, ksize), dtype=torch.float32, device=x.device)
+    dw = _grad_out(out, (cout, c, ksize, ksize, ksize), x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
     with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
         _lib.check(_lib.lib().brats_conv3d_wgrad_shift(ptr, c, p, dptr, dp, ws.data_ptr(), dw.data_ptr(),
