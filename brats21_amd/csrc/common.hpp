@@ -45,6 +45,19 @@ DEVI void unpack2(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 
 #define MFMA16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif
 
+// two floats -> one packed pair of the 16-bit type in ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, RNE); the
+// element-wise form (f2bf(lo) | f2bf(hi) << 16) costs three: a conversion each plus shift-and-or
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+#ifdef BRATS_FP16
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_;
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 half2_;
+#endif
+DEVI uint32_t pack2(float lo, float hi) {
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2_));
+}
+
 template <typename T> DEVI float to_f(T v);
 template <> DEVI float to_f<float>(float v) { return v; }
 template <> DEVI float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
@@ -66,8 +79,8 @@ template <> struct Vec<bf16_t, 4> {
   }
   static DEVI void store(bf16_t* p, const float* o) {
     u32x2 v;
-    v[0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-    v[1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+    v[0] = pack2(o[0], o[1]);
+    v[1] = pack2(o[2], o[3]);
     *(u32x2*)p = v;
   }
 };
@@ -80,7 +93,7 @@ template <> struct Vec<bf16_t, 8> {
   static DEVI void store(bf16_t* p, const float* o) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v[i] = pack2(o[2 * i], o[2 * i + 1]);
     *(u32x4*)p = v;
   }
   // non-temporal forms for tensors far larger than L2 + Infinity Cache that are streamed once per pass: measured on a
@@ -93,7 +106,7 @@ template <> struct Vec<bf16_t, 8> {
   static DEVI void store_nt(bf16_t* p, const float* o) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) v[i] = pack2(o[2 * i], o[2 * i + 1]);
     __builtin_nontemporal_store(v, (u32x4*)p);
   }
 };

@@ -180,6 +180,44 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
   }
 }
 
+// One chunk of MFMA work with a ring of RB activation fragments: fragment j = (macro-step k = j / 8, x-row i = j % 8) is
+// read RB - 1 fragments (3 (RB - 1) MFMAs) ahead of its use; the weight fragments of step k + WD are requested at the start
+// of step k.  Registers: NF * 8 * 4 accumulators + (WD + 1) * NF * 4 weights + RB * 4 activations.
+template <int NF, int WD, int RB, typename G>
+DEVI void conv_mma_ring(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0, int lane,
+                        f32x4 (&acc)[NF][8]) {
+  constexpr int NB = 8, YB = 4, MS = G::MS, NJ = MS * NB;
+  constexpr int FOZ = G::HY * G::HX * G::S;
+  const bf16x8* wp0 = (const bf16x8*)wpk_chunk + (size_t)f0 * 64 + lane;
+  bf16x8 a[WD + 1][NF];
+  bf16x8 b[RB];
+  auto load_a = [&](auto k_) {
+    constexpr int k = k_;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)k * rows16 + f) * 64];
+  };
+  auto read_b = [&](auto j_) {
+    constexpr int j = j_, k = j / NB, i = j % NB;
+    constexpr int o0 = G::unitoff(4 * k), o1 = G::unitoff(4 * k + 1), o2 = G::unitoff(4 * k + 2), o3 = G::unitoff(4 * k + 3);
+    int lb;
+    if constexpr (o1 - o0 == G::UB && o2 - o0 == 2 * G::UB && o3 - o0 == 3 * G::UB) lb = lane_b + o0;
+    else lb = lane_b + (q == 0 ? o0 : q == 1 ? o1 - G::UB : q == 2 ? o2 - 2 * G::UB : o3 - 3 * G::UB);
+    b[j % RB] = *(const bf16x8*)(ldsb + lb + ((i / YB) * FOZ + (i % YB) * G::HX * G::S));
+  };
+  static_for<0, (WD < MS ? WD : MS)>([&](auto k_) { load_a(k_); });
+  static_for<0, RB - 1>([&](auto j_) { read_b(j_); });
+  static_for<0, NJ>([&](auto j_) {
+    constexpr int j = j_, k = j / NB, i = j % NB;
+    if constexpr (i == 0 && k + WD < MS) load_a(std::integral_constant<int, k + WD>{});
+    if constexpr (j + RB - 1 < NJ) read_b(std::integral_constant<int, j + RB - 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+      acc[f][i] = MFMA16_16x16x32(a[k % (WD + 1)][f], b[j % RB], acc[f][i]);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 // 16-lane (one MFMA row group) all-reduce with DPP row rotations: 4 VALU ops, no LDS crossbar.
 DEVI float row16_sum(float x) {
   x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
@@ -230,11 +268,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     lds_off[j] = pc < PPR ? wave * (G::HX * G::S) + hx * G::S + part * 16 : -1;
   }
 
+  // accumulators start at the bias (zero without one; the second K-split partition adds to the first: zero): no bias add in
+  // the epilogue, whose instruction count is what it costs beside the partner workgroup's MFMA stream (conv_igemm_vs8.hpp)
   f32x4 acc[NF][NB];
 #pragma unroll
-  for (int f = 0; f < NF; ++f)
+  for (int f = 0; f < NF; ++f) {
+    const int cbase = (f0 + f) * 16 + 4 * q;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && cbase < p.cout && !(KSPLIT && wn == 1)) b = *(const f32x4*)(p.bias + cbase);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NB; ++i) acc[f][i] = b;
+  }
 
   // lane's voxel inside the halo tile (tap (0,0,0) corner) + quarter offset
   const int lane_b = ((wm * 2) * G::HY * G::HX + (VS ? wn * 2 * G::HX : 0) + v) * G::S + q * G::UB;
@@ -320,13 +364,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int ypit = second ? p.y2pitch : p.ypitch;
     const int csub = second ? p.ysplit : 0;
     const int lane_o = (x0 + v) * ypit + 4 * q - csub;  // elements from the row origin
-    float bias[NF][4], s1[NF][4], s2[NF][4];
+    float s1[NF][4], s2[NF][4];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const int cbase = (f0 + f) * 16 + 4 * q;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        bias[f][r] = (p.bias && cbase < p.cout) ? p.bias[cbase + r] : 0.f;
         s1[f][r] = 0.f;
         s2[f][r] = 0.f;
       }
@@ -354,12 +396,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              o[r] = acc[f][i + e][r] + bias[f][r];
+              o[r] = acc[f][i + e][r];
               s1[f][r] += o[r];
-              s2[f][r] += o[r] * o[r];
+              s2[f][r] = __builtin_fmaf(o[r], o[r], s2[f][r]);
             }
-            pk[e][0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-            pk[e][1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+            pk[e][0] = pack2(o[0], o[1]);
+            pk[e][1] = pack2(o[2], o[3]);
           }
           const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
           const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -376,9 +418,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            o[r] = acc[f][i][r] + bias[f][r];
+            o[r] = acc[f][i][r];
             s1[f][r] += o[r];
-            s2[f][r] += o[r] * o[r];
+            s2[f][r] = __builtin_fmaf(o[r], o[r], s2[f][r]);
           }
           Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
@@ -397,10 +439,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            o[r] = acc[f][i][r] + bias[f][r];
+            o[r] = acc[f][i][r];
             const float om = o[r] * mf;
             s1[f][r] += om;
-            s2[f][r] += om * o[r];
+            s2[f][r] = __builtin_fmaf(om, o[r], s2[f][r]);
           }
           if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }

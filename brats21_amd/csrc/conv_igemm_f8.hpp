@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f8_kernel(const ConvF8Param
           for (int r = 0; r < 4; ++r) {
             o[r] = acc[f][i][r] * mul[f][r] + bias[f][r];
             s1[f][r] += o[r];
-            s2[f][r] += o[r] * o[r];
+            s2[f][r] = __builtin_fmaf(o[r], o[r], s2[f][r]);
           }
           Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f8_kernel(const ConvF8Param
             o[r] = acc[f][i][r] * mul[f][r] + bias[f][r];
             const float om = o[r] * mf;
             s1[f][r] += om;
-            s2[f][r] += om * o[r];
+            s2[f][r] = __builtin_fmaf(om, o[r], s2[f][r]);
           }
           if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }

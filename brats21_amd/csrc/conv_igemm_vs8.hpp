@@ -23,7 +23,23 @@ constexpr int conv_vs8_lds_bytes() {
   return (G::LDS_TILE + 15) / 16 * 16 + 4 * NF * 16 * 2 * 4;
 }
 
-// Epilogue of the 4 x 8 x 16-tile kernels (conv_igemm_vs8_kernel, conv_igemm_ld_kernel): bias, per-channel statistics of the
+// Accumulators start at the bias (zero without one): the epilogue has no bias add.  The epilogue of a tile runs beside the
+// partner workgroup's MFMA stream, where a vector instruction gets an issue slot only every ~16 cycles (an MFMA holds the
+// SIMD's vector issue for 8 of its 16 cycles): its ~800 VALU instructions WERE the 12 k cycles the stamps showed (round 3),
+// so it is written for instruction count -- bias in the accumulator, one fma per squared sum, one v_cvt_pk per pair.
+template <int NF>
+DEVI void vs8_init_acc(const ConvParams& p, f32x4 (&acc)[NF][8], int f0, int q) {
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int cbase = (f0 + f) * 16 + 4 * q;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && cbase < p.cout) b = *(const f32x4*)(p.bias + cbase);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[f][i] = b;
+  }
+}
+
+// Epilogue of the 4 x 8 x 16-tile kernels (conv_igemm_vs8_kernel, conv_igemm_ld_kernel): per-channel statistics of the
 // wave's 4x4x16 sub-tile half (DPP row sums -> sred[wm + 2 wn][NF*16][2]) and the NDHWC stores.  acc[f][i]: cout fragment f,
 // voxel fragment i = x-row (z = z0 + 2 wm + i / 4, y = y0 + 4 wn + i % 4).
 template <int NF>
@@ -37,13 +53,11 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
   const int ypit = second ? p.y2pitch : p.ypitch;
   const int csub = second ? p.ysplit : 0;
   const int lane_o = (x0 + v) * ypit + 4 * q - csub;
-  float bias[NF][4], s1[NF][4], s2[NF][4];
+  float s1[NF][4], s2[NF][4];
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
-    const int cbase = (f0 + f) * 16 + 4 * q;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      bias[f][rr] = (p.bias && cbase < p.cout) ? p.bias[cbase + rr] : 0.f;
       s1[f][rr] = 0.f;
       s2[f][rr] = 0.f;
     }
@@ -67,12 +81,12 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
           float o[4];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            o[rr] = acc[f][i + e][rr] + bias[f][rr];
+            o[rr] = acc[f][i + e][rr];
             s1[f][rr] += o[rr];
-            s2[f][rr] += o[rr] * o[rr];
+            s2[f][rr] = __builtin_fmaf(o[rr], o[rr], s2[f][rr]);
           }
-          pk[e][0] = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-          pk[e][1] = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+          pk[e][0] = pack2(o[0], o[1]);
+          pk[e][1] = pack2(o[2], o[3]);
         }
         const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
         const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
@@ -93,10 +107,10 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
         float o[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          o[rr] = acc[f][i][rr] + bias[f][rr];
+          o[rr] = acc[f][i][rr];
           const float om = o[rr] * mf;
           s1[f][rr] += om;
-          s2[f][rr] += om * o[rr];
+          s2[f][rr] = __builtin_fmaf(om, o[rr], s2[f][rr]);
         }
         if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
       }
@@ -139,8 +153,10 @@ DEVI void vs8_epilogue_stats(const ConvParams& p, int ty4, const float* sred, in
   }
 }
 
-template <int CK, int DIL, int NF>
-__global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
+// W3 (round 3 experiment, BRATS_CONV_VS8_W3=1): the same kernel compiled for THREE workgroups per CU -- 168 VGPRs, made
+// possible by the ring form of the MMA loop (conv_mma_ring: 20 instead of 32 activation-fragment registers); 3 x 53.4 KB of LDS.
+template <int CK, int DIL, int NF, bool W3 = false>
+__global__ __launch_bounds__(256, W3 ? 3 : 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
   using T = bf16_t;
   using G = ConvGeom<T, 3, CK, DIL, VS8_TY>;
   constexpr int NB = 8, YB = 4;
@@ -177,10 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
   }
 
   f32x4 acc[NF][NB];
-#pragma unroll
-  for (int f = 0; f < NF; ++f)
-#pragma unroll
-    for (int i = 0; i < NB; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  vs8_init_acc<NF>(p, acc, f0, q);
 
   const int lane_b = ((wm * 2) * G::HY * G::HX + wn * YB * G::HX + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;
@@ -235,7 +248,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
     __syncthreads();
     VS8_STAMP(3);  // LDS writes + barrier
     const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
-    conv_mma_chunk<T, 3, CK, DIL, NF, -1, NB, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    if constexpr (W3) conv_mma_ring<NF, 2, 5, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    else conv_mma_chunk<T, 3, CK, DIL, NF, -1, NB, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     VS8_STAMP(4);  // MFMA loop
   }
 
@@ -264,10 +278,10 @@ static inline int conv_vs8_mode() {
   return v;
 }
 
-template <int CK, int DIL, int NF>
+template <int CK, int DIL, int NF, bool W3 = false>
 int conv_launch_vs8(const ConvParams& p0, hipStream_t st) {
   constexpr int lds = conv_vs8_lds_bytes<CK, DIL, NF>();
-  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF>;
+  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF, W3>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   ConvParams p = p0;

@@ -444,3 +444,54 @@ def test_conv3d_cout48_kernels_vs_torch(cin, cin2, cout, n, size, pitch, mode):
     ref1, ref2 = y_ref.double().sum((2, 3, 4)), (y_ref.double() ** 2).sum((2, 3, 4))
     torch.testing.assert_close(st[..., 0], ref1, atol=1e-2 * float(ref2.max()) ** 0.5, rtol=1e-3)
     torch.testing.assert_close(st[..., 1], ref2, atol=1e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("cout,cin,k,mode,cin_off,cin_cnt", [
+    (48, 48, 3, 0, 0, None),     # forward layout, 48-channel chunk (or 24 / 16 by the kernel switch)
+    (48, 96, 3, 1, 0, None),     # input-gradient layout: rows = input channels, taps flipped
+    (40, 32, 3, 0, 0, None),     # rows not a multiple of 16 (zero-padded fragment rows)
+    (96, 64, 3, 1, 16, 32),      # a channel slice of the weight tensor (two-source layers pack their halves separately)
+    (24, 48, 1, 0, 0, None),     # 1x1x1
+    (8, 8, 3, 0, 0, None),       # 8-channel chunk (first layer after padding)
+])
+def test_pack_weights_matches_layout_oracle(dtype, cout, cin, k, mode, cin_off, cin_cnt):
+    """brats_conv3d_pack_weights (16-bit: coalesced reads + LDS transpose, round 3; f32: element-wise) against a numpy
+    statement of the fragment layout out[chunk][ms][row16][lane][e] (csrc/conv_igemm.hpp), bit for bit."""
+    import numpy as np
+    from brats21_amd import ops
+    dev = _dev()
+    w = _rand((cout, cin, k, k, k), 71)
+    packed = ops._pack_weights(w.to(dev), dtype, mode, None, cin_off, cin_cnt, 1, None)
+    torch.cuda.synchronize()
+    taps = k ** 3
+    cnt = cin - cin_off if cin_cnt is None else cin_cnt
+    kdim, rows = (cnt, cout) if mode == 0 else (cout, cnt)
+    ck = ops.conv_chunk(dtype, k, 1, kdim, 0, rows)
+    rows16 = (rows + 15) // 16
+    bf = dtype != torch.float32
+    epl = 8 if bf else 4
+    units = taps * (ck // 8) if bf else taps * ck
+    ms_n = (units + 3) // 4 if bf else (units // 4 + 3) // 4
+    wn = w.numpy().reshape(cout, cin, taps)
+    ref = np.zeros((kdim // ck, ms_n, rows16, 64, epl), dtype=np.float32)
+    for chunk in range(kdim // ck):
+        for ms in range(ms_n):
+            for lane in range(64):
+                q, r = lane >> 4, lane & 15
+                for e in range(epl):
+                    if bf:
+                        g = 4 * ms + q
+                        valid, tap, kc = g < units, g // (ck // 8), chunk * ck + (g % (ck // 8)) * 8 + e
+                    else:
+                        g = 4 * (4 * ms + e) + q
+                        valid, tap, kc = g < units, g // ck, chunk * ck + g % ck
+                    if not valid:
+                        continue
+                    for ft in range(rows16):
+                        row = ft * 16 + r
+                        if row >= rows:
+                            continue
+                        ref[chunk, ms, ft, lane, e] = wn[row, cin_off + kc, tap] if mode == 0 else wn[kc, cin_off + row, taps - 1 - tap]
+    got = packed.view(dtype).float().cpu().numpy().reshape(ref.shape)
+    assert np.array_equal(got, torch.from_numpy(ref).to(dtype).float().numpy())
