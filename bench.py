@@ -375,7 +375,7 @@ def main():
                                f"fwd + deep-supervision Dice + bwd + {args.optimizer}" + (" as one hipGraph" if args.graph else "") +
                                (" (BASELINE.json configs[1])" if (args.model, args.width, args.fp8) == ("equiunet", 48, None) else
                                 " (BASELINE.json configs[2], per-GPU share)" if (args.model, args.width, args.fp8) == ("equiunet_assp_evo", 48, None) else
-                                " (BASELINE.json configs[4], per-GPU share at 2 patches)" if (args.model, args.width) == ("equiunet_assp_evo", 64) and args.fp8 else ""),
+                                f" (BASELINE.json configs[4], per-GPU share at {args.batch} patches, {args.precision} storage)" if (args.model, args.width) == ("equiunet_assp_evo", 64) and args.fp8 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
         "roofline": roofline,
     }

@@ -4,14 +4,14 @@
 # usage: bash scripts/final_profile.sh [tag]     (tag = round prefix of the files copied to profiles/, e.g. r02)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
-python3 bench.py --steps 10 --warmup 3 --kernel-table > $out/bench.json 2> $out/conv_table.txt
+python3 bench.py --steps 20 --warmup 5 --kernel-table > $out/bench.json 2> $out/conv_table.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > $out/bench_profiled.log 2>&1
 cp $out/stats/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 bash scripts/pmc.sh final/pmc scripts/prof_conv.py all > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc > $out/pmc_conv.txt
 bash scripts/pmc.sh final/pmc_dom scripts/prof_conv.py dom > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc_dom > $out/pmc_dominant.txt
-python3 scripts/pmc_report.py final/pmc_dom --json "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128" "conv_igemm_vs8_kernel<24, 1, 3>" > $out/pmc_dominant.json
+python3 scripts/pmc_report.py final/pmc_dom --json "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128" "conv_igemm_vs8_kernel<24, 1, 3, false>" > $out/pmc_dominant.json
 python3 bench.py --steps 10 --warmup 3 --fp8 all --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_fp8.json
 python3 bench.py --steps 10 --warmup 3 --fp8 all --graph --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_fp8_graph.json
 python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp.json
@@ -22,4 +22,7 @@ cp $out/stats_assp/*/*kernel_stats.csv $out/bench_assp_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_assp64 -- python3 bench.py --model equiunet_assp_evo --width 64 --fp8 all --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > /dev/null 2>&1
 cp $out/stats_assp64/*/*kernel_stats.csv $out/bench_assp64_fp8_kernel_stats.csv
 PYTHONPATH=. python3 scripts/time_wgrad_f8.py > $out/wgrad_f8_table.txt 2>/dev/null
+python3 bench.py --precision fp16 --steps 10 --warmup 3 --infer-headline-only --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_fp16.json
+python3 bench.py --model equiunet_assp_evo --width 64 --precision fp16 --batch 4 --fp8 all --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp64_fp16_fp8_b4.json
+BRATS_FORCE_DDP=1 python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_ddp1_forced.json
 tail -c 600 $out/bench.json; echo; cat $out/pmc_conv.txt | cut -c1-250
