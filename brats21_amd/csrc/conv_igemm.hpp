@@ -113,7 +113,15 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       constexpr int k = k_;
       constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
 #pragma unroll
+#ifdef BRATS_ABL_NOWLOAD  // ablation (diagnostic build only, WRONG results): no weight loads inside the MMA loop -- the first WD + 1
+      // macro-steps' fragments are reused; prices what the MFMA waves' own vector-memory stream costs them
+      for (int f = 0; f < NF; ++f) {
+        if constexpr (k <= WD) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
+        else OPAQUE_V(a[k % (WD + 1)][f]);
+      }
+#else
       for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
+#endif
     };
     auto read_b = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
@@ -194,7 +202,14 @@ DEVI void conv_mma_ring(const char* ldsb, int lane_b, int q, const void* wpk_chu
   auto load_a = [&](auto k_) {
     constexpr int k = k_;
 #pragma unroll
-    for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)k * rows16 + f) * 64];
+    for (int f = 0; f < NF; ++f) {
+#ifdef BRATS_ABL_NOWLOAD  // (ablation, see conv_mma_chunk)
+      if constexpr (k <= WD) a[k % (WD + 1)][f] = wp0[((size_t)k * rows16 + f) * 64];
+      else OPAQUE_V(a[k % (WD + 1)][f]);
+#else
+      a[k % (WD + 1)][f] = wp0[((size_t)k * rows16 + f) * 64];
+#endif
+    }
   };
   auto read_b = [&](auto j_) {
     constexpr int j = j_, k = j / NB, i = j % NB;

@@ -79,7 +79,11 @@ DEVI void conv_ld_loader(const ConvParams& p, char* lds, int lw, int lane, int n
     auto issue = [&](auto k_) {
       constexpr int k = k_;
       const int j = lw + NLW * k;  // scalar
+#ifdef BRATS_ABL_NOHALO  // (ablation, diagnostic build only: DMA kept, all from one 16 KB window = L1 hits with non-zero data)
+      if (j < L::NDMA) lds_dma16_async(rs, dst + j * 1024, ((voff[k] * pb + addend) & 0x3ff0) | okm[k]);
+#else
       if (j < L::NDMA) lds_dma16_async(rs, dst + j * 1024, (voff[k] * pb + addend) | okm[k]);
+#endif
     };
     if (chunk == 0) static_for<0, L::DPW>([&](auto k_) { decode(k_); issue(k_); });
     else static_for<0, L::DPW>([&](auto k_) { issue(k_); });

@@ -90,7 +90,11 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
         }
         const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
         const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+#ifdef BRATS_ABL_NOSTORE  // ablation (diagnostic build only, WRONG results): the epilogue without its global stores
+        { u32x4 keep_ = u32x4{lo[0], hi[0], lo[1], hi[1]}; asm volatile("" :: "v"(keep_)); }
+#else
         *(u32x4*)(rowp + lane_w + (f0 + f) * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
+#endif
       }
     }
   } else {
@@ -226,7 +230,12 @@ __global__ __launch_bounds__(256, W3 ? 3 : 2) void conv_igemm_vs8_kernel(const C
       const int rb = ((gz * p.H + gy) * p.W + (x0 - G::R)) * pb;
 #pragma unroll
       for (int j = 0; j < IPR; ++j) {
+#ifdef BRATS_ABL_NOHALO  // ablation (diagnostic build only, WRONG results): halo loads without their memory traffic
+        // (loads kept, but all from one 16 KB window: L1 hits with non-zero data -- zeros would raise the MFMA clock)
+        const int vo = (row_ok && hx_part[j] >= 0) ? (rb + goff[j]) & 0x3ff0 : -1;
+#else
         const int vo = (row_ok && hx_part[j] >= 0) ? rb + goff[j] : -1;
+#endif
         r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
       }
     }

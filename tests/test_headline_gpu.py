@@ -253,3 +253,35 @@ def test_config4_assp64_fp16_fp8_four_patches():
     print(f"\nASSP-64 fp16 + e4m3, 4x4x128^3: losses {runs[0][0]}, loss scale {runs[0][2]}")
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     assert runs[0][0][2] < runs[0][0][0]
+
+
+def test_assp48_full_size_patch_vs_oracle():
+    """BASELINE.json configs[2]'s model at its patch size: EquiUnetASSPEvo width 48 on 1x4x128^3 (torch-default init, the
+    bench's image) against the CPU oracle (oracle/unet.py: networks/equiunet2021.py:289-333 incl. the MONAI stubs) --
+    f32 mode: logits and both deep heads within 1e-3; bf16 / fp16 modes: deviation printed, hard Dice within 1e-3."""
+    _cpu_threads()
+    m = _get("equiunet_assp_evo", 48)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    s3 = (128, 128, 128)
+    x = synth.random_image(1, 4, s3, seed=1234)
+    t = synth.nested_spheres(1, s3)
+    with torch.no_grad():
+        ref, ref_deeps = unet.assp_evo_forward(sd, x)
+        m.precision = "fp32"
+        out, deeps = m(x.to(DEV))
+        err = float((out.cpu() - ref).abs().max())
+        derr = [float((d.cpu() - r).abs().max()) for d, r in zip(deeps, ref_deeps)]
+        print(f"\nASSP-48 @128^3 f32: logits max abs err {err:.3e} (|logits| max {float(ref.abs().max()):.2f}); deep heads {derr}")
+        assert err < LOGIT_ATOL and max(derr) < LOGIT_ATOL, (err, derr)
+        d_ref = unet.hard_dice(ref, t)
+        for prec in ("bf16", "fp16"):
+            m.precision = prec
+            o = m(x.to(DEV))[0].float().cpu()
+            dev = (o - ref).abs()
+            d = unet.hard_dice(o, t)
+            print(f"ASSP-48 @128^3 {prec}: max {float(dev.max()):.3e} mean {float(dev.mean()):.3e}; hard Dice oracle {d_ref.flatten().tolist()} "
+                  f"{prec} {d.flatten().tolist()}")
+            assert torch.isfinite(o).all()
+            assert float((d_ref - d).abs().max()) <= DICE_ATOL, (prec, d_ref, d)
+    m.precision = "auto"
