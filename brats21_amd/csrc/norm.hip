@@ -5,6 +5,7 @@
 // group variance, x*sigmoid(x) numerator).
 #include "twin_begin.hpp"
 #include "common.hpp"
+#include "se.hpp"
 
 // ---- statistics finalize ---------------------------------------------------------------------------
 // stage 1: part[z][n][c] = sum over a slice of the tiles of the conv epilogue's per-tile partials (f64), one block per
@@ -618,7 +619,9 @@ extern "C" int BRATS_API(brats_evonorm_finalize)(const float* stats, int tiles_p
   return 0;
 }
 
-DEVI float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup): the three
+// EvoNorm passes are VALU-bound at 128^3 (28 VALU instructions per element with the division, ~19 without)
+DEVI float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 template <typename T, bool NT = false>
 __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
@@ -709,18 +712,22 @@ extern "C" int BRATS_API(brats_evonorm_fwd)(const void* x, int xpitch, const flo
 
 // backward pass 1: red[n][c] = { sum_v dz, sum_v dz * x*sigmoid(x), sum_v dz * d/dx[x*sigmoid(x)] }
 // (the third sum gives the bias gradient of the preceding convolution without another pass over dx)
-template <typename T, bool NT = false>
+// RAW5 (brats_evonorm_se_bwd): dz is the SE block's output gradient `do` as it is, and two more sums -- sum_v x*sigmoid(x),
+// sum_v d/dx[x*sigmoid(x)] -- come along: the SE backward (se.hip) derives d loss / d gate and the three sums above for
+// dz = do * gscale + gadd from these five (se.hpp), so that no pass computes sum_v do * z on its own.
+template <typename T, bool NT = false, bool RAW5 = false>
 __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                           float* __restrict__ red, int voxels, int C, const float* __restrict__ gscale,
                                           const float* __restrict__ gadd) {
   constexpr int VW = 16 / sizeof(T);
+  constexpr int NV = RAW5 ? 5 : 3;
   extern __shared__ float sm[];
   const int n = blockIdx.y;
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
-  float a1[VW], a2[VW], a3[VW];
+  float a1[VW], a2[VW], a3[VW], a4[VW], a5[VW];
 #pragma unroll
-  for (int j = 0; j < VW; ++j) a1[j] = a2[j] = a3[j] = 0.f;
+  for (int j = 0; j < VW; ++j) a1[j] = a2[j] = a3[j] = a4[j] = a5[j] = 0.f;
   if (myvl < vl_n) {
     const T* dzb = dz + (size_t)n * voxels * dzpitch;
     const T* xb = x + (size_t)n * voxels * xpitch;
@@ -732,11 +739,20 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
     auto body = [&](const float* g_, const float* xx) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
-        const float g = g_[j] * gs[j] + ga[j];
         const float sg = sigmoidf_(xx[j]);
-        a1[j] += g;
-        a2[j] += g * xx[j] * sg;
-        a3[j] += g * sg * (1.f + xx[j] * (1.f - sg));
+        if constexpr (RAW5) {
+          const float num = xx[j] * sg, dnum = sg * (1.f + xx[j] * (1.f - sg));
+          a1[j] += g_[j];
+          a2[j] += g_[j] * num;
+          a3[j] += g_[j] * dnum;
+          a4[j] += num;
+          a5[j] += dnum;
+        } else {
+          const float g = g_[j] * gs[j] + ga[j];
+          a1[j] += g;
+          a2[j] += g * xx[j] * sg;
+          a3[j] += g * sg * (1.f + xx[j] * (1.f - sg));
+        }
       }
     };
     const size_t stride = (size_t)gridDim.x * vl_n;
@@ -757,20 +773,24 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
       body(g0, x0);
     }
   }
-  float* scr = sm;  // [vl_n][C][3]
+  float* scr = sm;  // [vl_n][C][NV]
   if (myvl < vl_n) {
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      scr[(myvl * C + c0 + j) * 3] = a1[j];
-      scr[(myvl * C + c0 + j) * 3 + 1] = a2[j];
-      scr[(myvl * C + c0 + j) * 3 + 2] = a3[j];
+      scr[(myvl * C + c0 + j) * NV] = a1[j];
+      scr[(myvl * C + c0 + j) * NV + 1] = a2[j];
+      scr[(myvl * C + c0 + j) * NV + 2] = a3[j];
+      if constexpr (RAW5) {
+        scr[(myvl * C + c0 + j) * NV + 3] = a4[j];
+        scr[(myvl * C + c0 + j) * NV + 4] = a5[j];
+      }
     }
   }
   __syncthreads();
-  float* part = red + (size_t)gridDim.y * C * 3 + ((size_t)blockIdx.x * gridDim.y + n) * C * 3;  // per-block partials
-  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+  float* part = red + (size_t)gridDim.y * C * NV + ((size_t)blockIdx.x * gridDim.y + n) * C * NV;  // per-block partials
+  for (int i = threadIdx.x; i < NV * C; i += blockDim.x) {
     float t = 0.f;
-    for (int l = 0; l < vl_n; ++l) t += scr[l * C * 3 + i];
+    for (int l = 0; l < vl_n; ++l) t += scr[l * C * NV + i];
     part[i] = t;
   }
 }
@@ -906,6 +926,66 @@ extern "C" int BRATS_API(brats_evonorm_bwd)(const void* dz, int dzpitch, const v
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
                        xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
   }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// EvoNorm backward of the layer a ResidualSELayer sits on, with the SE backward in the middle (se.hpp): pass 1 over (dout, x)
+// with the five raw sums -> brats_se_bwd_launch (d loss / d gate from the sums; gadd, the SE parameter gradients, the three
+// sums for dz = dout * gate1p + gadd) -> pass 2.  Replaces brats_channel_dot + brats_se_bwd + brats_evonorm_bwd(gscale, gadd):
+// one pass over two tensors less per block.  ws: brats_chan_ws_floats(N, C, 5) + N * C * 3 floats.
+extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, const void* x, int xpitch, const float* mean_rstd,
+                                    const float* gamma, const float* beta, void* dx, int dxpitch, float* ws, float* dgamma,
+                                    float* dbeta, const double* chan_sums, float* dconvbias, const float* se_chansum,
+                                    const float* hidden, const float* gate1p, const float* w1, const float* w2, float* gadd,
+                                    float* dw1, float* db1, float* dw2, float* db2, int Ch, int dtype, int N, int voxels, int C,
+                                    int groups, float* amax, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dout || !x || !dx || !ws || !mean_rstd || !gamma || !beta || !gate1p || !gadd)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: null pointer");
+  if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: dconvbias needs the forward per-channel sums");
+  if (C % vw || C % groups || dopitch % vw || xpitch % vw || dxpitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: C=%d / pitches must be multiples of %d", C, vw);
+  hipStream_t st = (hipStream_t)s;
+  const int cv = C / vw, vl = 256 / cv;
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const size_t cap1 = big ? CHAN_MAX_BLOCKS : 512, cap2 = big ? 8192 : 2048;
+  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx)), N);
+  const size_t lds1 = (size_t)(vl * C * 5) * sizeof(float);
+  dim3 g2((unsigned)(gx < 1 ? 1 : (gx > cap2 ? cap2 : gx)), N);
+  const size_t lds2 = (size_t)3 * C * sizeof(float);
+  float* raw5 = ws;
+  float* red3 = ws + (size_t)(1 + CHAN_MAX_BLOCKS) * N * C * 5;
+  if (big)
+    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, true, true>), g1, dim3(256), lds1, st, (const bf16_t*)dout, dopitch,
+                       (const bf16_t*)x, xpitch, raw5, voxels, C, (const float*)nullptr, (const float*)nullptr);
+  else if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, false, true>), g1, dim3(256), lds1, st, (const bf16_t*)dout, dopitch,
+                       (const bf16_t*)x, xpitch, raw5, voxels, C, (const float*)nullptr, (const float*)nullptr);
+  else
+    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<float, false, true>), g1, dim3(256), lds1, st, (const float*)dout, dopitch,
+                       (const float*)x, xpitch, raw5, voxels, C, (const float*)nullptr, (const float*)nullptr);
+  BRATS_CHECK_LAUNCH();
+  brats_ordered_sum(raw5 + (size_t)N * C * 5, raw5, (int)g1.x, N * C * 5, st);
+  SeFold fold;
+  fold.raw5 = raw5; fold.mean_rstd = mean_rstd; fold.gamma = gamma; fold.beta = beta; fold.red3 = red3; fold.groups = groups;
+  fold.voxels = (float)voxels;
+  if (int rc = brats_se_bwd_launch(nullptr, fold, se_chansum, 1.f / (float)voxels, hidden, gate1p, w1, w2, gadd, dw1, db1, dw2, db2,
+                                   N, C, Ch, st))
+    return rc;
+  if (big)
+    hipLaunchKernelGGL((evonorm_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dout, dopitch, (const bf16_t*)x,
+                       xpitch, mean_rstd, gamma, red3, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups,
+                       (uint32_t*)amax, gate1p, gadd);
+  else if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dout, dopitch, (const bf16_t*)x,
+                       xpitch, mean_rstd, gamma, red3, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups,
+                       (uint32_t*)amax, gate1p, gadd);
+  else
+    hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dout, dopitch, (const float*)x,
+                       xpitch, mean_rstd, gamma, red3, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups,
+                       (uint32_t*)amax, gate1p, gadd);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

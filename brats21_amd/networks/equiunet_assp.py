@@ -229,13 +229,17 @@ def _block_bwd(cx, rec, do, need_dx=True):
     blk, r1, r2, z2, cs, hidden, gate1p = rec
     s = blk.conv_conv_se
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
-    n, d, h, w, c = z2.shape
-    dgate = ops.channel_dot(do, z2)  # [N, C] = sum_v do * z2
-    gadd, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, cs, d * h * w, hidden, gate1p, fc1.weight, fc2.weight)
-    for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2)):
+    # one call: pass 1 of the EvoNorm backward over (do, y) also yields d loss / d gate = sum_v do * z2 (linear in its sums),
+    # the SE backward runs on those, pass 2 reads the gradient as do * (1 + gate) + dgap / V  (csrc/se.hpp)
+    conv, evo, saved, y, mr, chan = r2
+    amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
+    dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2 = ops.evonorm_se_bwd(do, y, mr, _flat(evo.gamma), _flat(evo.beta), cs, hidden, gate1p,
+                                                                    fc1.weight, fc2.weight, 8, chan=chan, amax=amax)
+    if amax is not None:
+        dy._amax = amax
+    for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2), (evo.gamma, dgamma), (evo.beta, dbeta)):
         cx.put(prm, g)
-    # d out / d z2 = do * (1 + gate) + dgap / V per (n, channel): read inside the EvoNorm backward instead of a pass of its own
-    dz1 = _conv_evo_bwd(cx, r2, do, gscale=gate1p, gadd=gadd)
+    dz1 = _conv_any_bwd(cx, conv, saved, dy, True, db=dcb)
     return _conv_evo_bwd(cx, r1, dz1, need_dx)
 
 

@@ -815,6 +815,33 @@ def se_gate_bwd(dgate, chansum, voxels, hidden, gate1p, w1, w2):
     return gadd, dw1, db1, dw2, db2
 
 
+def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None):
+    """EvoNorm backward of the layer under a ResidualSELayer with the SE backward folded in (csrc/se.hpp): `do` is the
+    gradient of the SE block's OUTPUT.  -> (dy, dgamma, dbeta, dconvbias|None, dW1, db1, dW2, db2)."""
+    dop, c, dopitch = _desc(do)
+    yp, _, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    ch = w1.shape[0]
+    dev = y.device
+    dy = new_act(n, d, h, w, c, y.dtype, dev)
+    ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 5) + n * c * 3, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dcb = torch.empty(c, dtype=torch.float32, device=dev) if chan is not None else None
+    gadd = torch.empty((n, c), dtype=torch.float32, device=dev)
+    dw1, db1 = torch.empty((ch, c), dtype=torch.float32, device=dev), torch.empty((ch,), dtype=torch.float32, device=dev)
+    dw2, db2 = torch.empty((c, ch), dtype=torch.float32, device=dev), torch.empty((c,), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().brats_evonorm_se_bwd(dop, dopitch, yp, ypitch, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), dy.data_ptr(), c,
+                                               ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                               chan.data_ptr() if chan is not None else None,
+                                               dcb.data_ptr() if dcb is not None else None, _f32(se_chansum.contiguous()),
+                                               _f32(hidden), _f32(gate1p), _f32(w1.detach().contiguous()),
+                                               _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
+                                               dw2.data_ptr(), db2.data_ptr(), ch, _code(y.dtype), n, d * h * w, c, groups,
+                                               _f32(amax), _stream()), "evonorm_se_bwd")
+    return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2
+
+
 _DCONV_JOB = np.dtype([("term", [("x", "<u8"), ("w", "<u8"), ("xpitch", "<i4"), ("cin", "<i4"), ("ksize", "<i4"), ("dil", "<i4")], (4,)),
                        ("nterms", "<i4"), ("rows", "<i4"), ("bias", "<u8"), ("y", "<u8"), ("ypitch", "<i4"), ("reserved", "<i4")])
 # == brats_dconv_job (include/brats_hip.h)

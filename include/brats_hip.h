@@ -220,7 +220,7 @@ int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, co
                       brats_stream_t s);
 /* ---- squeeze-excite (MONAI ResidualSELayer(3, C, r = 2, relu, sigmoid), equiunet2021.py:204-205): per-(n,channel)
  * reductions over voxels, per-(n,channel) scale(+add) passes, and the gate itself (round 3: ONE launch forward, ONE launch
- * backward instead of ~20 ATen launches per block):
+ * backward instead of ~20 ATen launches per block; up to 16 workgroups of 1024 threads, csrc/se.hip):
  *   gate1p[n][c] = 1 + sigmoid(b2 + W2 relu(b1 + W1 (chansum[n] * inv_vox)))      W1 [Ch][C], W2 [C][Ch] (nn.Linear layout)
  *   hidden[n][j] = the post-ReLU hidden vector (saved for the backward)
  * backward: dgate[n][c] = d loss / d gate (= brats_channel_dot(dout, z)) -> gadd[n][c] = (d loss / d gap) * inv_vox (the
@@ -230,6 +230,18 @@ int brats_se_fwd(const float* chansum, float inv_vox, const float* w1, const flo
 int brats_se_bwd(const float* dgate, const float* chansum, float inv_vox, const float* hidden, const float* gate1p,
                  const float* w1, const float* w2, float* gadd /*[N][C]*/, float* dw1, float* db1, float* dw2, float* db2,
                  int N, int C, int Ch, brats_stream_t s);
+/* The EvoNorm backward of the layer a ResidualSELayer sits on (ConvEvoBlockCorrected, equiunet2021.py:192-209) with the SE
+ * backward in the middle: pass 1 over (dout, x) collects five raw per-(n, channel) sums, from which brats_se_bwd's work is
+ * done WITHOUT brats_channel_dot's pass (d loss / d gate = sum_v dout * z is linear in them), then pass 2 reads the
+ * gradient as dout * gate1p + gadd.  Same results as brats_channel_dot + brats_se_bwd + brats_evonorm_bwd(gscale = gate1p,
+ * gadd) up to f32 summation order.  ws: brats_chan_ws_floats(N, C, 5) + N * C * 3 floats; se_chansum = the `chansum` of
+ * brats_evonorm_fwd ([N][C] = sum_v z); outputs as in brats_evonorm_bwd and brats_se_bwd. */
+int brats_evonorm_se_bwd(const void* dout, int dopitch, const void* x, int xpitch, const float* mean_rstd, const float* gamma,
+                         const float* beta, void* dx, int dxpitch, float* ws, float* dgamma, float* dbeta,
+                         const double* chan_sums, float* dconvbias, const float* se_chansum, const float* hidden,
+                         const float* gate1p, const float* w1, const float* w2, float* gadd, float* dw1, float* db1,
+                         float* dw2, float* db2, int Ch, int dtype, int N, int voxels, int C, int groups, float* amax,
+                         brats_stream_t s);
 int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,
                       int dtype, int N, int voxels, int C, brats_stream_t s);
 int brats_channel_scale(const void* a, int apitch, const float* scale /*[N][C]*/, const float* add /*[N][C] or NULL*/,

@@ -218,6 +218,41 @@ def test_evonorm_bwd_with_folded_se_gradient_map():
                 torch.testing.assert_close(a.float(), b.float(), atol=tol * float(b.float().abs().max()), rtol=tol)
 
 
+@pytest.mark.parametrize("n,c,size", [(2, 48, (6, 8, 16)), (3, 96, (4, 4, 8)), (2, 384, (2, 4, 4)), (1, 16, (5, 7, 9))])
+def test_evonorm_se_bwd_matches_three_call_composition(n, c, size):
+    """brats_evonorm_se_bwd (pass 1 with five raw sums -> SE backward on the sums -> pass 2; csrc/se.hpp) against the
+    composition it replaces: channel_dot(do, z) -> se_gate_bwd -> evonorm_bwd(do, gscale = 1 + gate, gadd).  The same
+    mathematics with the sums taken in a different order: f32 within 2e-5 of the largest entry; bf16 within one rounding of
+    the stored gradient."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 + c)
+    ch, vox = c // 2, size[0] * size[1] * size[2]
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1e-2)):
+        y = torch.randn((n, *size, c), generator=g).to(dev).to(dt)
+        do = (torch.randn((n, *size, c), generator=g) * 0.1).to(dev).to(dt)
+        mr = torch.stack([torch.randn((n, 8), generator=g) * 0.1, torch.rand((n, 8), generator=g) + 0.5], -1).to(dev).contiguous()
+        gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(c, generator=g) * 0.3).to(dev)
+        w1, b1 = (torch.randn((ch, c), generator=g) * 0.3).to(dev), (torch.randn((ch,), generator=g) * 0.2).to(dev)
+        w2, b2 = (torch.randn((c, ch), generator=g) * 0.3).to(dev), (torch.randn((c,), generator=g) * 0.2).to(dev)
+        z, cs = ops.evonorm(y, mr, gamma, beta, 8, want_chansum=True)
+        gate1p, hidden = ops.se_gate(cs, vox, w1, b1, w2, b2)
+        dgate = ops.channel_dot(do, z)
+        gadd, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, cs, vox, hidden, gate1p, w1, w2)
+        dy, dgamma, dbeta, _ = ops.evonorm_bwd(do, y, mr, gamma, 8, gscale=gate1p, gadd=gadd)
+        got = ops.evonorm_se_bwd(do, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8)
+        names = ("dy", "dgamma", "dbeta", "dcb", "dw1", "db1", "dw2", "db2")
+        for name, a, b in zip(names, got, (dy, dgamma, dbeta, None, dw1, db1, dw2, db2)):
+            if b is None:
+                assert a is None
+                continue
+            scale = float(b.float().abs().max()) + 1e-30
+            assert float((a.float() - b.float()).abs().max()) <= tol * scale, (name, str(dt))
+        again = ops.evonorm_se_bwd(do, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8)
+        assert all(torch.equal(a, b) for a, b in zip(again, got) if a is not None)  # bitwise reproducible
+
+
 @pytest.mark.parametrize("n,c", [(2, 48), (1, 16), (4, 384), (3, 96)])
 def test_se_gate_kernels_vs_torch_autograd(n, c):
     """csrc/se.hip (one launch forward, one backward) against the MONAI ResidualSELayer arithmetic in torch f64:
