@@ -285,14 +285,43 @@ extern "C" int BRATS_API(brats_affine_act_fwd)(const void* y, int ypitch, const 
 // A thread owns one 16-byte channel vector (fixed for the whole kernel) and walks voxels: its per-channel constants
 // live in registers (read from LDS per element they made both passes LDS-bound at ~3.5 TB/s), two voxels are in
 // flight per iteration.
-template <typename T, bool HEAVY, bool NT = false>
+// 16 bytes of a tensor kept as loaded (4 registers) until the arithmetic wants the 8 (4) floats: the head-fold passes hold four
+// voxels per thread in flight, unpacked up front they cost 32 registers and an occupancy step
+template <typename T> struct Raw16;
+template <> struct Raw16<bf16_t> {
+  typedef u32x4 type;
+  template <bool NT> static DEVI type load(const bf16_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)p); else return *(const u32x4*)p;
+  }
+  static DEVI void unpack(const type& v, float* o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2(v[i], o[2 * i], o[2 * i + 1]);
+  }
+};
+template <> struct Raw16<float> {
+  typedef f32x4 type;
+  template <bool NT> static DEVI type load(const float* p) { return *(const f32x4*)p; }
+  static DEVI void unpack(const type& v, float* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+
+// HK > 0 (brats_gn_act_bwd_head): the layer's output feeds ONLY a 1x1x1 head convolution (the network's last layer), so its
+// gradient is dz[v][c] = sum_k dl[k][v] * w[k][c] with K = HK logit planes: computed here from the 12 bytes of dl per voxel
+// instead of being written (bf16, 2 * C bytes per voxel) by brats_head_bwd and read back by both passes; the head's own
+// weight / bias gradients, sum_v dl[k][v] * z[v][c] and sum_v dl[k][v], come out of pass 1, which has z = act(pre) at hand.
+struct HeadFold {
+  const float* dl = nullptr;  // [N][HK][voxels]
+  const float* w = nullptr;   // [HK][C]
+  float* hpart = nullptr;     // pass 1: per-block partials [n * gridDim.x + block][HK * C + HK]
+};
+template <typename T, bool HEAVY, bool NT = false, int HK = 0>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                             int ypitch, const float* __restrict__ scale_shift,
                                                             const float* __restrict__ mean_rstd, float* __restrict__ red, int act,
-                                                            SlopeArg sl, int voxels, int C, int groups) {
+                                                            SlopeArg sl, int voxels, int C, int groups, HeadFold hf) {
   constexpr int VW = 16 / sizeof(T);
+  constexpr int HKA = HK > 0 ? HK : 1;
   const float slope = sl.p ? *sl.p : sl.v;
-  extern __shared__ float sm[];  // reduction scratch [vl_n][C][2]
+  extern __shared__ float sm[];  // reduction scratch [vl_n][C][2] (+ [vl_n][HK][C] + [vl_n][HK])
   const int n = blockIdx.y;
   const int cpg = C / groups;
   const int cv = C / VW;
@@ -300,8 +329,15 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv;
   const int c0 = mycv * VW;
   float a1[VW], a2[VW];
+  float aw[HKA][VW], ab[HKA];
 #pragma unroll
   for (int j = 0; j < VW; ++j) a1[j] = a2[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < HKA; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) aw[k][j] = 0.f;
+  }
   if (myvl < vl_n) {
     float sc[VW], sh[VW], rs[VW], mo[VW];  // pre = y*sc + sh ; xhat = y*rs + mo
 #pragma unroll
@@ -317,6 +353,57 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     const T* yb = y + (size_t)n * voxels * ypitch + c0;
     const size_t stride = (size_t)gridDim.x * vl_n;
     size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+    if constexpr (HK > 0) {
+      float wr[HKA][VW];
+#pragma unroll
+      for (int k = 0; k < HK; ++k)
+#pragma unroll
+        for (int j = 0; j < VW; ++j) wr[k][j] = hf.w[k * C + c0 + j];
+      const float* dl = hf.dl + (size_t)n * HK * voxels;
+      const float nslope = act == BRATS_ACT_RELU ? 0.f : slope;
+      // a2 = sum u * xhat = rs * sum(u * y) + mo * sum(u): the loop keeps sum(u * y), the affine map is applied once after it
+      auto hbody = [&](const float* g, const float* yy) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          float d = 0.f;
+#pragma unroll
+          for (int k = 0; k < HK; ++k) d += g[k] * wr[k][j];
+          const float pre = yy[j] * sc[j] + sh[j];
+          const bool pos = pre > 0.f;  // relu = leakyrelu with slope 0: selects, no branches on `act` per element
+          const float u = d * (pos ? 1.f : nslope);
+          a1[j] += u;
+          a2[j] += u * yy[j];
+          const float z = pos ? pre : pre * nslope;
+#pragma unroll
+          for (int k = 0; k < HK; ++k) aw[k][j] += g[k] * z;
+        }
+#pragma unroll
+        for (int k = 0; k < HK; ++k) ab[k] += g[k];
+      };
+      // four voxels (4 x 16 bytes of y + 4 x HK floats of dl) in flight per thread; a wave's loads cover adjacent voxels.
+      // (With two voxels in flight the pass was latency-bound at 1.5 TB/s.)
+      auto step = [&](size_t v0, auto cnt) {
+        constexpr int NV = decltype(cnt)::value;
+        typename Raw16<T>::type yr[NV];
+        float gq[NV][HKA];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) yr[i] = Raw16<T>::template load<NT>(yb + (v0 + i * stride) * ypitch);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+          for (int k = 0; k < HK; ++k) gq[i][k] = dl[(size_t)k * voxels + v0 + i * stride];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          float yy[VW];
+          Raw16<T>::unpack(yr[i], yy);
+          hbody(gq[i], yy);
+        }
+      };
+      for (; vox + 3 * stride < (size_t)voxels; vox += 4 * stride) step(vox, std::integral_constant<int, 4>{});
+      for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+#pragma unroll
+      for (int j = 0; j < VW; ++j) a2[j] = a2[j] * rs[j] + mo[j] * a1[j];
+    } else {
     auto body = [&](const float* g, const float* yy) {
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
@@ -346,6 +433,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
       vload<T, VW, NT>(yb + vox * ypitch, y0);
       body(g0, y0);
     }
+    }
   }
   // block reduction over voxel lanes through LDS, then one atomic per channel per block
   float* scr = sm;  // [vl_n][C][2]
@@ -363,6 +451,29 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     float t = 0.f;
     for (int l = 0; l < vl_n; ++l) t += scr[l * C * 2 + i];
     part[i] = t;
+  }
+  if constexpr (HK > 0) {  // the head's weight / bias gradient partials: [HK][C] + [HK] per block, added in block order afterwards
+    float* hs = sm + vl_n * C * 2;  // [vl_n][HK][C] + [vl_n][HK]
+    if (myvl < vl_n) {
+#pragma unroll
+      for (int k = 0; k < HK; ++k) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) hs[(myvl * HK + k) * C + c0 + j] = aw[k][j];
+        if (mycv == 0) hs[vl_n * HK * C + myvl * HK + k] = ab[k];
+      }
+    }
+    __syncthreads();
+    float* hp = hf.hpart + ((size_t)n * gridDim.x + blockIdx.x) * (HK * C + HK);
+    for (int i = threadIdx.x; i < HK * C; i += blockDim.x) {
+      float t = 0.f;
+      for (int l = 0; l < vl_n; ++l) t += hs[l * HK * C + i];
+      hp[i] = t;
+    }
+    if ((int)threadIdx.x < HK) {
+      float t = 0.f;
+      for (int l = 0; l < vl_n; ++l) t += hs[vl_n * HK * C + l * HK + threadIdx.x];
+      hp[HK * C + threadIdx.x] = t;
+    }
   }
 }
 
@@ -389,15 +500,16 @@ __global__ void __launch_bounds__(256) gn_bwd_finish_kernel(float* __restrict__ 
 
 // pass 2: dy = rstd*(u*gamma - m1 - xhat*m2) = u*A + y*B + K with per-channel A = rstd*gamma, B = -rstd^2*m2,
 // K = rstd*(mean*rstd*m2 - m1);  block (0,0) also finishes dgamma/dbeta
-template <typename T, bool HEAVY, bool NT = false>
+template <typename T, bool HEAVY, bool NT = false, int HK = 0>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                            int ypitch, const float* __restrict__ scale_shift,
                                                            const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ red, T* __restrict__ dy, int dypitch,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int act,
                                                            SlopeArg sl, int N, int voxels, int C, int groups,
-                                                           uint32_t* __restrict__ amax) {
+                                                           uint32_t* __restrict__ amax, HeadFold hf) {
   constexpr int VW = 16 / sizeof(T);
+  constexpr int HKA = HK > 0 ? HK : 1;
   const float slope = sl.p ? *sl.p : sl.v;
   extern __shared__ float sm[];
   float* m12 = sm;  // [groups][2]: m1, m2 per group
@@ -457,6 +569,46 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
       for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
     }
   };
+  if constexpr (HK > 0) {
+    float wr[HKA][VW];
+#pragma unroll
+    for (int k = 0; k < HK; ++k)
+#pragma unroll
+      for (int j = 0; j < VW; ++j) wr[k][j] = hf.w[k * C + c0 + j];
+    const float* dl = hf.dl + (size_t)n * HK * voxels;
+    const float nslope = act == BRATS_ACT_RELU ? 0.f : slope;
+    auto step = [&](size_t v0, auto cnt) {  // four voxels in flight per thread, as in pass 1
+      constexpr int NV = decltype(cnt)::value;
+      typename Raw16<T>::type yr[NV];
+      float gq[NV][HKA];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) yr[i] = Raw16<T>::template load<NT>(yb + (v0 + i * stride) * ypitch);
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int k = 0; k < HK; ++k) gq[i][k] = dl[(size_t)k * voxels + v0 + i * stride];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float yy[VW], o[VW];
+        Raw16<T>::unpack(yr[i], yy);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          float d = 0.f;
+#pragma unroll
+          for (int k = 0; k < HK; ++k) d += gq[i][k] * wr[k][j];
+          const float u = d * (yy[j] * sc[j] + sh[j] > 0.f ? 1.f : nslope);
+          o[j] = u * ca[j] + (yy[j] * cb[j] + ck[j]);
+        }
+        if (amax) {
+#pragma unroll
+          for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
+        }
+        vstore<T, VW, NT>(dyb + (v0 + i * stride) * dypitch, o);
+      }
+    };
+    for (; vox + 3 * stride < (size_t)voxels; vox += 4 * stride) step(vox, std::integral_constant<int, 4>{});
+    for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+  } else {
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float g0[VW], y0[VW], g1[VW], y1[VW], o0[VW], o1[VW];
     vload<T, VW, NT>(dzb + vox * dzpitch, g0);
@@ -475,73 +627,91 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
     body(g0, y0, o0);
     vstore<T, VW, NT>(dyb + vox * dypitch, o0);
   }
+  }
   if (amax) record_absmax<T>(mx, amax);
 }
 
 constexpr int GN_BWD_MAX_BLOCKS = 2048;
 extern "C" size_t BRATS_API(brats_gn_bwd_ws_floats)(int N, int C) { return (size_t)(1 + GN_BWD_MAX_BLOCKS) * N * C * 2; }
 
+template <typename T, bool HEAVY, bool NT, int HK>
+static void gn_bwd_launch(dim3 g1, dim3 g2, size_t lds1, size_t lds2, hipStream_t st, const void* dz, int dzpitch, const void* y,
+                          int ypitch, const float* scale_shift, const float* mean_rstd, const float* gamma, void* dy, int dypitch,
+                          float* red, float* dgamma, float* dbeta, int act, SlopeArg slope, int N, int voxels, int C, int groups,
+                          float* amax, HeadFold hf) {
+  hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, HEAVY, NT, HK>), g1, dim3(256), lds1, st, (const T*)dz, dzpitch, (const T*)y, ypitch,
+                     scale_shift, mean_rstd, red, act, slope, voxels, C, groups, hf);
+  // pass 1 leaves one partial sum per block; gn_bwd_finish_kernel adds them in block order
+  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
+  hipLaunchKernelGGL((gn_bwd_apply_kernel<T, HEAVY, NT, HK>), g2, dim3(256), lds2, st, (const T*)dz, dzpitch, (const T*)y, ypitch,
+                     scale_shift, mean_rstd, gamma, red, (T*)dy, dypitch, dgamma, dbeta, act, slope, N, voxels, C, groups,
+                     (uint32_t*)amax, hf);
+}
+
+static int gn_act_bwd_impl(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift, const float* mean_rstd,
+                           const float* gamma, void* dy, int dypitch, float* red, float* dgamma, float* dbeta, int dtype, int act,
+                           SlopeArg slope, int N, int voxels, int C, int groups, float* amax, HeadFold hf, int K, hipStream_t st) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: C=%d / pitches must be multiples of %d", C, vw);
+  const int cv = C / vw, vl = 256 / cv;
+  const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const int cap1 = big ? GN_BWD_MAX_BLOCKS : 512;
+  dim3 g1(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx), N);
+  const size_t lds1 = (size_t)(vl * C * 2 + (K ? vl * (K * C + K) : 0)) * sizeof(float);
+  dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
+  const size_t lds2 = (size_t)2 * groups * sizeof(float);
+#define GN_BWD_GO(T, HEAVY, NT, HK) gn_bwd_launch<T, HEAVY, NT, HK>(g1, g2, lds1, lds2, st, dz, dzpitch, y, ypitch, scale_shift, mean_rstd, \
+                                                                  gamma, dy, dypitch, red, dgamma, dbeta, act, slope, N, voxels, C, groups, amax, hf)
+  if (K) {  // (relu / leakyrelu, three logit planes: checked by the caller)
+    if (lds1 > 64 * 1024) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_head: C=%d exceeds the LDS budget of pass 1", C);
+    if (big) GN_BWD_GO(bf16_t, false, true, 3);
+    else if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, 3);
+    else GN_BWD_GO(float, false, false, 3);
+  } else if (big && act <= BRATS_ACT_LEAKY) GN_BWD_GO(bf16_t, false, true, 0);
+  else if (act > BRATS_ACT_LEAKY) {
+    if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, true, false, 0);
+    else GN_BWD_GO(float, true, false, 0);
+  } else {
+    if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, 0);
+    else GN_BWD_GO(float, false, false, 0);
+  }
+#undef GN_BWD_GO
+  BRATS_CHECK_LAUNCH();
+  return (int)g1.x;  // > 0: the number of pass-1 blocks per sample (the head partials' count)
+}
+
 extern "C" int BRATS_API(brats_gn_act_bwd)(const void* dz, int dzpitch, const void* y, int ypitch, const float* scale_shift,
                                 const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red,
                                 float* dgamma, float* dbeta, int dtype, int act, float slope_value, const float* slope_dev,
                                 int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
-  const SlopeArg slope{slope_value, slope_dev};
-  const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!dz || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma) BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: null pointer");
-  if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
-    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: C=%d / pitches must be multiples of %d", C, vw);
-  hipStream_t st = (hipStream_t)s;
-  const int cv = C / vw, vl = 256 / cv;
-  const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
-  // pass 1 leaves one partial sum per block; gn_bwd_finish_kernel adds them in block order
-  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
-  const int cap1 = big ? GN_BWD_MAX_BLOCKS : 512;
-  dim3 g1(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx), N);
-  const size_t lds1 = (size_t)(vl * C * 2) * sizeof(float);
-  dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
-  const size_t lds2 = (size_t)2 * groups * sizeof(float);
-  if (dtype == BRATS_BF16 && act <= BRATS_ACT_LEAKY && stream_nt((size_t)N * voxels * C * 2)) {
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, false, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                       ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
-    hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                       ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                       voxels, C, groups, (uint32_t*)amax);
-  } else if (act > BRATS_ACT_LEAKY) {
-  if (dtype == BRATS_BF16) {
-      hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
-      hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                         ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups, (uint32_t*)amax);
-    } else {
-      hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, true>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
-                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
-      hipLaunchKernelGGL((gn_bwd_apply_kernel<float, true>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
-                         ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups, (uint32_t*)amax);
-    }
-  } else {
-  if (dtype == BRATS_BF16) {
-      hipLaunchKernelGGL((gn_bwd_reduce_kernel<bf16_t, false>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
-      hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y,
-                         ypitch, scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups, (uint32_t*)amax);
-    } else {
-      hipLaunchKernelGGL((gn_bwd_reduce_kernel<float, false>), g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)y,
-                         ypitch, scale_shift, mean_rstd, red, act, slope, voxels, C, groups);
-      hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3((N * C * 2 + 7) / 8), dim3(256), 0, st, red, (int)g1.x, N * C * 2);
-      hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y,
-                         ypitch, scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, slope, N,
-                         voxels, C, groups, (uint32_t*)amax);
-    }
-  }
-  BRATS_CHECK_LAUNCH();
-  return 0;
+  const int rc = gn_act_bwd_impl(dz, dzpitch, y, ypitch, scale_shift, mean_rstd, gamma, dy, dypitch, red, dgamma, dbeta, dtype, act,
+                                 SlopeArg{slope_value, slope_dev}, N, voxels, C, groups, amax, HeadFold{}, 0, (hipStream_t)s);
+  return rc < 0 ? rc : 0;
+}
+
+// GroupNorm + activation backward of a layer whose output feeds only a 1x1x1 head convolution with K = 3 logit planes (the
+// network's last ConvBnRelu + outconv, networks/equiunet2020.py:488): dz is never materialised (HeadFold above), and the
+// head's dweight [K][C] / dbias [K] come out of the same passes.  Replaces brats_head_bwd(scale 1) + brats_gn_act_bwd.
+// dlogits: f32 [N][K][voxels]; hw: the head weight [K][C]; hws: brats_gn_bwd_head_ws_floats(N, C, K) floats.
+extern "C" size_t BRATS_API(brats_gn_bwd_head_ws_floats)(int N, int C, int K) { return (size_t)N * GN_BWD_MAX_BLOCKS * (K * C + K); }
+extern "C" int BRATS_API(brats_gn_act_bwd_head)(const float* dlogits, const float* hw, int K, const void* y, int ypitch,
+                                     const float* scale_shift, const float* mean_rstd, const float* gamma, void* dy, int dypitch,
+                                     float* red, float* hws, float* dgamma, float* dbeta, float* dhw, float* dhb, int dtype,
+                                     int act, float slope_value, int N, int voxels, int C, int groups, float* amax,
+                                     brats_stream_t s) {
+  if (!dlogits || !hw || !y || !dy || !red || !hws || !scale_shift || !mean_rstd || !gamma || !dhw || !dhb)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_head: null pointer");
+  if (K != 3 || act > BRATS_ACT_LEAKY)
+    BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_head: built for K = 3 logit planes and relu / leakyrelu (K=%d, act=%d)", K, act);
+  HeadFold hf;
+  hf.dl = dlogits; hf.w = hw; hf.hpart = hws;
+  const int nb = gn_act_bwd_impl(nullptr, 8, y, ypitch, scale_shift, mean_rstd, gamma, dy, dypitch, red, dgamma, dbeta, dtype, act,
+                                 SlopeArg{slope_value, nullptr}, N, voxels, C, groups, amax, hf, K, (hipStream_t)s);
+  if (nb < 0) return nb;
+  return brats_ordered_sum2(hws, dhw, K * C, dhb, N * nb, K * C + K, (hipStream_t)s);  // totals straight into dhw [K][C], dhb [K]
 }
 
 // =================================================================================================
@@ -627,15 +797,17 @@ template <typename T, bool NT = false>
 __global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
                                    int zpitch, float* __restrict__ chansum, int voxels, int C, int groups,
-                                   uint32_t* __restrict__ amax) {
+                                   uint32_t* __restrict__ amax, const float* __restrict__ gscale) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];  // sc[C] = rstd*gamma, be[C], then reduction scratch
   float* sc = sm;
   float* be = sm + C;
   const int n = blockIdx.y, cpg = C / groups;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    sc[c] = mean_rstd[(n * groups + c / cpg) * 2 + 1] * gamma[c];
-    be[c] = beta[c];
+    // gscale (brats_evonorm_se_fwd): the ResidualSELayer's 1 + gate per (n, channel), applied to z in the same pass
+    const float gs = gscale ? gscale[(size_t)n * C + c] : 1.f;
+    sc[c] = mean_rstd[(n * groups + c / cpg) * 2 + 1] * gamma[c] * gs;
+    be[c] = beta[c] * gs;
   }
   __syncthreads();
   const int cv = C / VW, vl_n = blockDim.x / cv;
@@ -698,14 +870,104 @@ extern "C" int BRATS_API(brats_evonorm_fwd)(const void* x, int xpitch, const flo
   const size_t lds = (size_t)(2 * C + vl * C) * sizeof(float);
   if (dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2))  // (beyond the Infinity Cache: non-temporal streaming, common.hpp)
     hipLaunchKernelGGL((evonorm_fwd_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
-                       (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
+                       (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax, (const float*)nullptr);
   else if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(evonorm_fwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
-                       (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
+                       (bf16_t*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax, (const float*)nullptr);
   else
     hipLaunchKernelGGL(evonorm_fwd_kernel<float>, grid, dim3(256), lds, st, (const float*)x, xpitch, mean_rstd, gamma, beta,
-                       (float*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax);
+                       (float*)z, zpitch, chansum, voxels, C, groups, (uint32_t*)amax, (const float*)nullptr);
   if (chansum) brats_ordered_sum(chansum + (size_t)N * C, chansum, (int)grid.x, N * C, st);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[n][c] = sum_v x*sigmoid(x) (per-block partials, added in block order by the caller): the statistics pass of
+// brats_evonorm_se_fwd
+template <typename T, bool NT = false>
+__global__ void evonorm_numsum_kernel(const T* __restrict__ x, int xpitch, float* __restrict__ out, int voxels, int C) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];
+  const int n = blockIdx.y;
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  float acc[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  if (myvl < vl_n) {
+    const T* xb = x + (size_t)n * voxels * xpitch + c0;
+    const size_t stride = (size_t)gridDim.x * vl_n;
+    size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+    for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+      float x0[VW], x1[VW];
+      vload<T, VW, NT>(xb + vox * xpitch, x0);
+      vload<T, VW, NT>(xb + (vox + stride) * xpitch, x1);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += x0[j] * sigmoidf_(x0[j]);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += x1[j] * sigmoidf_(x1[j]);
+    }
+    if (vox < (size_t)voxels) {
+      float x0[VW];
+      vload<T, VW, NT>(xb + vox * xpitch, x0);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += x0[j] * sigmoidf_(x0[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < VW; ++j) sm[myvl * C + c0 + j] = acc[j];
+  }
+  __syncthreads();
+  float* part = out + (size_t)gridDim.y * C + ((size_t)blockIdx.x * gridDim.y + n) * C;  // per-block partials
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += sm[l * C + c];
+    part[c] = t;
+  }
+}
+
+// EvoNorm + ResidualSELayer forward without storing the EvoNorm output z: pass 1 reads x and sums num(x) per (n, channel);
+// the SE gate runs on sum_v z reconstructed from those sums (se.hpp); pass 2 writes out = z * (1 + gate) directly.  Replaces
+// brats_evonorm_fwd(chansum) + brats_se_fwd + brats_channel_scale: 3 tensor passes (x, x, out) instead of 4 (x, z, z, out).
+// ws: brats_chan_ws_floats(N, C, 1) floats; chansum_out [N][C] = sum_v z (what brats_evonorm_se_bwd's se_chansum wants).
+extern "C" int BRATS_API(brats_evonorm_se_fwd)(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
+                                    const float* w1, const float* b1, const float* w2, const float* b2, void* out, int opitch,
+                                    float* ws, float* chansum_out, float* gate1p, float* hidden, int Ch, int dtype, int N,
+                                    int voxels, int C, int groups, float* amax, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!x || !out || !mean_rstd || !gamma || !beta || !ws || !chansum_out || !gate1p || !hidden)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_se_fwd: null pointer");
+  if (C % vw || C % groups || xpitch % vw || opitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_se_fwd: bad argument (C, pitches multiples of %d)", vw);
+  hipStream_t st = (hipStream_t)s;
+  const int cv = C / vw, vl = 256 / cv;
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const size_t cap = big ? CHAN_MAX_BLOCKS : 512;
+  dim3 g1((unsigned)(gx < 1 ? 1 : (gx > cap ? cap : gx)), N);
+  const size_t lds1 = (size_t)vl * C * sizeof(float);
+  if (big)
+    hipLaunchKernelGGL((evonorm_numsum_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)x, xpitch, ws, voxels, C);
+  else if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(evonorm_numsum_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)x, xpitch, ws, voxels, C);
+  else
+    hipLaunchKernelGGL(evonorm_numsum_kernel<float>, g1, dim3(256), lds1, st, (const float*)x, xpitch, ws, voxels, C);
+  BRATS_CHECK_LAUNCH();
+  brats_ordered_sum(ws + (size_t)N * C, ws, (int)g1.x, N * C, st);
+  SeFwdFold fold;
+  fold.numsum = ws; fold.mean_rstd = mean_rstd; fold.gamma = gamma; fold.beta = beta; fold.chansum_out = chansum_out;
+  fold.groups = groups; fold.voxels = (float)voxels;
+  if (int rc = brats_se_fwd_launch(nullptr, fold, 1.f / (float)voxels, w1, b1, w2, b2, gate1p, hidden, N, C, Ch, st)) return rc;
+  dim3 g2((unsigned)(gx < 1 ? 1 : (gx > CHAN_MAX_BLOCKS ? CHAN_MAX_BLOCKS : gx)), N);
+  const size_t lds2 = (size_t)(2 * C + vl * C) * sizeof(float);
+  if (big)
+    hipLaunchKernelGGL((evonorm_fwd_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
+                       (bf16_t*)out, opitch, (float*)nullptr, voxels, C, groups, (uint32_t*)amax, (const float*)gate1p);
+  else if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(evonorm_fwd_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)x, xpitch, mean_rstd, gamma, beta,
+                       (bf16_t*)out, opitch, (float*)nullptr, voxels, C, groups, (uint32_t*)amax, (const float*)gate1p);
+  else
+    hipLaunchKernelGGL(evonorm_fwd_kernel<float>, g2, dim3(256), lds2, st, (const float*)x, xpitch, mean_rstd, gamma, beta,
+                       (float*)out, opitch, (float*)nullptr, voxels, C, groups, (uint32_t*)amax, (const float*)gate1p);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

@@ -137,17 +137,27 @@ DEVI void slice_of(int total, int parts, int idx, int& lo, int& hi) {
 
 // grid = (G, N), block = SE_NT.  LDS: gap[C] + hid[Ch].  Every workgroup of a sample computes the whole hidden vector, then
 // its slice of the gate rows
-__global__ __launch_bounds__(SE_NT) void se_fwd_kernel(const float* __restrict__ chansum, float inv_vox, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ gate1p,
-                                                       float* __restrict__ hidden, int C, int Ch) {
+__global__ __launch_bounds__(SE_NT) void se_fwd_kernel(const float* __restrict__ chansum, SeFwdFold fold, float inv_vox,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ gate1p, float* __restrict__ hidden, int C, int Ch) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   float* gap = (float*)lds_raw;
   float* hid = gap + C;
   const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  for (int c = tid; c < C; c += blockDim.x) gap[c] = chansum[(size_t)n * C + c] * inv_vox;
-  __syncthreads();
   const bool first = blockIdx.x == 0;
+  const int cpg = fold.numsum ? C / fold.groups : 1;
+  for (int c = tid; c < C; c += blockDim.x) {
+    float cs;
+    if (fold.numsum) {
+      cs = fold.mean_rstd[(n * fold.groups + c / cpg) * 2 + 1] * fold.gamma[c] * fold.numsum[(size_t)n * C + c] + fold.beta[c] * fold.voxels;
+      if (first) fold.chansum_out[(size_t)n * C + c] = cs;
+    } else {
+      cs = chansum[(size_t)n * C + c];
+    }
+    gap[c] = cs * inv_vox;
+  }
+  __syncthreads();
   rows_dot4(w1, 0, Ch, C, gap, wave, nw, lane, [&](int j, float s) {
     const float h = fmaxf(s + b1[j], 0.f);
     hid[j] = h;
@@ -246,16 +256,24 @@ static int se_workgroups(int C, int Ch) {
   return g < 1 ? 1 : (g > SE_MAX_WGS ? SE_MAX_WGS : (int)g);
 }
 
-extern "C" int brats_se_fwd(const float* chansum, float inv_vox, const float* w1, const float* b1, const float* w2, const float* b2,
-                            float* gate1p, float* hidden, int N, int C, int Ch, brats_stream_t s) {
-  if (!chansum || !w1 || !b1 || !w2 || !b2 || !gate1p || !hidden || N <= 0 || C <= 0 || Ch <= 0)
+int brats_se_fwd_launch(const float* chansum, const SeFwdFold& fold, float inv_vox, const float* w1, const float* b1, const float* w2,
+                        const float* b2, float* gate1p, float* hidden, int N, int C, int Ch, hipStream_t st) {
+  if ((!chansum && !fold.numsum) || !w1 || !b1 || !w2 || !b2 || !gate1p || !hidden || N <= 0 || C <= 0 || Ch <= 0)
     BRATS_FAIL(BRATS_E_ARG, "se_fwd: null pointer or non-positive size");
+  if (fold.numsum && (!fold.mean_rstd || !fold.gamma || !fold.beta || !fold.chansum_out || fold.groups <= 0 || C % fold.groups))
+    BRATS_FAIL(BRATS_E_ARG, "se_fwd: incomplete EvoNorm fold arguments");
   const size_t lds = (size_t)(C + Ch) * 4;
   if (lds > 64 * 1024) BRATS_FAIL(BRATS_E_UNSUPPORTED, "se_fwd: C = %d, C/r = %d exceed the 64 KB LDS budget", C, Ch);
-  hipLaunchKernelGGL(se_fwd_kernel, dim3(se_workgroups(C, Ch), N), dim3(SE_NT), lds, (hipStream_t)s, chansum, inv_vox, w1, b1, w2, b2,
-                     gate1p, hidden, C, Ch);
+  hipLaunchKernelGGL(se_fwd_kernel, dim3(se_workgroups(C, Ch), N), dim3(SE_NT), lds, st, chansum, fold, inv_vox, w1, b1, w2, b2, gate1p,
+                     hidden, C, Ch);
   BRATS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int brats_se_fwd(const float* chansum, float inv_vox, const float* w1, const float* b1, const float* w2, const float* b2,
+                            float* gate1p, float* hidden, int N, int C, int Ch, brats_stream_t s) {
+  if (!chansum) BRATS_FAIL(BRATS_E_ARG, "se_fwd: null pointer or non-positive size");
+  return brats_se_fwd_launch(chansum, SeFwdFold{}, inv_vox, w1, b1, w2, b2, gate1p, hidden, N, C, Ch, (hipStream_t)s);
 }
 
 int brats_se_bwd_launch(const float* dgate, const SeFold& fold, const float* chansum, float inv_vox, const float* hidden,

@@ -146,7 +146,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
-def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None):
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None, head=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
     fp8 == "all": the input gradient (dgrad) and -- for the dilation-1 layers the all-taps kernel covers -- the weight
     gradient run on the e4m3 kernels too, scaled by the |max| of dy that the GroupNorm backward records (and the |max| of
@@ -165,8 +165,19 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         grads[names[unit.prelu.weight]] = ops.prelu_slope_grad(dz, y, scale_shift)
         if sink is not None:
             sink(names[unit.prelu.weight], grads[names[unit.prelu.weight]])
-    dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
-                                       slope_t=slope_t)
+    if head is not None:
+        # the last layer: its output feeds only the 1x1x1 head, whose backward is folded into the GroupNorm backward --
+        # d(up1) is never written, the head's weight / bias gradients come out of the same passes (ops.gn_act_bwd_head)
+        hd, dout = head
+        dy, dgamma, dbeta, dhw, dhb = ops.gn_act_bwd_head(dout, hd.weight, y, scale_shift, mean_rstd, unit.bn.weight.detach(),
+                                                          unit.groups, kact, amax=amax)
+        for prm, g in ((hd.weight, dhw), (hd.bias, dhb)):
+            grads[names[prm]] = g
+            if sink is not None:
+                sink(names[prm], g)
+    else:
+        dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
+                                           slope_t=slope_t)
     # data-parallel: the weight gradient is written straight into its slice of the all-reduce bucket
     wdst = dest(names[unit.conv.weight]) if dest is not None else None
     with ops.side_stream(side, dy, x, x2) as on_side:
@@ -287,13 +298,18 @@ class _EquiUnetFn(torch.autograd.Function):
         # buckets' copies and collectives are ordered against it
         side = ops.get_side_stream(douts[0].device) if (m.wgrad_stream and m._grad_sink is None) else None
 
-        def cbw(unit, dz, need_dx=True):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest)
+        def cbw(unit, dz, need_dx=True, head=None):
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
+        top = None  # the output head on up1: folded into the GroupNorm backward of the last layer where that is built
         for (hd, src, sc), dout in zip(ctx.heads, douts):
             if dout is None:
+                continue
+            if (hd is m.outconv and m.fold_head_bwd
+                    and ops.head_fold_ok(hd.weight, *_unit_act(m.decoder1.ConvBnRelu2, act))):
+                top = (hd, dout)
                 continue
             dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
             grads[names[hd.weight]] = dw
@@ -310,8 +326,8 @@ class _EquiUnetFn(torch.autograd.Function):
         def plus(a, b):
             return a if b is None else a + b
 
-        d_up1 = extra(up1)
-        d_skip1, d_u1 = cbw(m.decoder1.ConvBnRelu1, cbw(m.decoder1.ConvBnRelu2, d_up1))
+        d_c1 = cbw(m.decoder1.ConvBnRelu2, None, head=top) if top is not None else cbw(m.decoder1.ConvBnRelu2, extra(up1))
+        d_skip1, d_u1 = cbw(m.decoder1.ConvBnRelu1, d_c1)
         d_up2 = plus(ops.upsample_bwd(d_u1, 2), extra(up2))
         d_skip2, d_u2 = cbw(m.decoder2.ConvBnRelu1, cbw(m.decoder2.ConvBnRelu2, d_up2))
         d_up3 = plus(ops.upsample_bwd(d_u2, 2), extra(up3))
@@ -370,6 +386,9 @@ class EquiUnet(_PackedWeightsModule):
         # step is GPU-bound and the single gather-heavy launch (0.21 ms) saves only 0.05 ms of GPU time over the 34 small
         # ones while measuring 0.1 ms slower end to end (same-box A/B); EquiUnetASSPEvo (host-bound eager) gains 10 %.
         self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "0") != "0"
+        # the output head's backward inside the GroupNorm backward of the last layer (brats_gn_act_bwd_head); 0: the two-call
+        # path (brats_head_bwd + brats_gn_act_bwd) for same-box A/B runs
+        self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
         f = self.features
         nl = norm_layer
         self.encoder1 = UBlock(inplanes, f[0], f[0], norm=nl, act=act)

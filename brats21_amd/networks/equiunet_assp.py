@@ -213,20 +213,23 @@ def _conv_evo_bwd(cx, rec, dz, need_dx=True, gscale=None, gadd=None):
 def _block_fwd(cx, blk, x, out=None):
     s = blk.conv_conv_se
     z1, _, r1 = _conv_evo_fwd(cx, s[0], s[1], x)
-    z2, cs, r2 = _conv_evo_fwd(cx, s[3], s[4], z1, want_chansum=True)
-    # ResidualSELayer: out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2): the gate is one launch (csrc/se.hip)
-    n, d, h, w, c = z2.shape
+    # second conv + EvoNorm + ResidualSELayer (out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2)) as one call: a statistics
+    # pass over y, the gate (csrc/se.hip), then the EvoNorm pass writes z2 * (1 + gate) -- z2 itself is never stored
+    conv, evo = s[3], s[4]
+    y, stats, saved = _conv_any_fwd(cx, conv, z1, 1, True)
+    n, d, h, w, c = y.shape
+    mr, chan = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
-    gate1p, hidden = ops.se_gate(cs, d * h * w, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
-    amax = cx.slot(z2.device)
-    o = ops.channel_scale(z2, gate1p, out=out, amax=amax)
+    amax = cx.slot(y.device)
+    o, cs, gate1p, hidden = ops.evonorm_se(y, mr, _flat(evo.gamma), _flat(evo.beta), fc1.weight, fc1.bias, fc2.weight, fc2.bias, 8,
+                                           out=out, amax=amax)
     if amax is not None:
         o._amax = amax
-    return o, (blk, r1, r2, z2, cs, hidden, gate1p)
+    return o, (blk, r1, (conv, evo, saved, y, mr, chan), cs, hidden, gate1p)
 
 
 def _block_bwd(cx, rec, do, need_dx=True):
-    blk, r1, r2, z2, cs, hidden, gate1p = rec
+    blk, r1, r2, cs, hidden, gate1p = rec
     s = blk.conv_conv_se
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
     # one call: pass 1 of the EvoNorm backward over (do, y) also yields d loss / d gate = sum_v do * z2 (linear in its sums),

@@ -626,6 +626,34 @@ def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope
     return dy, dgamma, dbeta
 
 
+def gn_act_bwd_head(dlogits, head_weight, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None):
+    """GroupNorm + activation backward of the layer under the 1x1x1 output head, the head's backward folded in
+    (include/brats_hip.h: brats_gn_act_bwd_head): -> (dy, dgamma, dbeta, dhead_weight [K,C,1,1,1], dhead_bias [K])."""
+    yp, c, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    k = head_weight.shape[0]
+    dev = y.device
+    hw = head_weight.detach().reshape(k, c).contiguous().float()
+    dl = dlogits.contiguous().float()
+    dy = new_act(n, d, h, w, c, y.dtype, dev)
+    red = torch.empty(_lib.lib().brats_gn_bwd_ws_floats(n, c), dtype=torch.float32, device=dev)
+    hws = torch.empty(_lib.lib().brats_gn_bwd_head_ws_floats(n, c, k), dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dhw = torch.empty((k, c), dtype=torch.float32, device=dev)
+    dhb = torch.empty(k, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().brats_gn_act_bwd_head(dl.data_ptr(), hw.data_ptr(), k, yp, ypitch, scale_shift.data_ptr(),
+                                                mean_rstd.data_ptr(), _f32(gamma), dy.data_ptr(), c, red.data_ptr(), hws.data_ptr(),
+                                                dgamma.data_ptr(), dbeta.data_ptr(), dhw.data_ptr(), dhb.data_ptr(), _code(y.dtype),
+                                                ACTS[act], slope, n, d * h * w, c, groups, _f32(amax), _stream()), "gn_act_bwd_head")
+    return dy, dgamma, dbeta, dhw.reshape(k, c, 1, 1, 1), dhb
+
+
+def head_fold_ok(head_weight, act, slope_t):
+    """brats_gn_act_bwd_head is built for three logit planes and relu / leakyrelu without a learnable slope."""
+    return head_weight.shape[0] == 3 and act in ("relu", "leakyrelu") and slope_t is None
+
+
 def prelu_slope_grad(dz, y, scale_shift):
     """d loss / d slope [1] of z = PReLU(y * scale + shift) with one shared slope (nn.PReLU()): sum dz * min(pre, 0)."""
     dzp, c, dzpitch = _desc(dz)
@@ -813,6 +841,27 @@ def se_gate_bwd(dgate, chansum, voxels, hidden, gate1p, w1, w2):
                                        _f32(w1.detach().contiguous()), _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(),
                                        db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), n, c, ch, _stream()), "se_bwd")
     return gadd, dw1, db1, dw2, db2
+
+
+def evonorm_se(y, mean_rstd, gamma, beta, w1, b1, w2, b2, groups=8, out=None, amax=None):
+    """EvoNorm + ResidualSELayer in one call, the EvoNorm output never stored (csrc/se.hpp):
+    -> (out = z * (1 + gate), chansum [N, C] = sum_v z, gate1p [N, C], hidden [N, C/r])."""
+    ptr, c, p = _desc(y)
+    n, d, h, w, _ = y.shape
+    ch = w1.shape[0]
+    dev = y.device
+    if out is None:
+        out = new_act(n, d, h, w, c, y.dtype, dev)
+    optr, _, op = _desc(out)
+    ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 1), dtype=torch.float32, device=dev)
+    cs = torch.empty((n, c), dtype=torch.float32, device=dev)
+    gate1p = torch.empty((n, c), dtype=torch.float32, device=dev)
+    hidden = torch.empty((n, ch), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().brats_evonorm_se_fwd(ptr, p, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), _f32(w1.detach().contiguous()),
+                                               _f32(b1.detach()), _f32(w2.detach().contiguous()), _f32(b2.detach()), optr, op,
+                                               ws.data_ptr(), cs.data_ptr(), gate1p.data_ptr(), hidden.data_ptr(), ch,
+                                               _code(y.dtype), n, d * h * w, c, groups, _f32(amax), _stream()), "evonorm_se_fwd")
+    return out, cs, gate1p, hidden
 
 
 def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None):

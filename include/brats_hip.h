@@ -187,6 +187,17 @@ int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, con
                      float* red /* workspace */, float* dgamma, float* dbeta,
                      int dtype, int act, float slope, const float* slope_dev, int N, int voxels, int C, int groups,
                      float* amax /* optional, zero before the call: receives max|dy| */, brats_stream_t s);
+/* The same backward for the layer whose output feeds ONLY a 1x1x1 head convolution with K = 3 logit planes -- the network's
+ * last ConvBnRelu + outconv (networks/equiunet2020.py:488): dz[v][c] = sum_k dlogits[k][v] * hw[k][c] is computed inside both
+ * passes from the 12 bytes of dlogits per voxel instead of being written (2 * C bytes per voxel) by brats_head_bwd and read
+ * back twice, and the head's own gradients dhw [K][C] = sum_v dlogits[k][v] * z[v][c], dhb [K] = sum_v dlogits[k][v] come
+ * out of pass 1 (z = act(GN(y)) is at hand there).  Replaces brats_head_bwd(scale 1) + brats_gn_act_bwd for that layer;
+ * relu / leakyrelu only.  dlogits: f32 [N][K][voxels]; hws: brats_gn_bwd_head_ws_floats(N, C, K) floats. */
+size_t brats_gn_bwd_head_ws_floats(int N, int C, int K);
+int brats_gn_act_bwd_head(const float* dlogits, const float* hw, int K, const void* y, int ypitch, const float* scale_shift,
+                          const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red /* as above */,
+                          float* hws, float* dgamma, float* dbeta, float* dhw, float* dhb, int dtype, int act, float slope,
+                          int N, int voxels, int C, int groups, float* amax, brats_stream_t s);
 /* gradient of nn.PReLU's scalar slope: dslope[0] = sum dz * min(y*scale + shift, 0) over the whole tensor; ws = f32
  * workspace of brats_prelu_ws_floats(N) elements (block partials, added in block order) */
 size_t brats_prelu_ws_floats(int N);
@@ -241,6 +252,16 @@ int brats_evonorm_se_bwd(const void* dout, int dopitch, const void* x, int xpitc
                          const double* chan_sums, float* dconvbias, const float* se_chansum, const float* hidden,
                          const float* gate1p, const float* w1, const float* w2, float* gadd, float* dw1, float* db1,
                          float* dw2, float* db2, int Ch, int dtype, int N, int voxels, int C, int groups, float* amax,
+                         brats_stream_t s);
+/* The forward counterpart: EvoNorm + ResidualSELayer without storing the EvoNorm output z.  Pass 1 reads x and sums
+ * x*sigmoid(x) per (n, channel); sum_v z -- what the gate's global average pool reads -- is linear in those sums; pass 2
+ * writes out = z * (1 + gate) directly (3 tensor passes instead of the 4 of brats_evonorm_fwd(chansum) + brats_se_fwd +
+ * brats_channel_scale).  ws: brats_chan_ws_floats(N, C, 1) floats; chansum_out [N][C] = sum_v z, gate1p [N][C], hidden
+ * [N][Ch]: kept for brats_evonorm_se_bwd. */
+int brats_evonorm_se_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
+                         const float* w1, const float* b1, const float* w2, const float* b2, void* out, int opitch,
+                         float* ws, float* chansum_out, float* gate1p, float* hidden, int Ch, int dtype, int N, int voxels,
+                         int C, int groups, float* amax /* optional, zero before the call: receives max|out| */,
                          brats_stream_t s);
 int brats_channel_dot(const void* a, int apitch, const void* b /*may be NULL*/, int bpitch, float* out /*[N][C]*/,
                       int dtype, int N, int voxels, int C, brats_stream_t s);

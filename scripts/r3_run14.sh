@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 3, GPU run 14: the output head's backward folded into the last layer's GroupNorm backward -- tests, same-box A/B
+cd $GRAFT_REPO_ROOT; out=gpurun_out/r3_run14; rm -rf $out; mkdir -p $out
+timeout 1500 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "groupnorm or head" > $out/pytest_ops.log 2>&1; echo "pytest ops rc=$?" >> $out/summary.txt
+timeout 2400 python -m pytest tests/test_equiunet_gpu.py tests/test_headline_gpu.py -m gpu -x -q > $out/pytest_net.log 2>&1; echo "pytest net rc=$?" >> $out/summary.txt
+for rep in 1 2 3; do
+  for fh in 0 1; do
+    echo "== fold_head=$fh rep $rep" >> $out/ab.log
+    BRATS_FOLD_HEAD=$fh timeout 600 python bench.py --steps 30 --warmup 10 --no-infer --no-cpu-baseline --no-parity-leg 2>>$out/ab.err | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('step', r['ms_per_step'], r['config']['loss'], r['roofline']['avg_ms'], r['roofline']['frac'])" >> $out/ab.log 2>&1
+  done
+done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > $out/prof.log 2>&1
+f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv; rm -rf $out/prof
+cat $out/summary.txt; tail -5 $out/pytest_ops.log; tail -5 $out/pytest_net.log; cat $out/ab.log; tail -3 $out/ab.err; head -14 $out/kernel_stats.csv | cut -c1-150

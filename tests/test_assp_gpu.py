@@ -219,6 +219,34 @@ def test_evonorm_bwd_with_folded_se_gradient_map():
 
 
 @pytest.mark.parametrize("n,c,size", [(2, 48, (6, 8, 16)), (3, 96, (4, 4, 8)), (2, 384, (2, 4, 4)), (1, 16, (5, 7, 9))])
+def test_evonorm_se_fwd_matches_three_call_composition(n, c, size):
+    """brats_evonorm_se_fwd (sum of x*sigmoid(x) -> gate on the reconstructed sum_v z -> out = z * (1 + gate) in the EvoNorm
+    pass; z never stored) against evonorm(chansum) -> se_gate -> channel_scale.  f32: the same mathematics in another order;
+    bf16: the composition rounds z to bf16 before scaling, the fused call rounds once (closer to the f32 result)."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21 + c)
+    ch, vox = c // 2, size[0] * size[1] * size[2]
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):
+        y = torch.randn((n, *size, c), generator=g).to(dev).to(dt)
+        mr = torch.stack([torch.randn((n, 8), generator=g) * 0.1, torch.rand((n, 8), generator=g) + 0.5], -1).to(dev).contiguous()
+        gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(c, generator=g) * 0.3).to(dev)
+        w1, b1 = (torch.randn((ch, c), generator=g) * 0.3).to(dev), (torch.randn((ch,), generator=g) * 0.2).to(dev)
+        w2, b2 = (torch.randn((c, ch), generator=g) * 0.3).to(dev), (torch.randn((c,), generator=g) * 0.2).to(dev)
+        z, cs = ops.evonorm(y, mr, gamma, beta, 8, want_chansum=True)
+        gate1p, hidden = ops.se_gate(cs, vox, w1, b1, w2, b2)
+        ref = ops.channel_scale(z, gate1p)
+        out, cs2, gate2, hidden2 = ops.evonorm_se(y, mr, gamma, beta, w1, b1, w2, b2, 8)
+        for name, a, b, t in (("chansum", cs2, cs, 2e-5), ("gate1p", gate2, gate1p, 2e-5), ("hidden", hidden2, hidden, 2e-5),
+                              ("out", out, ref, tol)):
+            scale = float(b.float().abs().max()) + 1e-30
+            assert float((a.float() - b.float()).abs().max()) <= t * scale, (name, str(dt))
+        again = ops.evonorm_se(y, mr, gamma, beta, w1, b1, w2, b2, 8)
+        assert all(torch.equal(a, b) for a, b in zip(again, (out, cs2, gate2, hidden2)))
+
+
+@pytest.mark.parametrize("n,c,size", [(2, 48, (6, 8, 16)), (3, 96, (4, 4, 8)), (2, 384, (2, 4, 4)), (1, 16, (5, 7, 9))])
 def test_evonorm_se_bwd_matches_three_call_composition(n, c, size):
     """brats_evonorm_se_bwd (pass 1 with five raw sums -> SE backward on the sums -> pass 2; csrc/se.hpp) against the
     composition it replaces: channel_dot(do, z) -> se_gate_bwd -> evonorm_bwd(do, gscale = 1 + gate, gadd).  The same

@@ -153,6 +153,50 @@ def test_groupnorm_act_fwd_bwd(dtype, c, act):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,act,size", [(48, "relu", (8, 8, 8)), (16, "leakyrelu", (4, 6, 10)), (8, "relu", (3, 5, 7))])
+def test_groupnorm_bwd_with_folded_output_head(dtype, c, act, size):
+    """brats_gn_act_bwd_head (the last layer's GroupNorm backward computing dz = W_head^T dlogits on the fly, the head's
+    weight / bias gradients out of the same passes) against torch autograd of conv1x1(act(GN(y))) on the conv output as
+    stored, and against the two calls it replaces (head_bwd + gn_act_bwd)."""
+    from brats21_amd import ops
+    dev = _dev()
+    n, cin, vox = 2, 8, size[0] * size[1] * size[2]
+    x = _q(_rand((n, cin, *size), 61), dtype)
+    w = _q(_rand((c, cin, 3, 3, 3), 62, 0.1), dtype)
+    gamma = 1.0 + 0.2 * _rand((c,), 63)
+    beta = 0.1 * _rand((c,), 64)
+    hw = _rand((3, c, 1, 1, 1), 65, 0.2)
+    dl = _rand((n, 3, *size), 66)
+    y, stats = ops.conv3d(_to_ndhwc(x, dtype, dev), ops.pack_weights(w.to(dev), dtype, ops.PACK_FWD), c, 3, 1, want_stats=True)
+    mr, ss = ops.gn_finalize(stats, n, c, 8, vox, gamma.to(dev), beta.to(dev))
+    z = ops.affine_act(y, ss, act)
+    # torch autograd on the stored conv output (so the activation masks agree)
+    y_ref = _from_ndhwc(y).detach().requires_grad_(True)
+    g_r, b_r, hw_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), hw.clone().requires_grad_(True)
+    zn = F.group_norm(y_ref, 8, g_r, b_r, 1e-5)
+    z_ref = F.relu(zn) if act == "relu" else F.leaky_relu(zn, 0.01)
+    hb_r = torch.zeros(3, requires_grad=True)
+    F.conv3d(z_ref, hw_r, hb_r).backward(dl)
+    dy, dgamma, dbeta, dhw, dhb = ops.gn_act_bwd_head(dl.to(dev), hw.to(dev), y, ss, mr, gamma.to(dev), 8, act)
+    bad = ((_from_ndhwc(dy) - y_ref.grad).abs() > _tol(dtype, 1e-4, 3e-2) + _tol(dtype, 1e-3, 2e-2) * y_ref.grad.abs()).float().mean()
+    assert float(bad) <= (0.0 if dtype == torch.float32 else 1e-3), float(bad)
+    torch.testing.assert_close(dgamma.cpu(), g_r.grad, atol=_tol(dtype, 1e-3, 2.0), rtol=_tol(dtype, 1e-4, 3e-2))
+    torch.testing.assert_close(dbeta.cpu(), b_r.grad, atol=_tol(dtype, 1e-3, 2.0), rtol=_tol(dtype, 1e-4, 3e-2))
+    torch.testing.assert_close(dhb.cpu(), hb_r.grad, atol=1e-3, rtol=1e-4)
+    # the head's weight gradient reads z: in the 16-bit modes torch saw the f32 z, the kernels the same f32 z (not the stored one)
+    torch.testing.assert_close(dhw.cpu(), hw_r.grad, atol=_tol(dtype, 1e-3, 5e-2), rtol=_tol(dtype, 1e-4, 1e-2))
+    # the two-call path
+    dz2, dhw2, dhb2 = ops.head_bwd(z, hw.to(dev), dl.to(dev), 1)
+    dy2, dgamma2, dbeta2 = ops.gn_act_bwd(dz2, y, ss, mr, gamma.to(dev), 8, act)
+    t = _tol(dtype, 2e-5, 2e-2)
+    for name, a, b in (("dy", dy, dy2), ("dgamma", dgamma, dgamma2), ("dbeta", dbeta, dbeta2), ("dhw", dhw, dhw2), ("dhb", dhb, dhb2)):
+        scale = float(b.float().abs().max()) + 1e-30
+        assert float((a.float() - b.float()).abs().max()) <= t * scale, name
+    again = ops.gn_act_bwd_head(dl.to(dev), hw.to(dev), y, ss, mr, gamma.to(dev), 8, act)
+    assert all(torch.equal(a, b) for a, b in zip(again, (dy, dgamma, dbeta, dhw, dhb)))  # bitwise reproducible
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("with_avg", [False, True])
 def test_pool_fwd_bwd(dtype, with_avg):
     from brats21_amd import ops
