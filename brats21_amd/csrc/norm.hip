@@ -285,6 +285,25 @@ extern "C" int BRATS_API(brats_affine_act_fwd)(const void* y, int ypitch, const 
 // A thread owns one 16-byte channel vector (fixed for the whole kernel) and walks voxels: its per-channel constants
 // live in registers (read from LDS per element they made both passes LDS-bound at ~3.5 TB/s), two voxels are in
 // flight per iteration.
+// Block reduction over the voxel lanes of a per-thread channel vector, ONE value plane at a time through scr[vl_n][C]: the
+// passes that carry 5 - 8 planes (EvoNorm's five sums, the head's K weight-gradient planes) would otherwise hold
+// vl_n * C * planes floats of LDS (65 KB at C = 48) for their last microsecond and lose occupancy for the whole stream.
+// put(c, sum over lanes in lane order).  Starts with a barrier (scr may still be read by the previous plane).
+template <int VW, typename F>
+DEVI void lane_reduce_plane(float* scr, const float* a, bool live, int myvl, int vl_n, int C, int c0, F&& put) {
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) scr[myvl * C + c0 + j] = a[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int l = 0; l < vl_n; ++l) t += scr[l * C + c];
+    put(c, t);
+  }
+}
+
 // 16 bytes of a tensor kept as loaded (4 registers) until the arithmetic wants the 8 (4) floats: the head-fold passes hold four
 // voxels per thread in flight, unpacked up front they cost 32 registers and an occupancy step
 template <typename T> struct Raw16;
@@ -453,25 +472,19 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     part[i] = t;
   }
   if constexpr (HK > 0) {  // the head's weight / bias gradient partials: [HK][C] + [HK] per block, added in block order afterwards
-    float* hs = sm + vl_n * C * 2;  // [vl_n][HK][C] + [vl_n][HK]
-    if (myvl < vl_n) {
+    const bool live = myvl < vl_n;
+    float* hb = sm + vl_n * C * 2;  // [vl_n][HK]
+    if (live && mycv == 0) {
 #pragma unroll
-      for (int k = 0; k < HK; ++k) {
-#pragma unroll
-        for (int j = 0; j < VW; ++j) hs[(myvl * HK + k) * C + c0 + j] = aw[k][j];
-        if (mycv == 0) hs[vl_n * HK * C + myvl * HK + k] = ab[k];
-      }
+      for (int k = 0; k < HK; ++k) hb[myvl * HK + k] = ab[k];
     }
-    __syncthreads();
     float* hp = hf.hpart + ((size_t)n * gridDim.x + blockIdx.x) * (HK * C + HK);
-    for (int i = threadIdx.x; i < HK * C; i += blockDim.x) {
-      float t = 0.f;
-      for (int l = 0; l < vl_n; ++l) t += hs[l * HK * C + i];
-      hp[i] = t;
-    }
+#pragma unroll
+    for (int k = 0; k < HK; ++k)  // (one plane at a time through the first vl_n * C floats of the scratch)
+      lane_reduce_plane<VW>(sm, aw[k], live, myvl, vl_n, C, c0, [&](int c, float t) { hp[k * C + c] = t; });
     if ((int)threadIdx.x < HK) {
       float t = 0.f;
-      for (int l = 0; l < vl_n; ++l) t += hs[vl_n * HK * C + l * HK + threadIdx.x];
+      for (int l = 0; l < vl_n; ++l) t += hb[l * HK + threadIdx.x];
       hp[HK * C + threadIdx.x] = t;
     }
   }
@@ -659,13 +672,12 @@ static int gn_act_bwd_impl(const void* dz, int dzpitch, const void* y, int ypitc
   const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
   const int cap1 = big ? GN_BWD_MAX_BLOCKS : 512;
   dim3 g1(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx), N);
-  const size_t lds1 = (size_t)(vl * C * 2 + (K ? vl * (K * C + K) : 0)) * sizeof(float);
+  const size_t lds1 = (size_t)(vl * C * 2 + (K ? vl * K : 0)) * sizeof(float);
   dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
 #define GN_BWD_GO(T, HEAVY, NT, HK) gn_bwd_launch<T, HEAVY, NT, HK>(g1, g2, lds1, lds2, st, dz, dzpitch, y, ypitch, scale_shift, mean_rstd, \
                                                                   gamma, dy, dypitch, red, dgamma, dbeta, act, slope, N, voxels, C, groups, amax, hf)
   if (K) {  // (relu / leakyrelu, three logit planes: checked by the caller)
-    if (lds1 > 64 * 1024) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_head: C=%d exceeds the LDS budget of pass 1", C);
     if (big) GN_BWD_GO(bf16_t, false, true, 3);
     else if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, 3);
     else GN_BWD_GO(float, false, false, 3);
@@ -794,7 +806,7 @@ extern "C" int BRATS_API(brats_evonorm_finalize)(const float* stats, int tiles_p
 DEVI float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 template <typename T, bool NT = false>
-__global__ void evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
+__global__ void __launch_bounds__(256) evonorm_fwd_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ mean_rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
                                    int zpitch, float* __restrict__ chansum, int voxels, int C, int groups,
                                    uint32_t* __restrict__ amax, const float* __restrict__ gscale) {
@@ -885,7 +897,7 @@ extern "C" int BRATS_API(brats_evonorm_fwd)(const void* x, int xpitch, const flo
 // out[n][c] = sum_v x*sigmoid(x) (per-block partials, added in block order by the caller): the statistics pass of
 // brats_evonorm_se_fwd
 template <typename T, bool NT = false>
-__global__ void evonorm_numsum_kernel(const T* __restrict__ x, int xpitch, float* __restrict__ out, int voxels, int C) {
+__global__ void __launch_bounds__(256) evonorm_numsum_kernel(const T* __restrict__ x, int xpitch, float* __restrict__ out, int voxels, int C) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   const int n = blockIdx.y;
@@ -977,19 +989,39 @@ extern "C" int BRATS_API(brats_evonorm_se_fwd)(const void* x, int xpitch, const 
 // RAW5 (brats_evonorm_se_bwd): dz is the SE block's output gradient `do` as it is, and two more sums -- sum_v x*sigmoid(x),
 // sum_v d/dx[x*sigmoid(x)] -- come along: the SE backward (se.hip) derives d loss / d gate and the three sums above for
 // dz = do * gscale + gadd from these five (se.hpp), so that no pass computes sum_v do * z on its own.
-template <typename T, bool NT = false, bool RAW5 = false>
-__global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
+// HK > 0 (RAW5 only; brats_evonorm_se_bwd with dlogits): the SE block's output feeds only the 1x1x1 output head, `do` =
+// W_head^T dlogits is computed on the fly (HeadFold, as in gn_bwd_reduce_kernel); the head's weight gradient
+// sum_v dl[k] * out[v][c], out = (num * sc + be) * gate1p, is linear in sum_v dl[k] * num and sum_v dl[k].
+struct EvoHead {
+  HeadFold hf;
+  const float* mean_rstd = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* gate1p = nullptr;
+  int groups = 1;
+};
+template <typename T, bool NT = false, bool RAW5 = false, int HK = 0>
+__global__ void __launch_bounds__(256) evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                           float* __restrict__ red, int voxels, int C, const float* __restrict__ gscale,
-                                          const float* __restrict__ gadd) {
+                                          const float* __restrict__ gadd, EvoHead eh) {
   constexpr int VW = 16 / sizeof(T);
   constexpr int NV = RAW5 ? 5 : 3;
+  constexpr int HKA = HK > 0 ? HK : 1;
+  static_assert(HK == 0 || RAW5, "the head fold exists for the five-sum pass only");
   extern __shared__ float sm[];
   const int n = blockIdx.y;
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
   float a1[VW], a2[VW], a3[VW], a4[VW], a5[VW];
+  float aw[HKA][VW], ab[HKA];
 #pragma unroll
   for (int j = 0; j < VW; ++j) a1[j] = a2[j] = a3[j] = a4[j] = a5[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < HKA; ++k) {
+    ab[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) aw[k][j] = 0.f;
+  }
   if (myvl < vl_n) {
     const T* dzb = dz + (size_t)n * voxels * dzpitch;
     const T* xb = x + (size_t)n * voxels * xpitch;
@@ -1019,6 +1051,49 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
     };
     const size_t stride = (size_t)gridDim.x * vl_n;
     size_t vox = (size_t)blockIdx.x * vl_n + myvl;
+    if constexpr (HK > 0) {
+      float wr[HKA][VW];
+#pragma unroll
+      for (int k = 0; k < HK; ++k)
+#pragma unroll
+        for (int j = 0; j < VW; ++j) wr[k][j] = eh.hf.w[k * C + c0 + j];
+      const float* dl = eh.hf.dl + (size_t)n * HK * voxels;
+      auto step = [&](size_t v0, auto cnt) {  // four voxels in flight per thread
+        constexpr int NVX = decltype(cnt)::value;
+        typename Raw16<T>::type xr[NVX];
+        float gq[NVX][HKA];
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) xr[i] = Raw16<T>::template load<NT>(xb + (v0 + i * stride) * xpitch + c0);
+#pragma unroll
+        for (int i = 0; i < NVX; ++i)
+#pragma unroll
+          for (int k = 0; k < HK; ++k) gq[i][k] = dl[(size_t)k * voxels + v0 + i * stride];
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+          float xx[VW];
+          Raw16<T>::unpack(xr[i], xx);
+#pragma unroll
+          for (int j = 0; j < VW; ++j) {
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < HK; ++k) d += gq[i][k] * wr[k][j];
+            const float sg = sigmoidf_(xx[j]);
+            const float num = xx[j] * sg, dnum = sg * (1.f + xx[j] * (1.f - sg));
+            a1[j] += d;
+            a2[j] += d * num;
+            a3[j] += d * dnum;
+            a4[j] += num;
+            a5[j] += dnum;
+#pragma unroll
+            for (int k = 0; k < HK; ++k) aw[k][j] += gq[i][k] * num;
+          }
+#pragma unroll
+          for (int k = 0; k < HK; ++k) ab[k] += gq[i][k];
+        }
+      };
+      for (; vox + 3 * stride < (size_t)voxels; vox += 4 * stride) step(vox, std::integral_constant<int, 4>{});
+      for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+    } else {
     for (; vox + stride < (size_t)voxels; vox += 2 * stride) {  // two voxels (4 loads) in flight per thread
       float g0[VW], x0[VW], g1[VW], x1[VW];
       vload<T, VW, NT>(dzb + vox * dzpitch + c0, g0);
@@ -1034,39 +1109,54 @@ __global__ void evonorm_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch,
       vload<T, VW, NT>(xb + vox * xpitch + c0, x0);
       body(g0, x0);
     }
-  }
-  float* scr = sm;  // [vl_n][C][NV]
-  if (myvl < vl_n) {
-#pragma unroll
-    for (int j = 0; j < VW; ++j) {
-      scr[(myvl * C + c0 + j) * NV] = a1[j];
-      scr[(myvl * C + c0 + j) * NV + 1] = a2[j];
-      scr[(myvl * C + c0 + j) * NV + 2] = a3[j];
-      if constexpr (RAW5) {
-        scr[(myvl * C + c0 + j) * NV + 3] = a4[j];
-        scr[(myvl * C + c0 + j) * NV + 4] = a5[j];
-      }
     }
   }
-  __syncthreads();
+  float* scr = sm;  // [vl_n][C] (+ [vl_n][HK])
+  const bool live = myvl < vl_n;
   float* part = red + (size_t)gridDim.y * C * NV + ((size_t)blockIdx.x * gridDim.y + n) * C * NV;  // per-block partials
-  for (int i = threadIdx.x; i < NV * C; i += blockDim.x) {
-    float t = 0.f;
-    for (int l = 0; l < vl_n; ++l) t += scr[l * C * NV + i];
-    part[i] = t;
+  lane_reduce_plane<VW>(scr, a1, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * NV] = t; });
+  lane_reduce_plane<VW>(scr, a2, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * NV + 1] = t; });
+  lane_reduce_plane<VW>(scr, a3, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * NV + 2] = t; });
+  if constexpr (RAW5) {
+    lane_reduce_plane<VW>(scr, a4, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * NV + 3] = t; });
+    lane_reduce_plane<VW>(scr, a5, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * NV + 4] = t; });
+  }
+  if constexpr (HK > 0) {  // the head's weight / bias gradient partials [HK][C] + [HK] of this block (one sample)
+    float* hb = sm + vl_n * C;  // [vl_n][HK]
+    if (live && mycv == 0) {
+#pragma unroll
+      for (int k = 0; k < HK; ++k) hb[myvl * HK + k] = ab[k];
+    }
+    float* hp = eh.hf.hpart + ((size_t)n * gridDim.x + blockIdx.x) * (HK * C + HK);
+    const int cpg = C / eh.groups;
+#pragma unroll
+    for (int k = 0; k < HK; ++k)
+      lane_reduce_plane<VW>(scr, aw[k], live, myvl, vl_n, C, c0, [&](int c, float t) {
+        float tb = 0.f;
+        for (int l = 0; l < vl_n; ++l) tb += hb[l * HK + k];
+        // sum_v dl * out, out = (num * rstd * gamma + beta) * gate1p
+        const float sc = eh.mean_rstd[(n * eh.groups + c / cpg) * 2 + 1] * eh.gamma[c];
+        hp[k * C + c] = eh.gate1p[(size_t)n * C + c] * (sc * t + eh.beta[c] * tb);
+      });
+    if ((int)threadIdx.x < HK) {
+      float tb = 0.f;
+      for (int l = 0; l < vl_n; ++l) tb += hb[l * HK + threadIdx.x];
+      hp[HK * C + threadIdx.x] = tb;
+    }
   }
 }
 
 // pass 2: dx = dz*gamma*r*num'(x) - r^3 * A_g * (x - mean_g)/(M-1),  A_g = sum_{c in g} gamma_c * red[n][c][1]
-template <typename T, bool NT = false>
-__global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
+template <typename T, bool NT = false, int HK = 0>
+__global__ void __launch_bounds__(256) evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
                                          const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
                                          const float* __restrict__ red, T* __restrict__ dx, int dxpitch,
                                          float* __restrict__ dgamma, float* __restrict__ dbeta, const double* __restrict__ chan,
                                          float* __restrict__ dconvbias, int N, int voxels, int C, int groups,
                                          uint32_t* __restrict__ amax, const float* __restrict__ gscale,
-                                         const float* __restrict__ gadd) {
+                                         const float* __restrict__ gadd, HeadFold hf) {
   constexpr int VW = 16 / sizeof(T);
+  constexpr int HKA = HK > 0 ? HK : 1;
   extern __shared__ float sm[];
   float* gr = sm;          // [C] gamma * r
   float* mu = sm + C;      // [C] group mean
@@ -1130,6 +1220,41 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
   };
   const size_t stride = (size_t)gridDim.x * vl_n;
   size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
+  if constexpr (HK > 0) {
+    float wr[HKA][VW];
+#pragma unroll
+    for (int k = 0; k < HK; ++k)
+#pragma unroll
+      for (int j = 0; j < VW; ++j) wr[k][j] = hf.w[k * C + c0 + j];
+    const float* dl = hf.dl + (size_t)n * HK * voxels;
+    auto step = [&](size_t v0, auto cnt) {  // four voxels in flight per thread
+      constexpr int NVX = decltype(cnt)::value;
+      typename Raw16<T>::type xr[NVX];
+      float gq[NVX][HKA];
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) xr[i] = Raw16<T>::template load<NT>(xb + (v0 + i * stride) * xpitch);
+#pragma unroll
+      for (int i = 0; i < NVX; ++i)
+#pragma unroll
+        for (int k = 0; k < HK; ++k) gq[i][k] = dl[(size_t)k * voxels + v0 + i * stride];
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) {
+        float xx[VW], g[VW], o[VW];
+        Raw16<T>::unpack(xr[i], xx);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          float d = 0.f;
+#pragma unroll
+          for (int k = 0; k < HK; ++k) d += gq[i][k] * wr[k][j];
+          g[j] = d;
+        }
+        body(g, xx, o);
+        vstore<T, VW, NT>(dxb + (v0 + i * stride) * dxpitch, o);
+      }
+    };
+    for (; vox + 3 * stride < (size_t)voxels; vox += 4 * stride) step(vox, std::integral_constant<int, 4>{});
+    for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+  } else {
   for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
     float g0[VW], x0[VW], g1[VW], x1[VW], o0[VW], o1[VW];
     vload<T, VW, NT>(dzb + vox * dzpitch, g0);
@@ -1147,6 +1272,7 @@ __global__ void evonorm_bwd_apply_kernel(const T* __restrict__ dz, int dzpitch, 
     vload<T, VW, NT>(xb + vox * xpitch, x0);
     body(g0, x0, o0);
     vstore<T, VW, NT>(dxb + vox * dxpitch, o0);
+  }
   }
   if (amax) record_absmax<T>(mx, amax);
 }
@@ -1166,27 +1292,27 @@ extern "C" int BRATS_API(brats_evonorm_bwd)(const void* dz, int dzpitch, const v
   const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
   const size_t cap1 = big ? CHAN_MAX_BLOCKS : 512, cap2 = big ? 8192 : 2048;  // large tensors: many short-lived blocks stream faster
   dim3 g1((unsigned)(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx)), N);  // one partial per block, added in block order
-  const size_t lds1 = (size_t)(vl * C * 3) * sizeof(float);
+  const size_t lds1 = (size_t)(vl * C) * sizeof(float);  // (one value plane at a time: lane_reduce_plane)
   dim3 g2((unsigned)(gx < 1 ? 1 : (gx > cap2 ? cap2 : gx)), N);
   const size_t lds2 = (size_t)3 * C * sizeof(float);
   if (big) {
     hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, true>), g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, red, voxels, C, gscale, gadd);
+                       xpitch, red, voxels, C, gscale, gadd, EvoHead{});
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL((evonorm_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd, HeadFold{});
   } else if (dtype == BRATS_BF16) {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<bf16_t>, g1, dim3(256), lds1, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, red, voxels, C, gscale, gadd);
+                       xpitch, red, voxels, C, gscale, gadd, EvoHead{});
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
+                       xpitch, mean_rstd, gamma, red, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd, HeadFold{});
   } else {
     hipLaunchKernelGGL(evonorm_bwd_reduce_kernel<float>, g1, dim3(256), lds1, st, (const float*)dz, dzpitch, (const float*)x,
-                       xpitch, red, voxels, C, gscale, gadd);
+                       xpitch, red, voxels, C, gscale, gadd, EvoHead{});
     brats_ordered_sum(red + (size_t)N * C * 3, red, (int)g1.x, N * C * 3, st);
     hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x,
-                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd);
+                       xpitch, mean_rstd, gamma, red, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups, (uint32_t*)amax, gscale, gadd, HeadFold{});
   }
   BRATS_CHECK_LAUNCH();
   return 0;
@@ -1196,17 +1322,24 @@ extern "C" int BRATS_API(brats_evonorm_bwd)(const void* dz, int dzpitch, const v
 // with the five raw sums -> brats_se_bwd_launch (d loss / d gate from the sums; gadd, the SE parameter gradients, the three
 // sums for dz = dout * gate1p + gadd) -> pass 2.  Replaces brats_channel_dot + brats_se_bwd + brats_evonorm_bwd(gscale, gadd):
 // one pass over two tensors less per block.  ws: brats_chan_ws_floats(N, C, 5) + N * C * 3 floats.
+// dlogits != NULL (then dout may be NULL): the block's output feeds only the 1x1x1 output head with K = 3 logit planes -- the
+// head's backward is folded in as in brats_gn_act_bwd_head (dout = W_head^T dlogits on the fly; dhw [K][C], dhb [K] out of
+// pass 1); hws: brats_gn_bwd_head_ws_floats(N, C, K) floats.
 extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, const void* x, int xpitch, const float* mean_rstd,
                                     const float* gamma, const float* beta, void* dx, int dxpitch, float* ws, float* dgamma,
                                     float* dbeta, const double* chan_sums, float* dconvbias, const float* se_chansum,
                                     const float* hidden, const float* gate1p, const float* w1, const float* w2, float* gadd,
-                                    float* dw1, float* db1, float* dw2, float* db2, int Ch, int dtype, int N, int voxels, int C,
-                                    int groups, float* amax, brats_stream_t s) {
+                                    float* dw1, float* db1, float* dw2, float* db2, int Ch, const float* dlogits, const float* hw,
+                                    int K, float* hws, float* dhw, float* dhb, int dtype, int N, int voxels, int C, int groups,
+                                    float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
-  if (!dout || !x || !dx || !ws || !mean_rstd || !gamma || !beta || !gate1p || !gadd)
+  const bool head = dlogits != nullptr;
+  if ((!dout && !head) || !x || !dx || !ws || !mean_rstd || !gamma || !beta || !gate1p || !gadd)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: null pointer");
+  if (head && (!hw || !hws || !dhw || !dhb)) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: incomplete head arguments");
+  if (head && K != 3) BRATS_FAIL(BRATS_E_UNSUPPORTED, "evonorm_se_bwd: the head fold is built for K = 3 logit planes (K=%d)", K);
   if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: dconvbias needs the forward per-channel sums");
-  if (C % vw || C % groups || dopitch % vw || xpitch % vw || dxpitch % vw || C / vw > 256)
+  if (C % vw || C % groups || (!head && dopitch % vw) || xpitch % vw || dxpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: C=%d / pitches must be multiples of %d", C, vw);
   hipStream_t st = (hipStream_t)s;
   const int cv = C / vw, vl = 256 / cv;
@@ -1214,40 +1347,41 @@ extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, co
   const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
   const size_t cap1 = big ? CHAN_MAX_BLOCKS : 512, cap2 = big ? 8192 : 2048;
   dim3 g1((unsigned)(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx)), N);
-  const size_t lds1 = (size_t)(vl * C * 5) * sizeof(float);
+  const size_t lds1 = (size_t)(vl * C + (head ? vl * K : 0)) * sizeof(float);  // (one value plane at a time)
   dim3 g2((unsigned)(gx < 1 ? 1 : (gx > cap2 ? cap2 : gx)), N);
   const size_t lds2 = (size_t)3 * C * sizeof(float);
   float* raw5 = ws;
   float* red3 = ws + (size_t)(1 + CHAN_MAX_BLOCKS) * N * C * 5;
-  if (big)
-    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, true, true>), g1, dim3(256), lds1, st, (const bf16_t*)dout, dopitch,
-                       (const bf16_t*)x, xpitch, raw5, voxels, C, (const float*)nullptr, (const float*)nullptr);
-  else if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<bf16_t, false, true>), g1, dim3(256), lds1, st, (const bf16_t*)dout, dopitch,
-                       (const bf16_t*)x, xpitch, raw5, voxels, C, (const float*)nullptr, (const float*)nullptr);
-  else
-    hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<float, false, true>), g1, dim3(256), lds1, st, (const float*)dout, dopitch,
-                       (const float*)x, xpitch, raw5, voxels, C, (const float*)nullptr, (const float*)nullptr);
+  EvoHead eh;
+  eh.hf.dl = dlogits; eh.hf.w = hw; eh.hf.hpart = hws;
+  eh.mean_rstd = mean_rstd; eh.gamma = gamma; eh.beta = beta; eh.gate1p = gate1p; eh.groups = groups;
+  const float* nof = nullptr;
+#define EVO_P1(T, NT, HK) hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<T, NT, true, HK>), g1, dim3(256), lds1, st, (const T*)dout, dopitch, \
+                                             (const T*)x, xpitch, raw5, voxels, C, nof, nof, eh)
+#define EVO_P2(T, NT, HK) hipLaunchKernelGGL((evonorm_bwd_apply_kernel<T, NT, HK>), g2, dim3(256), lds2, st, (const T*)dout, dopitch, \
+                                             (const T*)x, xpitch, mean_rstd, gamma, red3, (T*)dx, dxpitch, dgamma, dbeta, chan_sums, \
+                                             dconvbias, N, voxels, C, groups, (uint32_t*)amax, gate1p, gadd, eh.hf)
+  if (head) {
+    if (big) EVO_P1(bf16_t, true, 3); else if (dtype == BRATS_BF16) EVO_P1(bf16_t, false, 3); else EVO_P1(float, false, 3);
+  } else {
+    if (big) EVO_P1(bf16_t, true, 0); else if (dtype == BRATS_BF16) EVO_P1(bf16_t, false, 0); else EVO_P1(float, false, 0);
+  }
   BRATS_CHECK_LAUNCH();
   brats_ordered_sum(raw5 + (size_t)N * C * 5, raw5, (int)g1.x, N * C * 5, st);
+  if (head) brats_ordered_sum2(hws, dhw, K * C, dhb, N * (int)g1.x, K * C + K, st);  // totals straight into dhw [K][C], dhb [K]
   SeFold fold;
   fold.raw5 = raw5; fold.mean_rstd = mean_rstd; fold.gamma = gamma; fold.beta = beta; fold.red3 = red3; fold.groups = groups;
   fold.voxels = (float)voxels;
   if (int rc = brats_se_bwd_launch(nullptr, fold, se_chansum, 1.f / (float)voxels, hidden, gate1p, w1, w2, gadd, dw1, db1, dw2, db2,
                                    N, C, Ch, st))
     return rc;
-  if (big)
-    hipLaunchKernelGGL((evonorm_bwd_apply_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dout, dopitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red3, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups,
-                       (uint32_t*)amax, gate1p, gadd);
-  else if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL(evonorm_bwd_apply_kernel<bf16_t>, g2, dim3(256), lds2, st, (const bf16_t*)dout, dopitch, (const bf16_t*)x,
-                       xpitch, mean_rstd, gamma, red3, (bf16_t*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups,
-                       (uint32_t*)amax, gate1p, gadd);
-  else
-    hipLaunchKernelGGL(evonorm_bwd_apply_kernel<float>, g2, dim3(256), lds2, st, (const float*)dout, dopitch, (const float*)x,
-                       xpitch, mean_rstd, gamma, red3, (float*)dx, dxpitch, dgamma, dbeta, chan_sums, dconvbias, N, voxels, C, groups,
-                       (uint32_t*)amax, gate1p, gadd);
+  if (head) {
+    if (big) EVO_P2(bf16_t, true, 3); else if (dtype == BRATS_BF16) EVO_P2(bf16_t, false, 3); else EVO_P2(float, false, 3);
+  } else {
+    if (big) EVO_P2(bf16_t, true, 0); else if (dtype == BRATS_BF16) EVO_P2(bf16_t, false, 0); else EVO_P2(float, false, 0);
+  }
+#undef EVO_P1
+#undef EVO_P2
   BRATS_CHECK_LAUNCH();
   return 0;
 }

@@ -228,7 +228,9 @@ def _block_fwd(cx, blk, x, out=None):
     return o, (blk, r1, (conv, evo, saved, y, mr, chan), cs, hidden, gate1p)
 
 
-def _block_bwd(cx, rec, do, need_dx=True):
+def _block_bwd(cx, rec, do, need_dx=True, head=None):
+    """head = (head module, dlogits) instead of `do`: the block's output feeds only the 1x1x1 output head, whose backward is
+    folded into the same call (d(up1) is never written)."""
     blk, r1, r2, cs, hidden, gate1p = rec
     s = blk.conv_conv_se
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
@@ -236,8 +238,12 @@ def _block_bwd(cx, rec, do, need_dx=True):
     # the SE backward runs on those, pass 2 reads the gradient as do * (1 + gate) + dgap / V  (csrc/se.hpp)
     conv, evo, saved, y, mr, chan = r2
     amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
-    dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2 = ops.evonorm_se_bwd(do, y, mr, _flat(evo.gamma), _flat(evo.beta), cs, hidden, gate1p,
-                                                                    fc1.weight, fc2.weight, 8, chan=chan, amax=amax)
+    res = ops.evonorm_se_bwd(do, y, mr, _flat(evo.gamma), _flat(evo.beta), cs, hidden, gate1p, fc1.weight, fc2.weight, 8, chan=chan,
+                             amax=amax, head=(head[0].weight, head[1]) if head is not None else None)
+    dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2 = res[:8]
+    if head is not None:
+        cx.put(head[0].weight, res[8])
+        cx.put(head[0].bias, res[9])
     if amax is not None:
         dy._amax = amax
     for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2), (evo.gamma, dgamma), (evo.beta, dbeta)):
@@ -323,8 +329,12 @@ class _AsspFn(torch.autograd.Function):
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
         down1, down2, down3, up3, up2, up1 = ctx.bufs
         dsrc = {}
+        top = None  # the output head on up1: folded into the backward of the decoder1 block (three logit planes)
         for (hd, src, sc), dout in zip(ctx.heads, douts):
             if dout is None:
+                continue
+            if src is up1 and sc == 1 and m.fold_head_bwd and hd.weight.shape[0] == 3:
+                top = (hd, dout)
                 continue
             dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
             cx.put(hd.weight, dw)
@@ -335,7 +345,7 @@ class _AsspFn(torch.autograd.Function):
             b = dsrc.get(t.data_ptr())
             return a if b is None else a + b
 
-        dcat1 = _block_bwd(cx, R["rd1"], dsrc[up1.data_ptr()])
+        dcat1 = _block_bwd(cx, R["rd1"], None, head=top) if top is not None else _block_bwd(cx, R["rd1"], dsrc[up1.data_ptr()])
         d_up2 = plus(_conv_evo_bwd(cx, R["ru1"], ops.upsample_bwd(dcat1[..., h0:], 2)), up2)
         dcat2 = _block_bwd(cx, R["rd2"], d_up2)
         d_up3 = plus(_conv_evo_bwd(cx, R["ru2"], ops.upsample_bwd(dcat2[..., h1:], 2)), up3)
@@ -377,6 +387,9 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
         self.precision = "auto"
         self.conv_fp8 = None  # None | "fwd" | "all": e4m3 kernel for the 3x3x3 convolutions (see EquiUnet.conv_fp8)
         self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "1") != "0"  # training: one multi-tensor weight-packing launch per step (ops.PackPlan)
+        # the output head's backward inside the backward of the decoder1 block (brats_evonorm_se_bwd with dlogits); 0: the
+        # separate brats_head_bwd pass, for same-box A/B runs
+        self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None
         self._grad_dest = None

@@ -864,14 +864,27 @@ def evonorm_se(y, mean_rstd, gamma, beta, w1, b1, w2, b2, groups=8, out=None, am
     return out, cs, gate1p, hidden
 
 
-def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None):
+def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None, head=None):
     """EvoNorm backward of the layer under a ResidualSELayer with the SE backward folded in (csrc/se.hpp): `do` is the
-    gradient of the SE block's OUTPUT.  -> (dy, dgamma, dbeta, dconvbias|None, dW1, db1, dW2, db2)."""
-    dop, c, dopitch = _desc(do)
-    yp, _, ypitch = _desc(y)
+    gradient of the SE block's OUTPUT.  -> (dy, dgamma, dbeta, dconvbias|None, dW1, db1, dW2, db2).
+    head = (head_weight [K,C,1,1,1], dlogits [N,K,D,H,W]) instead of `do` (None): the block feeds only the 1x1x1 output head,
+    whose backward is folded in too; two more results: dhead_weight [K,C,1,1,1], dhead_bias [K]."""
+    yp, c, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
     ch = w1.shape[0]
     dev = y.device
+    if head is None:
+        dop, _, dopitch = _desc(do)
+        dl = hw = hws = dhw = dhb = None
+        k = 0
+    else:
+        dop, dopitch = None, 0
+        k = head[0].shape[0]
+        hw = head[0].detach().reshape(k, c).contiguous().float()
+        dl = head[1].contiguous().float()
+        hws = torch.empty(_lib.lib().brats_gn_bwd_head_ws_floats(n, c, k), dtype=torch.float32, device=dev)
+        dhw = torch.empty((k, c), dtype=torch.float32, device=dev)
+        dhb = torch.empty(k, dtype=torch.float32, device=dev)
     dy = new_act(n, d, h, w, c, y.dtype, dev)
     ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 5) + n * c * 3, dtype=torch.float32, device=dev)
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
@@ -886,9 +899,12 @@ def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1
                                                dcb.data_ptr() if dcb is not None else None, _f32(se_chansum.contiguous()),
                                                _f32(hidden), _f32(gate1p), _f32(w1.detach().contiguous()),
                                                _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
-                                               dw2.data_ptr(), db2.data_ptr(), ch, _code(y.dtype), n, d * h * w, c, groups,
-                                               _f32(amax), _stream()), "evonorm_se_bwd")
-    return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2
+                                               dw2.data_ptr(), db2.data_ptr(), ch, _f32(dl), _f32(hw), k, _f32(hws), _f32(dhw),
+                                               _f32(dhb), _code(y.dtype), n, d * h * w, c, groups, _f32(amax), _stream()),
+               "evonorm_se_bwd")
+    if head is None:
+        return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2
+    return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2, dhw.reshape(k, c, 1, 1, 1), dhb
 
 
 _DCONV_JOB = np.dtype([("term", [("x", "<u8"), ("w", "<u8"), ("xpitch", "<i4"), ("cin", "<i4"), ("ksize", "<i4"), ("dil", "<i4")], (4,)),

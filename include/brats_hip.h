@@ -251,8 +251,12 @@ int brats_evonorm_se_bwd(const void* dout, int dopitch, const void* x, int xpitc
                          const float* beta, void* dx, int dxpitch, float* ws, float* dgamma, float* dbeta,
                          const double* chan_sums, float* dconvbias, const float* se_chansum, const float* hidden,
                          const float* gate1p, const float* w1, const float* w2, float* gadd, float* dw1, float* db1,
-                         float* dw2, float* db2, int Ch, int dtype, int N, int voxels, int C, int groups, float* amax,
-                         brats_stream_t s);
+                         float* dw2, float* db2, int Ch,
+                         const float* dlogits /* optional: f32 [N][K][voxels]; then dout may be NULL -- the block's output
+                         feeds only the 1x1x1 output head, whose backward is folded in as in brats_gn_act_bwd_head (K = 3) */,
+                         const float* hw /* [K][C] */, int K, float* hws /* brats_gn_bwd_head_ws_floats(N, C, K) floats */,
+                         float* dhw /* [K][C] */, float* dhb /* [K] */,
+                         int dtype, int N, int voxels, int C, int groups, float* amax, brats_stream_t s);
 /* The forward counterpart: EvoNorm + ResidualSELayer without storing the EvoNorm output z.  Pass 1 reads x and sums
  * x*sigmoid(x) per (n, channel); sum_v z -- what the gate's global average pool reads -- is linear in those sums; pass 2
  * writes out = z * (1 + gate) directly (3 tensor passes instead of the 4 of brats_evonorm_fwd(chansum) + brats_se_fwd +

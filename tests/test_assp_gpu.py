@@ -281,6 +281,39 @@ def test_evonorm_se_bwd_matches_three_call_composition(n, c, size):
         assert all(torch.equal(a, b) for a, b in zip(again, got) if a is not None)  # bitwise reproducible
 
 
+@pytest.mark.parametrize("n,c,size", [(2, 48, (6, 8, 16)), (1, 16, (5, 7, 9))])
+def test_evonorm_se_bwd_with_folded_output_head(n, c, size):
+    """brats_evonorm_se_bwd(dlogits) -- the decoder1 block's backward computing its output gradient W_head^T dlogits on the
+    fly and the head's weight / bias gradients out of pass 1 -- against head_bwd on the stored block output followed by
+    brats_evonorm_se_bwd(dout)."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31 + c)
+    ch = c // 2
+    for dt, tol in ((torch.float32, 3e-5), (torch.bfloat16, 1.5e-2)):
+        y = torch.randn((n, *size, c), generator=g).to(dev).to(dt)
+        mr = torch.stack([torch.randn((n, 8), generator=g) * 0.1, torch.rand((n, 8), generator=g) + 0.5], -1).to(dev).contiguous()
+        gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(c, generator=g) * 0.3).to(dev)
+        w1, b1 = (torch.randn((ch, c), generator=g) * 0.3).to(dev), (torch.randn((ch,), generator=g) * 0.2).to(dev)
+        w2, b2 = (torch.randn((c, ch), generator=g) * 0.3).to(dev), (torch.randn((c,), generator=g) * 0.2).to(dev)
+        hw = (torch.randn((3, c, 1, 1, 1), generator=g) * 0.2).to(dev)
+        dl = (torch.randn((n, 3, *size), generator=g) * 0.1).to(dev)
+        out, cs, gate1p, hidden = ops.evonorm_se(y, mr, gamma, beta, w1, b1, w2, b2, 8)
+        do, dhw_r, dhb_r = ops.head_bwd(out, hw, dl, 1)
+        ref = ops.evonorm_se_bwd(do, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8)
+        got = ops.evonorm_se_bwd(None, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8, head=(hw, dl))
+        names = ("dy", "dgamma", "dbeta", "dcb", "dw1", "db1", "dw2", "db2", "dhw", "dhb")
+        for name, a, b in zip(names, got, ref + (dhw_r, dhb_r)):
+            if b is None:
+                assert a is None
+                continue
+            scale = float(b.float().abs().max()) + 1e-30
+            assert float((a.float() - b.float()).abs().max()) <= tol * scale, (name, str(dt))
+        again = ops.evonorm_se_bwd(None, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8, head=(hw, dl))
+        assert all(torch.equal(a, b) for a, b in zip(again, got) if a is not None)  # bitwise reproducible
+
+
 @pytest.mark.parametrize("n,c", [(2, 48), (1, 16), (4, 384), (3, 96)])
 def test_se_gate_kernels_vs_torch_autograd(n, c):
     """csrc/se.hip (one launch forward, one backward) against the MONAI ResidualSELayer arithmetic in torch f64:
