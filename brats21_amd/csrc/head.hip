@@ -15,9 +15,13 @@ constexpr int HEAD_KMAX = 4;
 
 // thread = (voxel, 16-byte channel vector): fully coalesced loads; the K partial dot products of a voxel's
 // C/VW threads are summed through LDS (a thread-per-voxel loop over channels ran at 2.3 TB/s)
-template <typename T>
+// PRE (brats_gn_head_fwd): x is the last layer's raw convolution output and the head reads z = act(x * scale + shift) --
+// GroupNorm + relu / leakyrelu applied on load, rounded to the storage type as the stored z would be -- so that z itself
+// (2 * C bytes per voxel written and read back) never exists.  pre.scale_shift: [N][C][2]; pre.nslope: 0 for relu.
+struct HeadPre { const float* scale_shift; float nslope; };
+template <typename T, bool PRE = false>
 __global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ b,
-                                 float* __restrict__ low, int C, int K, size_t voxels) {
+                                 float* __restrict__ low, int C, int K, size_t voxels, HeadPre pre) {
   constexpr int VW = 16 / sizeof(T);
   extern __shared__ float sm[];
   float* ws = sm;                       // [K][C]
@@ -28,12 +32,28 @@ __global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const floa
   const int cv = C / VW, vl_n = blockDim.x / cv;
   const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
   const T* xb = x + (size_t)n * voxels * xpitch;
+  float psc[VW], psh[VW];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const bool in = myvl < vl_n;
+      psc[j] = in ? pre.scale_shift[((size_t)n * C + c0 + j) * 2] : 0.f;
+      psh[j] = in ? pre.scale_shift[((size_t)n * C + c0 + j) * 2 + 1] : 0.f;
+    }
+  }
   for (size_t vbase = (size_t)blockIdx.x * vl_n; vbase < voxels; vbase += (size_t)gridDim.x * vl_n) {
     const size_t v = vbase + myvl;
     float acc[HEAD_KMAX] = {0.f, 0.f, 0.f, 0.f};
     if (myvl < vl_n && v < voxels) {
       float a[VW];
       Vec<T, VW>::load(xb + v * xpitch + c0, a);
+      if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          const float p = a[j] * psc[j] + psh[j];
+          a[j] = to_f<T>(from_f<T>(p > 0.f ? p : p * pre.nslope));
+        }
+      }
 #pragma unroll
       for (int k = 0; k < HEAD_KMAX; ++k)
         if (k < K) {
@@ -61,11 +81,37 @@ __global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const floa
 // channels; the B operand of lane (voxel l & 15, q = l >> 4) is one 16-byte load of 8 consecutive channels, so a wave
 // instruction reads 1 KB of contiguous activations, and nothing goes through LDS or a cross-lane reduction (the first form
 // read its weights from LDS per element and reduced six channel-vector threads per voxel through LDS: 2.7 TB/s).
+template <bool PRE = false>
 __global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __restrict__ x, int xpitch, const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ low, int C, int K,
-                                                             size_t voxels) {
+                                                             size_t voxels, HeadPre pre) {
   const int lane = threadIdx.x & 63, v = lane & 15, q = lane >> 4;
   const int n = blockIdx.y;
+  // PRE: the lane's 16 channels (8q.. and 32 + 8q..) are fixed, their scale / shift live in registers
+  float psc[2][8], psh[2][8];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = 32 * s2 + 8 * q + j;
+        psc[s2][j] = c < C ? pre.scale_shift[((size_t)n * C + c) * 2] : 0.f;
+        psh[s2][j] = c < C ? pre.scale_shift[((size_t)n * C + c) * 2 + 1] : 0.f;
+      }
+  }
+  auto pre_act = [&](bf16x8 raw, int s2) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    u4 u = __builtin_bit_cast(u4, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float lo, hi;
+      unpack2(u[i], lo, hi);
+      lo = lo * psc[s2][2 * i] + psh[s2][2 * i];
+      hi = hi * psc[s2][2 * i + 1] + psh[s2][2 * i + 1];
+      u[i] = pack2(lo > 0.f ? lo : lo * pre.nslope, hi > 0.f ? hi : hi * pre.nslope);
+    }
+    return __builtin_bit_cast(bf16x8, u);
+  };
   // the f32 weights enter as three bf16 terms (w = hi + mid + lo exactly: 3 x 8 mantissa bits), so the products are
   // those of the f32 weights with the bf16 activations, as in the reference's arithmetic; six MFMAs per 16 voxels
   bf16x8 wa[3][2];
@@ -107,6 +153,10 @@ __global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __res
       const int off = vv < voxels ? (int)(vv * xpitch * 2) + 16 * q : -1;
       xb0[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off | dead0, 0, 0));
       xb1[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (off + 64) | dead1 | (off >> 31), 0, 0));
+    }
+    if constexpr (PRE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xb0[i] = pre_act(xb0[i], 0); xb1[i] = pre_act(xb1[i], 1); }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -172,6 +222,38 @@ __global__ void __launch_bounds__(256) upsample_planes_kernel(const float* __res
   }
 }
 
+template <bool PRE>
+static int head_conv_launch(const void* x, int xpitch, const float* w, const float* b, float* low, int dtype, int N, int C, int K,
+                            size_t vox, HeadPre pre, hipStream_t st) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  const int cvh = C / vw, vlh = 256 / cvh;
+  if (cvh > 256) BRATS_FAIL(BRATS_E_UNSUPPORTED, "head_fwd: C too large");
+  dim3 grid(sgrid((vox + vlh - 1) / vlh, 1), N);
+  const size_t ldsh = (size_t)(HEAD_KMAX * C + 256 * HEAD_KMAX) * sizeof(float);
+  if (dtype == BRATS_BF16 && C <= 64 && (double)vox * xpitch * 2 < 2147483648.0) {
+    const size_t waves = (vox + 63) / 64;
+    const unsigned gx = (unsigned)(waves / 4 < 1 ? 1 : (waves / 4 > 8192 ? 8192 : waves / 4));
+    hipLaunchKernelGGL(head_conv_mfma_kernel<PRE>, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)x, xpitch, w, b, low, C, K, vox, pre);
+  } else if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL((head_conv_kernel<bf16_t, PRE>), grid, dim3(256), ldsh, st, (const bf16_t*)x, xpitch, w, b, low, C, K, vox, pre);
+  else
+    hipLaunchKernelGGL((head_conv_kernel<float, PRE>), grid, dim3(256), ldsh, st, (const float*)x, xpitch, w, b, low, C, K, vox, pre);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+// logits [N][K][voxels] = conv1x1(act(y * scale + shift)) + bias: the output head on the last layer's raw convolution output
+// (HeadPre above) -- replaces brats_affine_act_fwd + brats_head_fwd(scale 1) for that layer; relu / leakyrelu.
+extern "C" int BRATS_API(brats_gn_head_fwd)(const void* y, int ypitch, const float* scale_shift, int act, float slope, const float* w,
+                                 const float* b, float* out, int dtype, int N, int C, int K, int voxels, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!y || !scale_shift || !w || !out || K < 1 || K > HEAD_KMAX || C % vw || ypitch % vw)
+    BRATS_FAIL(BRATS_E_ARG, "gn_head_fwd: bad argument (K<=4, C multiple of %d)", vw);
+  if (act > BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_head_fwd: relu / leakyrelu only (act=%d)", act);
+  return head_conv_launch<true>(y, ypitch, w, b, out, dtype, N, C, K, (size_t)voxels,
+                                HeadPre{scale_shift, act == BRATS_ACT_RELU ? 0.f : slope}, (hipStream_t)s);
+}
+
 extern "C" int BRATS_API(brats_head_fwd)(const void* x, int xpitch, const float* w, const float* b, float* lowres, float* out,
                               int dtype, int N, int C, int K, int D, int H, int W, int scale, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
@@ -181,18 +263,7 @@ extern "C" int BRATS_API(brats_head_fwd)(const void* x, int xpitch, const float*
   hipStream_t st = (hipStream_t)s;
   const size_t vox = (size_t)D * H * W;
   float* low = scale > 1 ? lowres : out;
-  const int cvh = C / vw, vlh = 256 / cvh;
-  if (cvh > 256) BRATS_FAIL(BRATS_E_UNSUPPORTED, "head_fwd: C too large");
-  dim3 grid(sgrid((vox + vlh - 1) / vlh, 1), N);
-  const size_t ldsh = (size_t)(HEAD_KMAX * C + 256 * HEAD_KMAX) * sizeof(float);
-  if (dtype == BRATS_BF16 && C <= 64 && (double)vox * xpitch * 2 < 2147483648.0) {
-    const size_t waves = (vox + 63) / 64;
-    const unsigned gx = (unsigned)(waves / 4 < 1 ? 1 : (waves / 4 > 8192 ? 8192 : waves / 4));
-    hipLaunchKernelGGL(head_conv_mfma_kernel, dim3(gx, N), dim3(256), 0, st, (const bf16_t*)x, xpitch, w, b, low, C, K, vox);
-  } else if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL(head_conv_kernel<bf16_t>, grid, dim3(256), ldsh, st, (const bf16_t*)x, xpitch, w, b, low, C, K, vox);
-  else
-    hipLaunchKernelGGL(head_conv_kernel<float>, grid, dim3(256), ldsh, st, (const float*)x, xpitch, w, b, low, C, K, vox);
+  if (int rc = head_conv_launch<false>(x, xpitch, w, b, low, dtype, N, C, K, vox, HeadPre{nullptr, 0.f}, st)) return rc;
   if (scale > 1) {
     if ((W * scale) % 4) BRATS_FAIL(BRATS_E_UNSUPPORTED, "head_fwd: up-sampled width %d must be a multiple of 4", W * scale);
     const int items = H * scale * (W * scale / 4);

@@ -121,7 +121,7 @@ def _unit_act(unit, act):
     return act, None
 
 
-def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
     -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
     x recorded); the normalise+act pass records the |max| of its own output for the next layer."""
@@ -138,6 +138,8 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None):
         y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
     n, d, h, wd, _ = y.shape
     mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
+    if no_act:  # the last layer under the fused output head (ops.gn_head): the activation is applied on load there
+        return y, (unit, x, x2, y, mean_rstd, scale_shift)
     amax = slots.take() if slots is not None else None
     kact, slope_t = _unit_act(unit, act)
     z = ops.affine_act(y, scale_shift, kact, out=out, amax=amax, slope_t=slope_t)
@@ -269,8 +271,24 @@ class _EquiUnetFn(torch.autograd.Function):
         # decoder (:481-486)
         up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, down3, x2=up(bottom_2)))
         up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, down2, x2=up(up3)))
-        up1 = cgr(m.decoder1.ConvBnRelu2, cgr(m.decoder1.ConvBnRelu1, down1, x2=up(up2)))
-        outs = [ops.head(up1, m.outconv.weight, m.outconv.bias, 1)]
+        u1 = cgr(m.decoder1.ConvBnRelu1, down1, x2=up(up2))
+        # the last layer's activation up1 feeds only the output head: where the kernels for it are built, the head reads
+        # the raw convolution output and applies GroupNorm + act on load (ops.gn_head), the backward recomputes what it
+        # needs (ops.gn_act_bwd_head) -- up1 (2 x 403 MB written + read at 2 x 48 x 128^3) is never stored
+        kact, slope_t = _unit_act(m.decoder1.ConvBnRelu2, act)
+        nk = m.outconv.weight.shape[0]
+        will_bwd = any(ctx.needs_input_grad)
+        fuse_top = (m.fold_head_fwd and slope_t is None and kact in ("relu", "leakyrelu") and nk <= 4
+                    and (not will_bwd or (m.fold_head_bwd and ops.head_fold_ok(m.outconv.weight, kact, slope_t))))
+        if fuse_top:
+            y1, rec1 = _cgr_fwd(m.decoder1.ConvBnRelu2, u1, dtype, act, None, None, fp8, slots, no_act=True)
+            tape.append(rec1)
+            up1 = None
+            outs = [ops.gn_head(y1, rec1[5], m.outconv.weight, m.outconv.bias, kact)]
+        else:
+            up1 = cgr(m.decoder1.ConvBnRelu2, u1)
+            outs = [ops.head(up1, m.outconv.weight, m.outconv.bias, 1)]
+        ctx.top_fused = fuse_top
         heads = [(m.outconv, up1, 1)]
         if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
             for hd, src, sc in ((m.deep_bottom[0], bottom, 8), (m.deep_bottom2[0], bottom_2, 8), (m.deep3[0], up3, 4),
@@ -307,8 +325,8 @@ class _EquiUnetFn(torch.autograd.Function):
         for (hd, src, sc), dout in zip(ctx.heads, douts):
             if dout is None:
                 continue
-            if (hd is m.outconv and m.fold_head_bwd
-                    and ops.head_fold_ok(hd.weight, *_unit_act(m.decoder1.ConvBnRelu2, act))):
+            if hd is m.outconv and (ctx.top_fused or (m.fold_head_bwd
+                                                       and ops.head_fold_ok(hd.weight, *_unit_act(m.decoder1.ConvBnRelu2, act)))):
                 top = (hd, dout)
                 continue
             dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
@@ -389,6 +407,8 @@ class EquiUnet(_PackedWeightsModule):
         # the output head's backward inside the GroupNorm backward of the last layer (brats_gn_act_bwd_head); 0: the two-call
         # path (brats_head_bwd + brats_gn_act_bwd) for same-box A/B runs
         self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
+        # ... and its forward on the last layer's raw convolution output (brats_gn_head_fwd): up1 is never stored
+        self.fold_head_fwd = os.environ.get("BRATS_FOLD_HEAD_FWD", os.environ.get("BRATS_FOLD_HEAD", "1")) != "0"
         f = self.features
         nl = norm_layer
         self.encoder1 = UBlock(inplanes, f[0], f[0], norm=nl, act=act)

@@ -730,6 +730,20 @@ def head(x, weight, bias, scale=1):
     return out
 
 
+def gn_head(y, scale_shift, weight, bias, act="relu", slope=0.01):
+    """NCDHW f32 logits of the output head on act(GroupNorm(y)) without storing that activation
+    (include/brats_hip.h: brats_gn_head_fwd); bit-identical to head(affine_act(y, scale_shift, act), weight, bias)."""
+    ptr, c, p = _desc(y)
+    n, d, h, w, _ = y.shape
+    k = weight.shape[0]
+    wf = weight.detach().reshape(k, c).contiguous().float()
+    out = torch.empty((n, k, d, h, w), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().brats_gn_head_fwd(ptr, p, scale_shift.data_ptr(), ACTS[act], slope, wf.data_ptr(),
+                                            _f32(bias.detach()) if bias is not None else None, out.data_ptr(), _code(y.dtype), n, c,
+                                            k, d * h * w, _stream()), "gn_head_fwd")
+    return out
+
+
 def head_bwd(x, weight, dout, scale=1, want_dx=True):
     """Returns (dx | None, dweight [K,C,1,1,1], dbias [K])."""
     ptr, c, p = _desc(x)

@@ -312,6 +312,13 @@ int brats_upsample_bwd(const void* dy, int dypitch, void* dx, int dxpitch, void*
 int brats_head_fwd(const void* x, int xpitch, const float* w /*[K][C]*/, const float* b, float* lowres /*[N][K][D][H][W] ws*/,
                    float* out /*[N][K][D*s][H*s][W*s]*/, int dtype, int N, int C, int K,
                    int D, int H, int W, int scale, brats_stream_t s);
+/* The output head on the network's last layer WITHOUT storing that layer's activation: logits [N][K][voxels] =
+ * conv1x1(act(y * scale + shift)) + b with y the raw convolution output and scale_shift [N][C][2] from brats_gn_finalize --
+ * GroupNorm + relu / leakyrelu applied on load, rounded to the storage type exactly as the stored activation would be
+ * (bit-identical logits).  Replaces brats_affine_act_fwd + brats_head_fwd(scale 1) for that layer; with
+ * brats_gn_act_bwd_head the activation is not needed by the backward pass either. */
+int brats_gn_head_fwd(const void* y, int ypitch, const float* scale_shift, int act, float slope, const float* w /*[K][C]*/,
+                      const float* b, float* out, int dtype, int N, int C, int K, int voxels, brats_stream_t s);
 /* dout [N][K][Ds][Hs][Ws] f32 -> dx (NDHWC dtype, may be NULL), dw [K][C], db [K] (overwritten).
  * ws: f32 workspace of brats_head_bwd_ws_bytes() (up-sampling adjoint temporaries + per-block partial sums of dw / db,
  * added in a fixed order: no float atomics). */

@@ -153,6 +153,24 @@ def test_groupnorm_act_fwd_bwd(dtype, c, act):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,act,size,k", [(48, "relu", (8, 8, 8), 3), (16, "leakyrelu", (4, 6, 10), 3), (8, "relu", (3, 5, 7), 4),
+                                          (64, "relu", (4, 4, 8), 3), (96, "relu", (4, 4, 4), 2)])
+def test_output_head_on_raw_convolution_output_is_bit_identical(dtype, c, act, size, k):
+    """brats_gn_head_fwd (GroupNorm + act applied on load, the activation never stored) == head(affine_act(y)) bit for bit,
+    in every storage type, on the MFMA form (16-bit, C <= 64) and the generic form."""
+    from brats21_amd import ops
+    dev = _dev()
+    n, vox = 2, size[0] * size[1] * size[2]
+    y = _to_ndhwc(_q(_rand((n, c, *size), 71), dtype), dtype, dev)
+    ss = torch.stack([1.0 + 0.3 * _rand((n, c), 72), 0.2 * _rand((n, c), 73)], -1).contiguous().to(dev)
+    hw = _rand((k, c, 1, 1, 1), 74, 0.2).to(dev)
+    hb = _rand((k,), 75, 0.1).to(dev)
+    ref = ops.head(ops.affine_act(y, ss, act), hw, hb, 1)
+    got = ops.gn_head(y, ss, hw, hb, act)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("c,act,size", [(48, "relu", (8, 8, 8)), (16, "leakyrelu", (4, 6, 10)), (8, "relu", (3, 5, 7))])
 def test_groupnorm_bwd_with_folded_output_head(dtype, c, act, size):
     """brats_gn_act_bwd_head (the last layer's GroupNorm backward computing dz = W_head^T dlogits on the fly, the head's
