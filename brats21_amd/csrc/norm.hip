@@ -280,6 +280,169 @@ extern "C" int BRATS_API(brats_affine_act_fwd)(const void* y, int ypitch, const 
   return 0;
 }
 
+// 16 bytes of a tensor kept as loaded (4 registers) until the arithmetic wants the 8 (4) floats: the head-fold passes hold four
+// voxels per thread in flight, unpacked up front they cost 32 registers and an occupancy step
+template <typename T> struct Raw16;
+template <> struct Raw16<bf16_t> {
+  typedef u32x4 type;
+  template <bool NT> static DEVI type load(const bf16_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)p); else return *(const u32x4*)p;
+  }
+  static DEVI void unpack(const type& v, float* o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2(v[i], o[2 * i], o[2 * i + 1]);
+  }
+};
+template <> struct Raw16<float> {
+  typedef f32x4 type;
+  template <bool NT> static DEVI type load(const float* p) { return *(const f32x4*)p; }
+  static DEVI void unpack(const type& v, float* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+};
+
+// ---- z = act(y*scale + shift) AND its 2x2x2 max pool (MaxAvgPool: [max | mean]) in one pass ---------------------------
+// The encoder levels end with ConvBnRelu -> MaxPool3d(2, 2) (networks/equiunet2020.py:469-475): z is written for the skip
+// connection and read right back by the pooling kernel (403 MB at 2 x 48 x 128^3).  Here a block walks (row pair, x segment)
+// items: a thread owns one x position x one 16-byte channel vector and the 2 x 2 (z, y) voxels above it -- 4 loads and 4
+// stores, each a contiguous run of the row across the lanes --; the thread of the even x gets its right-hand neighbour's four
+// values through LDS (the 6 lanes of a voxel may straddle a wave) and writes the pooled voxel.  Pooling sees the values as
+// stored (rounded to T), takes the max by the pooling kernel's rule (strict '>' in d, h, w order, NaN propagates) and the
+// mean in the same order: bit-identical to brats_affine_act_fwd + brats_maxpool2_fwd.  relu / leakyrelu.
+// (A first form gave a thread the whole window: its stores were 96-byte pieces at a 192-byte stride -- half-written lines
+// under the non-temporal hint -- and the fused pass was SLOWER than the two it replaced, 254 against 148 + 85 us.)
+template <typename T, bool NT = false>
+__global__ void __launch_bounds__(256) affine_act_pool_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
+                                                              T* __restrict__ z, int zpitch, T* __restrict__ p, int ppitch, int act,
+                                                              SlopeArg sl, int D, int H, int W, int C, int with_avg,
+                                                              uint32_t* __restrict__ amax) {
+  constexpr int VW = 16 / sizeof(T);
+  typedef typename Raw16<T>::type raw_t;
+  extern __shared__ __attribute__((aligned(16))) char pool_lds[];  // [2][blockDim.x][4] raw_t
+  raw_t* xch = (raw_t*)pool_lds;
+  const float slope = sl.p ? *sl.p : sl.v;
+  const bool relu = act == BRATS_ACT_RELU;
+  const int n = blockIdx.y;
+  const int cv = C / VW;
+  int xb = (blockDim.x / cv) & ~1;  // x positions per item: even, so that a pooling pair never straddles two items
+  if (xb > W) xb = W;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  const bool lane_on = myvl < xb;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int segs = (W + xb - 1) / xb;
+  const size_t items = (size_t)Do * Ho * segs, voxels = (size_t)D * H * W;
+  float sc[VW], sh[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) {
+    sc[j] = lane_on ? scale_shift[((size_t)n * C + c0 + j) * 2] : 0.f;
+    sh[j] = lane_on ? scale_shift[((size_t)n * C + c0 + j) * 2 + 1] : 0.f;
+  }
+  const T* yb = y + (size_t)n * voxels * ypitch + c0;
+  T* zb = z + (size_t)n * voxels * zpitch + c0;
+  T* pb = p + (size_t)n * Do * Ho * Wo * ppitch + c0;
+  float amx = 0.f;
+  int buf = 0;
+  for (size_t item = blockIdx.x; item < items; item += gridDim.x, buf ^= 1) {
+    const int seg = (int)(item % segs);
+    const size_t rp = item / segs;
+    const int yo = (int)(rp % Ho), zo = (int)(rp / Ho);
+    const int x = seg * xb + myvl;
+    const bool on = lane_on && x < W;
+    raw_t mine[4];
+    if (on) {
+      raw_t raw[4];
+      size_t vox[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // k = (dz, dy)
+        vox[k] = ((size_t)(2 * zo + (k >> 1)) * H + (2 * yo + (k & 1))) * W + x;
+        raw[k] = Raw16<T>::template load<NT>(yb + vox[k] * ypitch);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float a[VW];
+        Raw16<T>::unpack(raw[k], a);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          const float pre = a[j] * sc[j] + sh[j];
+          const float neg = relu ? 0.f : pre * slope;
+          a[j] = pre > 0.f ? pre : neg;
+        }
+        vstore<T, VW, NT>(zb + vox[k] * zpitch, a);
+        // the values as stored, packed: what the pooling half reads (its own and its neighbour's)
+        if constexpr (std::is_same<T, float>::value) {
+          mine[k] = raw_t{a[0], a[1], a[2], a[3]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) mine[k][q] = pack2(a[2 * q], a[2 * q + 1]);
+        }
+        if (amax) {
+          float r[VW];
+          Raw16<T>::unpack(mine[k], r);
+#pragma unroll
+          for (int j = 0; j < VW; ++j) amx = __builtin_fmaxf(amx, __builtin_fabsf(r[j]));
+        }
+        xch[((size_t)buf * blockDim.x + threadIdx.x) * 4 + k] = mine[k];
+      }
+    }
+    __syncthreads();  // (two buffers: the next item's writes cannot overtake this item's reads)
+    if (on && !(myvl & 1)) {
+      float mx[VW], sm[VW];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // pooling order: d, h, then w = (own, right-hand neighbour)
+        float a[VW], b[VW];
+        Raw16<T>::unpack(mine[k], a);
+        Raw16<T>::unpack(xch[((size_t)buf * blockDim.x + threadIdx.x + cv) * 4 + k], b);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          mx[j] = (a[j] > mx[j] || a[j] != a[j]) ? a[j] : mx[j];
+          sm[j] += a[j];
+          mx[j] = (b[j] > mx[j] || b[j] != b[j]) ? b[j] : mx[j];
+          sm[j] += b[j];
+        }
+      }
+      T* po = pb + (((size_t)zo * Ho + yo) * Wo + (x >> 1)) * ppitch;
+      Vec<T, VW>::store(po, mx);
+      if (with_avg) {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) sm[j] *= 0.125f;
+        Vec<T, VW>::store(po + C, sm);
+      }
+    }
+  }
+  if (amax) record_absmax<T>(amx, amax);
+}
+
+extern "C" int BRATS_API(brats_affine_act_pool_fwd)(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch, void* pooled,
+                                         int ppitch, int dtype, int act, float slope_value, const float* slope_dev, int N, int D,
+                                         int H, int W, int C, int with_avg, float* amax, brats_stream_t s) {
+  const SlopeArg slope{slope_value, slope_dev};
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!y || !z || !pooled || !scale_shift || C % vw || ypitch % vw || zpitch % vw || ppitch % vw || C / vw > 256 || ((D | H | W) & 1))
+    BRATS_FAIL(BRATS_E_ARG, "affine_act_pool_fwd: C / pitches multiples of %d (C <= %d), even spatial dims", vw, 256 * vw);
+  if (act > BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "affine_act_pool_fwd: relu / leakyrelu only (act=%d)", act);
+  int xb = (256 / (C / vw)) & ~1;
+  if (xb < 2) BRATS_FAIL(BRATS_E_UNSUPPORTED, "affine_act_pool_fwd: C=%d leaves no pooling pair per block", C);
+  if (xb > W) xb = W;
+  const size_t items = (size_t)(D / 2) * (H / 2) * ((W + xb - 1) / xb);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * D * H * W * C * 2);
+  const size_t cap = big ? 8192 : 2048;
+  dim3 grid((unsigned)(items < 1 ? 1 : (items > cap ? cap : items)), N);
+  const size_t lds = (size_t)2 * 256 * 4 * 16;
+  hipStream_t st = (hipStream_t)s;
+  uint32_t* am = (uint32_t*)amax;
+  if (big)
+    hipLaunchKernelGGL((affine_act_pool_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
+                       zpitch, (bf16_t*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am);
+  else if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL((affine_act_pool_kernel<bf16_t, false>), grid, dim3(256), lds, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
+                       zpitch, (bf16_t*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am);
+  else
+    hipLaunchKernelGGL((affine_act_pool_kernel<float, false>), grid, dim3(256), lds, st, (const float*)y, ypitch, scale_shift, (float*)z,
+                       zpitch, (float*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- backward of z = act(GN(y)) ----------------------------------------------------------------
 // pass 1: red[n][c] = { sum_v u, sum_v u*xhat },  u = dz * act'(y*scale+shift), xhat = (y-mean_g)*rstd_g
 // A thread owns one 16-byte channel vector (fixed for the whole kernel) and walks voxels: its per-channel constants
@@ -303,25 +466,6 @@ DEVI void lane_reduce_plane(float* scr, const float* a, bool live, int myvl, int
     put(c, t);
   }
 }
-
-// 16 bytes of a tensor kept as loaded (4 registers) until the arithmetic wants the 8 (4) floats: the head-fold passes hold four
-// voxels per thread in flight, unpacked up front they cost 32 registers and an occupancy step
-template <typename T> struct Raw16;
-template <> struct Raw16<bf16_t> {
-  typedef u32x4 type;
-  template <bool NT> static DEVI type load(const bf16_t* p) {
-    if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)p); else return *(const u32x4*)p;
-  }
-  static DEVI void unpack(const type& v, float* o) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) unpack2(v[i], o[2 * i], o[2 * i + 1]);
-  }
-};
-template <> struct Raw16<float> {
-  typedef f32x4 type;
-  template <bool NT> static DEVI type load(const float* p) { return *(const f32x4*)p; }
-  static DEVI void unpack(const type& v, float* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
-};
 
 // HK > 0 (brats_gn_act_bwd_head): the layer's output feeds ONLY a 1x1x1 head convolution (the network's last layer), so its
 // gradient is dz[v][c] = sum_k dl[k][v] * w[k][c] with K = HK logit planes: computed here from the 12 bytes of dl per voxel

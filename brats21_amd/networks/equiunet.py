@@ -121,7 +121,7 @@ def _unit_act(unit, act):
     return act, None
 
 
-def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False):
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
     -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
     x recorded); the normalise+act pass records the |max| of its own output for the next layer."""
@@ -142,9 +142,19 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
         return y, (unit, x, x2, y, mean_rstd, scale_shift)
     amax = slots.take() if slots is not None else None
     kact, slope_t = _unit_act(unit, act)
+    if pool and kact in ("relu", "leakyrelu") and y.numel() * y.element_size() >= (256 << 20):
+        # the layer ends an encoder level: normalise + act and the 2x2x2 max pool of the result in one pass -- for tensors
+        # beyond the Infinity Cache (the 128^3 level: 188 us against 148 + 85); smaller ones are re-read from the cache by
+        # the pooling kernel at no HBM cost and the two plain kernels are as fast (measured: 70 against 63 us)
+        z, pooled = ops.affine_act_pool(y, scale_shift, kact, amax=amax, slope_t=slope_t)
+        if amax is not None:
+            z._amax = pooled._amax = amax  # (max|pool(z)| <= max|z|: the pooled tensor inherits the scale source)
+        return (z, pooled), (unit, x, x2, y, mean_rstd, scale_shift)
     z = ops.affine_act(y, scale_shift, kact, out=out, amax=amax, slope_t=slope_t)
     if amax is not None:
         z._amax = amax
+    if pool:
+        return (z, _inherit_amax(ops.maxpool2(z), z)), (unit, x, x2, y, mean_rstd, scale_shift)
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
@@ -247,13 +257,10 @@ class _EquiUnetFn(torch.autograd.Function):
         fp8 = m.conv_fp8 if ops.is16(dtype) else None
         slots = _AmaxSlots(32, dev) if fp8 else None
 
-        def cgr(unit, xin, x2=None):
-            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots)
+        def cgr(unit, xin, x2=None, pool=False):
+            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=pool)
             tape.append(rec)
             return z
-
-        def pool(t):
-            return _inherit_amax(ops.maxpool2(t), t)
 
         def up(t):
             return _inherit_amax(ops.upsample(t, 2), t)
@@ -261,10 +268,11 @@ class _EquiUnetFn(torch.autograd.Function):
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if ops.is16(dtype) else 4)
         # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
         # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
-        down1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0))
-        down2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, pool(down1)))
-        down3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, pool(down2)))
-        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, pool(down3)))
+        # (the last layer of a level writes its activation -- the skip connection -- and the max-pooled tensor in one pass)
+        down1, p1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0), pool=True)
+        down2, p2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, p1), pool=True)
+        down3, p3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, p2), pool=True)
+        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, p3))
         # bottom (:477-478): dilated block, then conv over cat[down4, bottom]
         bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4))
         bottom_2 = cgr(m.bottom_2, down4, x2=bottom)

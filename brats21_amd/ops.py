@@ -610,6 +610,20 @@ def affine_act(y, scale_shift, act="relu", out=None, slope=0.01, amax=None, slop
     return out
 
 
+def affine_act_pool(y, scale_shift, act="relu", slope=0.01, amax=None, slope_t=None, with_avg=False):
+    """(z, pooled) = (affine_act(y), maxpool2(z)) in one pass (include/brats_hip.h: brats_affine_act_pool_fwd)."""
+    ptr, c, p = _desc(y)
+    n, d, h, w, _ = y.shape
+    z = new_act(n, d, h, w, c, y.dtype, y.device)
+    pooled = new_act(n, d // 2, h // 2, w // 2, c * (2 if with_avg else 1), y.dtype, y.device)
+    zp, _, zpitch = _desc(z)
+    pp, _, ppitch = _desc(pooled)
+    _lib.check(_lib.lib().brats_affine_act_pool_fwd(ptr, p, scale_shift.data_ptr(), zp, zpitch, pp, ppitch, _code(y.dtype), ACTS[act],
+                                                    slope, _f32(slope_t), n, d, h, w, c, int(with_avg), _f32(amax), _stream()),
+               "affine_act_pool_fwd")
+    return z, pooled
+
+
 def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None, slope_t=None):
     """Returns (dy, dgamma, dbeta) for z = act(GroupNorm(y)); amax (optional, zero-initialised) receives max|dy|."""
     dzp, c, dzpitch = _desc(dz)

@@ -176,6 +176,12 @@ int brats_gn_finalize(const float* stats, int tiles_per_sample, int N, int C, in
 int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch,
                          int dtype, int act, float slope, const float* slope_dev, int N, int voxels, int C, float* amax,
                          brats_stream_t s);
+/* The same pass for a layer that ends an encoder level (ConvBnRelu -> MaxPool3d(2, 2), equiunet2020.py:469-475): writes z
+ * AND its 2x2x2 max pool (with_avg: MaxAvgPool's [max | mean], 2C channels) -- z is not read back by a pooling kernel.
+ * Bit-identical to brats_affine_act_fwd + brats_maxpool2_fwd; relu / leakyrelu; amax receives max|z|. */
+int brats_affine_act_pool_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch, void* pooled,
+                              int ppitch, int dtype, int act, float slope, const float* slope_dev, int N, int D, int H,
+                              int W, int C, int with_avg, float* amax, brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
  * u = dz * act'(.) into `red` (workspace of brats_gn_bwd_ws_floats() elements); pass 2 writes dy and finishes
  * dgamma/dbeta [C]. */

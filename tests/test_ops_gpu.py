@@ -215,6 +215,24 @@ def test_groupnorm_bwd_with_folded_output_head(dtype, c, act, size):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,act,size,with_avg", [(48, "relu", (8, 8, 8), False), (16, "leakyrelu", (4, 6, 10), False),
+                                                  (8, "relu", (2, 6, 14), True), (96, "relu", (4, 4, 4), False)])
+def test_affine_act_with_fused_maxpool_is_bit_identical(dtype, c, act, size, with_avg):
+    """brats_affine_act_pool_fwd == brats_affine_act_fwd followed by brats_maxpool2_fwd, bit for bit (z, pooled, |max|)."""
+    from brats21_amd import ops
+    dev = _dev()
+    n = 2
+    y = _to_ndhwc(_q(_rand((n, c, *size), 81), dtype), dtype, dev)
+    ss = torch.stack([1.0 + 0.3 * _rand((n, c), 82), 0.2 * _rand((n, c), 83)], -1).contiguous().to(dev)
+    a_ref = torch.zeros(1, device=dev)
+    z_ref = ops.affine_act(y, ss, act, amax=a_ref)
+    p_ref = ops.maxpool2(z_ref, with_avg)
+    a_got = torch.zeros(1, device=dev)
+    z, pooled = ops.affine_act_pool(y, ss, act, amax=a_got, with_avg=with_avg)
+    assert torch.equal(z, z_ref) and torch.equal(pooled, p_ref) and torch.equal(a_got, a_ref)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("with_avg", [False, True])
 def test_pool_fwd_bwd(dtype, with_avg):
     from brats21_amd import ops
