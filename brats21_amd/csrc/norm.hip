@@ -309,11 +309,11 @@ template <> struct Raw16<float> {
 // mean in the same order: bit-identical to brats_affine_act_fwd + brats_maxpool2_fwd.  relu / leakyrelu.
 // (A first form gave a thread the whole window: its stores were 96-byte pieces at a 192-byte stride -- half-written lines
 // under the non-temporal hint -- and the fused pass was SLOWER than the two it replaced, 254 against 148 + 85 us.)
-template <typename T, bool NT = false>
+template <typename T, bool NT = false, bool AM = false>
 __global__ void __launch_bounds__(256) affine_act_pool_kernel(const T* __restrict__ y, int ypitch, const float* __restrict__ scale_shift,
                                                               T* __restrict__ z, int zpitch, T* __restrict__ p, int ppitch, int act,
                                                               SlopeArg sl, int D, int H, int W, int C, int with_avg,
-                                                              uint32_t* __restrict__ amax) {
+                                                              uint32_t* __restrict__ amax, uint8_t* __restrict__ argmax) {
   constexpr int VW = 16 / sizeof(T);
   typedef typename Raw16<T>::type raw_t;
   extern __shared__ __attribute__((aligned(16))) char pool_lds[];  // [2][blockDim.x][4] raw_t
@@ -385,8 +385,9 @@ __global__ void __launch_bounds__(256) affine_act_pool_kernel(const T* __restric
     __syncthreads();  // (two buffers: the next item's writes cannot overtake this item's reads)
     if (on && !(myvl & 1)) {
       float mx[VW], sm[VW];
+      int am[VW];  // the first arg-max in d, h, w order (torch's tie rule), 0..7: what the pooling backward recomputes
 #pragma unroll
-      for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; }
+      for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; am[j] = 0; }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {  // pooling order: d, h, then w = (own, right-hand neighbour)
         float a[VW], b[VW];
@@ -394,13 +395,26 @@ __global__ void __launch_bounds__(256) affine_act_pool_kernel(const T* __restric
         Raw16<T>::unpack(xch[((size_t)buf * blockDim.x + threadIdx.x + cv) * 4 + k], b);
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
-          mx[j] = (a[j] > mx[j] || a[j] != a[j]) ? a[j] : mx[j];
-          sm[j] += a[j];
-          mx[j] = (b[j] > mx[j] || b[j] != b[j]) ? b[j] : mx[j];
-          sm[j] += b[j];
+          if constexpr (AM) {
+            if (a[j] > mx[j] || a[j] != a[j]) { mx[j] = a[j]; am[j] = 2 * k; }
+            if (b[j] > mx[j] || b[j] != b[j]) { mx[j] = b[j]; am[j] = 2 * k + 1; }
+          } else {
+            mx[j] = (a[j] > mx[j] || a[j] != a[j]) ? a[j] : mx[j];
+            mx[j] = (b[j] > mx[j] || b[j] != b[j]) ? b[j] : mx[j];
+          }
+          sm[j] = (sm[j] + a[j]) + b[j];
         }
       }
-      T* po = pb + (((size_t)zo * Ho + yo) * Wo + (x >> 1)) * ppitch;
+      const size_t pvox = ((size_t)zo * Ho + yo) * Wo + (x >> 1);
+      T* po = pb + pvox * ppitch;
+      if constexpr (AM) {  // one byte per (pooled voxel, channel): brats_maxpool2_bwd_idx reads these instead of the 8 window voxels
+        uint32_t w[VW / 4];
+#pragma unroll
+        for (int q = 0; q < VW / 4; ++q) w[q] = am[4 * q] | (am[4 * q + 1] << 8) | (am[4 * q + 2] << 16) | (am[4 * q + 3] << 24);
+        uint32_t* ap = (uint32_t*)(argmax + ((size_t)n * Do * Ho * Wo + pvox) * C + c0);
+#pragma unroll
+        for (int q = 0; q < VW / 4; ++q) ap[q] = w[q];
+      }
       Vec<T, VW>::store(po, mx);
       if (with_avg) {
 #pragma unroll
@@ -413,8 +427,9 @@ __global__ void __launch_bounds__(256) affine_act_pool_kernel(const T* __restric
 }
 
 extern "C" int BRATS_API(brats_affine_act_pool_fwd)(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch, void* pooled,
-                                         int ppitch, int dtype, int act, float slope_value, const float* slope_dev, int N, int D,
-                                         int H, int W, int C, int with_avg, float* amax, brats_stream_t s) {
+                                         int ppitch, unsigned char* argmax, int dtype, int act, float slope_value,
+                                         const float* slope_dev, int N, int D, int H, int W, int C, int with_avg, float* amax,
+                                         brats_stream_t s) {
   const SlopeArg slope{slope_value, slope_dev};
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!y || !z || !pooled || !scale_shift || C % vw || ypitch % vw || zpitch % vw || ppitch % vw || C / vw > 256 || ((D | H | W) & 1))
@@ -430,15 +445,14 @@ extern "C" int BRATS_API(brats_affine_act_pool_fwd)(const void* y, int ypitch, c
   const size_t lds = (size_t)2 * 256 * 4 * 16;
   hipStream_t st = (hipStream_t)s;
   uint32_t* am = (uint32_t*)amax;
-  if (big)
-    hipLaunchKernelGGL((affine_act_pool_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
-                       zpitch, (bf16_t*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am);
-  else if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL((affine_act_pool_kernel<bf16_t, false>), grid, dim3(256), lds, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
-                       zpitch, (bf16_t*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am);
-  else
-    hipLaunchKernelGGL((affine_act_pool_kernel<float, false>), grid, dim3(256), lds, st, (const float*)y, ypitch, scale_shift, (float*)z,
-                       zpitch, (float*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am);
+#define POOL_GO(T, NT, AM) hipLaunchKernelGGL((affine_act_pool_kernel<T, NT, AM>), grid, dim3(256), lds, st, (const T*)y, ypitch, scale_shift, \
+                                              (T*)z, zpitch, (T*)pooled, ppitch, act, slope, D, H, W, C, with_avg, am, argmax)
+  if (argmax) {
+    if (big) POOL_GO(bf16_t, true, true); else if (dtype == BRATS_BF16) POOL_GO(bf16_t, false, true); else POOL_GO(float, false, true);
+  } else {
+    if (big) POOL_GO(bf16_t, true, false); else if (dtype == BRATS_BF16) POOL_GO(bf16_t, false, false); else POOL_GO(float, false, false);
+  }
+#undef POOL_GO
   BRATS_CHECK_LAUNCH();
   return 0;
 }

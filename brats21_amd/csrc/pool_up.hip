@@ -11,9 +11,11 @@ static inline int stream_grid(size_t total, int block) {
 }
 
 // ---- pooling -----------------------------------------------------------------------------------
+// argmax (optional): one byte per (pooled voxel, channel) = the window index 0..7 (d, h, w order) of torch's first arg-max;
+// brats_maxpool2_bwd_idx reads these instead of the window
 template <typename T>
 __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xpitch, T* __restrict__ y, int ypitch, int N, int C,
-                                    int D, int H, int W, int with_avg) {
+                                    int D, int H, int W, int with_avg, uint8_t* __restrict__ argmax) {
   constexpr int VW = 16 / sizeof(T);
   const int cv = C / VW, Do = D / 2, Ho = H / 2, Wo = W / 2;
   const size_t total = (size_t)N * Do * Ho * Wo * cv;
@@ -25,17 +27,27 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int xpitch, T* __re
     const int zo = v % Do;
     const int n = (int)(v / Do);
     float mx[VW], sm[VW];
+    int am[VW];
 #pragma unroll
-    for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; }
+    for (int j = 0; j < VW; ++j) { mx[j] = -INFINITY; sm[j] = 0.f; am[j] = 0; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int z = 2 * zo + (k >> 2), yy = 2 * yo + ((k >> 1) & 1), xx = 2 * xo + (k & 1);
       float a[VW];
       Vec<T, VW>::load(x + ((((size_t)n * D + z) * H + yy) * W + xx) * xpitch + c0, a);
 #pragma unroll
-      for (int j = 0; j < VW; ++j) { mx[j] = (a[j] > mx[j] || a[j] != a[j]) ? a[j] : mx[j]; sm[j] += a[j]; }
+      for (int j = 0; j < VW; ++j) {
+        if (a[j] > mx[j] || a[j] != a[j]) { mx[j] = a[j]; am[j] = k; }
+        sm[j] += a[j];
+      }
     }
-    T* yo_p = y + ((((size_t)n * Do + zo) * Ho + yo) * Wo + xo) * ypitch;
+    const size_t pvox = (((size_t)n * Do + zo) * Ho + yo) * Wo + xo;
+    T* yo_p = y + pvox * ypitch;
+    if (argmax) {
+      uint32_t* ap = (uint32_t*)(argmax + pvox * C + c0);
+#pragma unroll
+      for (int q = 0; q < VW / 4; ++q) ap[q] = am[4 * q] | (am[4 * q + 1] << 8) | (am[4 * q + 2] << 16) | (am[4 * q + 3] << 24);
+    }
     Vec<T, VW>::store(yo_p + c0, mx);
     if (with_avg) {
 #pragma unroll
@@ -102,18 +114,103 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int xpitch, const T
   }
 }
 
-extern "C" int BRATS_API(brats_maxpool2_fwd)(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C, int D, int H,
-                                  int W, int with_avg, brats_stream_t s) {
+// The same backward from a RECORDED arg-max (one byte per pooled voxel and channel, written by brats_affine_act_pool_fwd): the
+// 8 window voxels of x (403 MB at 2 x 48 x 128^3) are not read again.  A thread owns one x position x one 16-byte channel
+// vector and the 2 x 2 (z, y) voxels above it: its 4 skip-gradient loads and 4 stores are contiguous runs of a row across the
+// lanes; the pooled gradient and the arg-max bytes are read by both threads of an x pair.  Same arithmetic as
+// maxpool2_bwd_kernel ((avg / 8 + [k == argmax] * dy) + skip): bit-identical.
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool2_bwd_idx_kernel(const uint8_t* __restrict__ argmax, const T* __restrict__ dy, int dypitch,
+                                                               const T* __restrict__ dxs, int dxspitch, T* __restrict__ dx, int dxpitch,
+                                                               int C, int D, int H, int W, int with_avg) {
+  constexpr int VW = 16 / sizeof(T);
+  const int n = blockIdx.y;
+  const int cv = C / VW;
+  int xb = blockDim.x / cv;
+  if (xb > W) xb = W;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  const int Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int segs = (W + xb - 1) / xb;
+  const size_t items = (size_t)Do * Ho * segs, voxels = (size_t)D * H * W, pvoxels = (size_t)Do * Ho * Wo;
+  if (myvl >= xb) return;
+  const T* dyb = dy + (size_t)n * pvoxels * dypitch + c0;
+  const T* sb = dxs ? dxs + (size_t)n * voxels * dxspitch + c0 : nullptr;
+  T* ob = dx + (size_t)n * voxels * dxpitch + c0;
+  const uint8_t* ab = argmax + (size_t)n * pvoxels * C + c0;
+  for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const int seg = (int)(item % segs);
+    const size_t rp = item / segs;
+    const int yo = (int)(rp % Ho), zo = (int)(rp / Ho);
+    const int x = seg * xb + myvl;
+    if (x >= W) continue;
+    const size_t pvox = ((size_t)zo * Ho + yo) * Wo + (x >> 1);
+    float sk[4][VW];
+    size_t vox[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      vox[k] = ((size_t)(2 * zo + (k >> 1)) * H + (2 * yo + (k & 1))) * W + x;
+      if (sb) Vec<T, VW>::load(sb + vox[k] * dxspitch, sk[k]);
+    }
+    uint32_t aw[VW / 4];
+#pragma unroll
+    for (int q = 0; q < VW / 4; ++q) aw[q] = ((const uint32_t*)(ab + pvox * C))[q];
+    float g[VW], ga[VW];
+    Vec<T, VW>::load(dyb + pvox * dypitch, g);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) ga[j] = 0.f;
+    if (with_avg) {
+      Vec<T, VW>::load(dyb + pvox * dypitch + C, ga);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) ga[j] *= 0.125f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int kk = 2 * k + (x & 1);  // the voxel's index in the window, d, h, w order
+      float o[VW];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const int am = (aw[j >> 2] >> (8 * (j & 3))) & 0xff;
+        o[j] = ga[j] + (am == kk ? g[j] : 0.f);
+        if (sb) o[j] += sk[k][j];
+      }
+      Vec<T, VW>::store(ob + vox[k] * dxpitch, o);
+    }
+  }
+}
+
+extern "C" int BRATS_API(brats_maxpool2_bwd_idx)(const unsigned char* argmax, const void* dy, int dypitch, const void* dx_skip,
+                                      int dxskip_pitch, void* dx, int dxpitch, int dtype, int N, int C, int D, int H, int W,
+                                      int with_avg, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!argmax || !dy || !dx || C % vw || dypitch % vw || dxpitch % vw || (dx_skip && dxskip_pitch % vw) || ((D | H | W) & 1) ||
+      C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "maxpool2_bwd_idx: bad argument");
+  int xb = 256 / (C / vw);
+  if (xb > W) xb = W;
+  const size_t items = (size_t)(D / 2) * (H / 2) * ((W + xb - 1) / xb);
+  dim3 grid((unsigned)(items < 1 ? 1 : (items > 8192 ? 8192 : items)), N);
+  if (dtype == BRATS_BF16)
+    hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, argmax, (const bf16_t*)dy, dypitch,
+                       (const bf16_t*)dx_skip, dxskip_pitch, (bf16_t*)dx, dxpitch, C, D, H, W, with_avg);
+  else
+    hipLaunchKernelGGL(maxpool2_bwd_idx_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, argmax, (const float*)dy, dypitch,
+                       (const float*)dx_skip, dxskip_pitch, (float*)dx, dxpitch, C, D, H, W, with_avg);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int BRATS_API(brats_maxpool2_fwd)(const void* x, int xpitch, void* y, int ypitch, unsigned char* argmax, int dtype, int N,
+                                  int C, int D, int H, int W, int with_avg, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
   if (!x || !y || C % vw || xpitch % vw || ypitch % vw || (D | H | W) & 1)
     BRATS_FAIL(BRATS_E_ARG, "maxpool2_fwd: C/pitch multiple of %d and even spatial dims required", vw);
   const size_t total = (size_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vw);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
-                       (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch, N, C, D, H, W, with_avg);
+                       (const bf16_t*)x, xpitch, (bf16_t*)y, ypitch, N, C, D, H, W, with_avg, argmax);
   else
     hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)s,
-                       (const float*)x, xpitch, (float*)y, ypitch, N, C, D, H, W, with_avg);
+                       (const float*)x, xpitch, (float*)y, ypitch, N, C, D, H, W, with_avg, argmax);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

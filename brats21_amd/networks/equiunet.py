@@ -146,7 +146,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
         # the layer ends an encoder level: normalise + act and the 2x2x2 max pool of the result in one pass -- for tensors
         # beyond the Infinity Cache (the 128^3 level: 188 us against 148 + 85); smaller ones are re-read from the cache by
         # the pooling kernel at no HBM cost and the two plain kernels are as fast (measured: 70 against 63 us)
-        z, pooled = ops.affine_act_pool(y, scale_shift, kact, amax=amax, slope_t=slope_t)
+        z, pooled = ops.affine_act_pool(y, scale_shift, kact, amax=amax, slope_t=slope_t, want_argmax=pool == "argmax")
         if amax is not None:
             z._amax = pooled._amax = amax  # (max|pool(z)| <= max|z|: the pooled tensor inherits the scale source)
         return (z, pooled), (unit, x, x2, y, mean_rstd, scale_shift)
@@ -154,7 +154,7 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
     if amax is not None:
         z._amax = amax
     if pool:
-        return (z, _inherit_amax(ops.maxpool2(z), z)), (unit, x, x2, y, mean_rstd, scale_shift)
+        return (z, _inherit_amax(ops.maxpool2(z, want_argmax=pool == "argmax"), z)), (unit, x, x2, y, mean_rstd, scale_shift)
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
@@ -257,8 +257,11 @@ class _EquiUnetFn(torch.autograd.Function):
         fp8 = m.conv_fp8 if ops.is16(dtype) else None
         slots = _AmaxSlots(32, dev) if fp8 else None
 
+        will_bwd = any(ctx.needs_input_grad)
+
         def cgr(unit, xin, x2=None, pool=False):
-            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=pool)
+            # (training: the fused pooling pass also records the arg-max bytes its backward reads)
+            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=("argmax" if will_bwd else True) if pool else False)
             tape.append(rec)
             return z
 
@@ -285,7 +288,6 @@ class _EquiUnetFn(torch.autograd.Function):
         # needs (ops.gn_act_bwd_head) -- up1 (2 x 403 MB written + read at 2 x 48 x 128^3) is never stored
         kact, slope_t = _unit_act(m.decoder1.ConvBnRelu2, act)
         nk = m.outconv.weight.shape[0]
-        will_bwd = any(ctx.needs_input_grad)
         fuse_top = (m.fold_head_fwd and slope_t is None and kact in ("relu", "leakyrelu") and nk <= 4
                     and (not will_bwd or (m.fold_head_bwd and ops.head_fold_ok(m.outconv.weight, kact, slope_t))))
         if fuse_top:

@@ -274,8 +274,11 @@ class _AsspFn(torch.autograd.Function):
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if ops.is16(dtype) else 4)
+        will_bwd = any(ctx.needs_input_grad)
+
         def pool(t):  # max and average of a 2x2x2 cell never exceed the |max| of the input
-            return _inherit_amax(ops.maxpool2(t, with_avg=True), t)
+            # (training: the arg-max bytes go along, the pooling backward reads them instead of the window)
+            return _inherit_amax(ops.maxpool2(t, with_avg=True, want_argmax=will_bwd), t)
 
         def cat_amax(cat, a, b):  # a concat buffer written by two producers: |max| = the larger of theirs
             if cx.fp8 and hasattr(a, "_amax") and hasattr(b, "_amax"):

@@ -610,17 +610,23 @@ def affine_act(y, scale_shift, act="relu", out=None, slope=0.01, amax=None, slop
     return out
 
 
-def affine_act_pool(y, scale_shift, act="relu", slope=0.01, amax=None, slope_t=None, with_avg=False):
-    """(z, pooled) = (affine_act(y), maxpool2(z)) in one pass (include/brats_hip.h: brats_affine_act_pool_fwd)."""
+def affine_act_pool(y, scale_shift, act="relu", slope=0.01, amax=None, slope_t=None, with_avg=False, want_argmax=False):
+    """(z, pooled) = (affine_act(y), maxpool2(z)) in one pass (include/brats_hip.h: brats_affine_act_pool_fwd).
+    want_argmax: z._pool_argmax = the uint8 window index of every pooled element, which maxpool2_bwd(z, ...) then reads
+    instead of the window itself."""
     ptr, c, p = _desc(y)
     n, d, h, w, _ = y.shape
     z = new_act(n, d, h, w, c, y.dtype, y.device)
     pooled = new_act(n, d // 2, h // 2, w // 2, c * (2 if with_avg else 1), y.dtype, y.device)
+    idx = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=torch.uint8, device=y.device) if want_argmax else None
     zp, _, zpitch = _desc(z)
     pp, _, ppitch = _desc(pooled)
-    _lib.check(_lib.lib().brats_affine_act_pool_fwd(ptr, p, scale_shift.data_ptr(), zp, zpitch, pp, ppitch, _code(y.dtype), ACTS[act],
+    _lib.check(_lib.lib().brats_affine_act_pool_fwd(ptr, p, scale_shift.data_ptr(), zp, zpitch, pp, ppitch,
+                                                    idx.data_ptr() if idx is not None else None, _code(y.dtype), ACTS[act],
                                                     slope, _f32(slope_t), n, d, h, w, c, int(with_avg), _f32(amax), _stream()),
                "affine_act_pool_fwd")
+    if idx is not None:
+        z._pool_argmax = idx
     return z, pooled
 
 
@@ -681,15 +687,20 @@ def prelu_slope_grad(dz, y, scale_shift):
 
 
 # ------------------------------------------------------------------------------------------ pool / upsample
-def maxpool2(x, with_avg=False, out=None):
+def maxpool2(x, with_avg=False, out=None, want_argmax=False):
+    """want_argmax (training): x._pool_argmax = the uint8 window index of every pooled element; maxpool2_bwd(x, ...) then
+    reads those bytes instead of the eight window voxels of x."""
     ptr, c, p = _desc(x)
     n, d, h, w, _ = x.shape
     co = 2 * c if with_avg else c
     if out is None:
         out = new_act(n, d // 2, h // 2, w // 2, co, x.dtype, x.device)
     optr, oc, op = _desc(out)
-    _lib.check(_lib.lib().brats_maxpool2_fwd(ptr, p, optr, op, _code(x.dtype), n, c, d, h, w, int(with_avg), _stream()),
-               "maxpool2_fwd")
+    idx = torch.empty((n, d // 2, h // 2, w // 2, c), dtype=torch.uint8, device=x.device) if want_argmax else None
+    _lib.check(_lib.lib().brats_maxpool2_fwd(ptr, p, optr, op, idx.data_ptr() if idx is not None else None, _code(x.dtype), n, c, d,
+                                             h, w, int(with_avg), _stream()), "maxpool2_fwd")
+    if idx is not None:
+        x._pool_argmax = idx
     return out
 
 
@@ -701,6 +712,11 @@ def maxpool2_bwd(x, dy, dx_skip=None, with_avg=False):
     sptr, sp = (None, 0)
     if dx_skip is not None:
         sptr, _, sp = _desc(dx_skip)
+    idx = getattr(x, "_pool_argmax", None)
+    if idx is not None:  # recorded by affine_act_pool: the window voxels of x are not read again
+        _lib.check(_lib.lib().brats_maxpool2_bwd_idx(idx.data_ptr(), dptr, dp, sptr, sp, dx.data_ptr(), c, _code(x.dtype), n, c,
+                                                     d, h, w, int(with_avg), _stream()), "maxpool2_bwd_idx")
+        return dx
     _lib.check(_lib.lib().brats_maxpool2_bwd(ptr, p, None, 0, dptr, dp, sptr, sp, dx.data_ptr(), c, _code(x.dtype), n, c,
                                              d, h, w, int(with_avg), _stream()), "maxpool2_bwd")
     return dx

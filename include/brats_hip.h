@@ -180,8 +180,10 @@ int brats_affine_act_fwd(const void* y, int ypitch, const float* scale_shift, vo
  * AND its 2x2x2 max pool (with_avg: MaxAvgPool's [max | mean], 2C channels) -- z is not read back by a pooling kernel.
  * Bit-identical to brats_affine_act_fwd + brats_maxpool2_fwd; relu / leakyrelu; amax receives max|z|. */
 int brats_affine_act_pool_fwd(const void* y, int ypitch, const float* scale_shift, void* z, int zpitch, void* pooled,
-                              int ppitch, int dtype, int act, float slope, const float* slope_dev, int N, int D, int H,
-                              int W, int C, int with_avg, float* amax, brats_stream_t s);
+                              int ppitch, unsigned char* argmax /* optional: [N][D/2][H/2][W/2][C] bytes, the window index
+                              0..7 (d, h, w order) of torch's first arg-max: what brats_maxpool2_bwd_idx reads */,
+                              int dtype, int act, float slope, const float* slope_dev, int N, int D, int H, int W, int C,
+                              int with_avg, float* amax, brats_stream_t s);
 /* backward of z = act(GN(y)): pass 1 reduces, per (n,channel), sum(u) and sum(u*xhat) with
  * u = dz * act'(.) into `red` (workspace of brats_gn_bwd_ws_floats() elements); pass 2 writes dy and finishes
  * dgamma/dbeta [C]. */
@@ -297,12 +299,19 @@ int brats_dconv_pack_weights(const float* w, void* packed, int dtype, int mode, 
 int brats_dconv_run(const brats_dconv_job* jobs, int njobs, int dtype, int N, int D, int H, int W, brats_stream_t s);
 
 /* ---- pooling (nn.MaxPool3d(2,2) equiunet2020.py:433; MONAI MaxAvgPool equiunet2021.py:261) ---- */
-int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch, int dtype, int N, int C,
-                       int D, int H, int W, int with_avg, brats_stream_t s);
+int brats_maxpool2_fwd(const void* x, int xpitch, void* y, int ypitch,
+                       unsigned char* argmax /* optional: [N][D/2][H/2][W/2][C] bytes = the window index 0..7 (d, h, w
+                       order) of torch's first arg-max per pooled element, for brats_maxpool2_bwd_idx */,
+                       int dtype, int N, int C, int D, int H, int W, int with_avg, brats_stream_t s);
 /* dx = [dx_skip (may be NULL) +] maxpool^T(dy[..C]) [+ avgpool^T(dy[C..2C]) if with_avg] */
 int brats_maxpool2_bwd(const void* x, int xpitch, const void* y, int ypitch, const void* dy, int dypitch,
                        const void* dx_skip, int dxskip_pitch, void* dx, int dxpitch, int dtype,
                        int N, int C, int D, int H, int W, int with_avg, brats_stream_t s);
+/* The same backward from the arg-max bytes brats_affine_act_pool_fwd recorded: x is not read (8 window voxels per pooled
+ * voxel: 403 MB at 2 x 48 x 128^3); bit-identical to brats_maxpool2_bwd. */
+int brats_maxpool2_bwd_idx(const unsigned char* argmax, const void* dy, int dypitch, const void* dx_skip /*optional*/,
+                           int dxskip_pitch, void* dx, int dxpitch, int dtype, int N, int C, int D, int H, int W,
+                           int with_avg, brats_stream_t s);
 
 /* ---- trilinear up-sampling, align_corners=True (nn.Upsample equiunet2020.py:439,446-458) ------
  * NDHWC -> NDHWC (scale 2, into a concat slice) ... */

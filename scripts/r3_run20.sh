@@ -9,4 +9,4 @@ done
 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-parity-leg --infer-headline-only 2>>$out/ab.err | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print({k: v for k, v in r.get('inference', {}).items() if not isinstance(v, dict)})" >> $out/ab.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > $out/prof.log 2>&1
 f=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv; rm -rf $out/prof
-cat $out/summary.txt; tail -3 $out/pytest_ops.log; tail -3 $out/pytest_net.log; cat $out/ab.log | cut -c1-200; grep -E "affine|maxpool" $out/kernel_stats.csv | cut -c1-60,150-300
+cat $out/summary.txt; tail -3 $out/pytest_ops.log; tail -3 $out/pytest_net.log; cat $out/ab.log | cut -c1-200; grep -E "affine|maxpool" $out/kernel_stats.csv | cut -c1-60,150-300; head -1 $out/ab.log

@@ -228,8 +228,15 @@ def test_affine_act_with_fused_maxpool_is_bit_identical(dtype, c, act, size, wit
     z_ref = ops.affine_act(y, ss, act, amax=a_ref)
     p_ref = ops.maxpool2(z_ref, with_avg)
     a_got = torch.zeros(1, device=dev)
-    z, pooled = ops.affine_act_pool(y, ss, act, amax=a_got, with_avg=with_avg)
+    z, pooled = ops.affine_act_pool(y, ss, act, amax=a_got, with_avg=with_avg, want_argmax=True)
     assert torch.equal(z, z_ref) and torch.equal(pooled, p_ref) and torch.equal(a_got, a_ref)
+    # backward from the recorded arg-max bytes == backward that recomputes the arg-max from the window
+    dy = _to_ndhwc(_q(_rand((n, c * (2 if with_avg else 1), size[0] // 2, size[1] // 2, size[2] // 2), 84), dtype), dtype, dev)
+    skip = _to_ndhwc(_q(_rand((n, c, *size), 85), dtype), dtype, dev)
+    for sk in (None, skip):
+        ref = ops.maxpool2_bwd(z_ref, dy, dx_skip=sk, with_avg=with_avg)
+        got = ops.maxpool2_bwd(z, dy, dx_skip=sk, with_avg=with_avg)  # (z carries _pool_argmax)
+        assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -251,6 +258,12 @@ def test_pool_fwd_bwd(dtype, with_avg):
     torch.testing.assert_close(_from_ndhwc(y), y_ref.detach(), atol=_tol(dtype, 1e-6, 1e-2), rtol=0)
     dx = ops.maxpool2_bwd(xd, _to_ndhwc(dy, dtype, dev), dx_skip=_to_ndhwc(skip, dtype, dev, pitch=32, off=16), with_avg=with_avg)
     torch.testing.assert_close(_from_ndhwc(dx), xr.grad + skip, atol=_tol(dtype, 1e-6, 3e-2), rtol=_tol(dtype, 0, 1e-2))
+    # the forward that records the arg-max bytes + the backward that reads them: bit-identical to the pair above
+    xd2 = xd.clone()
+    y2 = ops.maxpool2(xd2, with_avg, want_argmax=True)
+    assert torch.equal(y2, y) and xd2._pool_argmax.dtype == torch.uint8
+    dx2 = ops.maxpool2_bwd(xd2, _to_ndhwc(dy, dtype, dev), dx_skip=_to_ndhwc(skip, dtype, dev, pitch=32, off=16), with_avg=with_avg)
+    assert torch.equal(dx2, dx)
 
 
 @pytest.mark.parametrize("dtype", DT)
