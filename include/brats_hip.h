@@ -40,7 +40,7 @@ enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
  * memory (`slope_dev` of brats_affine_act / brats_gn_bwd_apply) + brats_prelu_slope_grad for its gradient. */
 enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_ELU = 3, BRATS_ACT_SWISH = 4, BRATS_ACT_MISH = 5 };
 
-int brats_abi_version(void);
+int brats_abi_version(void); /* 2 since round 3: a changed signature (brats_maxpool2_fwd) bumps it */
 const char* brats_last_error(void);
 
 /* ---- layout ---------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(l, n), f"{n} declared in include/brats_hip.h but not exported"
-    assert _lib.lib().brats_abi_version() == 1
+    assert _lib.lib().brats_abi_version() == 2
 
 
 def test_host_side_queries_and_argument_errors():
@@ -42,7 +42,7 @@ def test_host_side_queries_and_argument_errors():
     # NULL pointers are rejected with an error string, never dereferenced
     rc = l.brats_conv3d_fwd(None, 8, 8, None, 0, 0, None, None, None, 8, None, 0, 0, None, _lib.BF16, 3, 1, 1, 8, 8, 8, 8, None)
     assert rc == -1 and b"conv3d_fwd" in l.brats_last_error()
-    rc = l.brats_maxpool2_fwd(None, 8, None, 8, _lib.BF16, 1, 8, 8, 8, 8, 0, None)
+    rc = l.brats_maxpool2_fwd(None, 8, None, 8, None, _lib.BF16, 1, 8, 8, 8, 8, 0, None)
     assert rc == -1
 
 
