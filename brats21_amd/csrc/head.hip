@@ -18,7 +18,14 @@ constexpr int HEAD_KMAX = 4;
 // PRE (brats_gn_head_fwd): x is the last layer's raw convolution output and the head reads z = act(x * scale + shift) --
 // GroupNorm + relu / leakyrelu applied on load, rounded to the storage type as the stored z would be -- so that z itself
 // (2 * C bytes per voxel written and read back) never exists.  pre.scale_shift: [N][C][2]; pre.nslope: 0 for relu.
-struct HeadPre { const float* scale_shift; float nslope; };
+// evo: the EvoNorm form z = x * sigmoid(x) * scale + shift (brats_evonorm_head_fwd: scale = rstd_g * gamma_c * (1 + gate),
+// shift = beta_c * (1 + gate) per (n, channel) -- the output of brats_evonorm_se_fwd's last pass, recomputed on load).
+struct HeadPre { const float* scale_shift; float nslope; int evo; };
+DEVI float head_pre(float x, float sc, float sh, const HeadPre& pre) {
+  if (pre.evo) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)) * sc + sh;  // (norm.hip: evonorm_fwd_kernel's expression)
+  const float p = x * sc + sh;
+  return p > 0.f ? p : p * pre.nslope;
+}
 template <typename T, bool PRE = false>
 __global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const float* __restrict__ w, const float* __restrict__ b,
                                  float* __restrict__ low, int C, int K, size_t voxels, HeadPre pre) {
@@ -49,10 +56,7 @@ __global__ void head_conv_kernel(const T* __restrict__ x, int xpitch, const floa
       Vec<T, VW>::load(xb + v * xpitch + c0, a);
       if constexpr (PRE) {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) {
-          const float p = a[j] * psc[j] + psh[j];
-          a[j] = to_f<T>(from_f<T>(p > 0.f ? p : p * pre.nslope));
-        }
+        for (int j = 0; j < VW; ++j) a[j] = to_f<T>(from_f<T>(head_pre(a[j], psc[j], psh[j], pre)));
       }
 #pragma unroll
       for (int k = 0; k < HEAD_KMAX; ++k)
@@ -106,9 +110,7 @@ __global__ void __launch_bounds__(256) head_conv_mfma_kernel(const bf16_t* __res
     for (int i = 0; i < 4; ++i) {
       float lo, hi;
       unpack2(u[i], lo, hi);
-      lo = lo * psc[s2][2 * i] + psh[s2][2 * i];
-      hi = hi * psc[s2][2 * i + 1] + psh[s2][2 * i + 1];
-      u[i] = pack2(lo > 0.f ? lo : lo * pre.nslope, hi > 0.f ? hi : hi * pre.nslope);
+      u[i] = pack2(head_pre(lo, psc[s2][2 * i], psh[s2][2 * i], pre), head_pre(hi, psc[s2][2 * i + 1], psh[s2][2 * i + 1], pre));
     }
     return __builtin_bit_cast(bf16x8, u);
   };
@@ -251,7 +253,18 @@ extern "C" int BRATS_API(brats_gn_head_fwd)(const void* y, int ypitch, const flo
     BRATS_FAIL(BRATS_E_ARG, "gn_head_fwd: bad argument (K<=4, C multiple of %d)", vw);
   if (act > BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_head_fwd: relu / leakyrelu only (act=%d)", act);
   return head_conv_launch<true>(y, ypitch, w, b, out, dtype, N, C, K, (size_t)voxels,
-                                HeadPre{scale_shift, act == BRATS_ACT_RELU ? 0.f : slope}, (hipStream_t)s);
+                                HeadPre{scale_shift, act == BRATS_ACT_RELU ? 0.f : slope, 0}, (hipStream_t)s);
+}
+
+// the same for EquiUnetASSPEvo's last block (EvoNorm + ResidualSELayer -> out_conv): logits = conv1x1(y * sigmoid(y) * scale +
+// shift) + bias with scale_shift [N][C][2] = { rstd_g * gamma_c * (1 + gate), beta_c * (1 + gate) } -- the block's output is
+// recomputed on load, rounded to the storage type as the stored tensor would be (bit-identical logits), never stored.
+extern "C" int BRATS_API(brats_evonorm_head_fwd)(const void* y, int ypitch, const float* scale_shift, const float* w, const float* b,
+                                      float* out, int dtype, int N, int C, int K, int voxels, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!y || !scale_shift || !w || !out || K < 1 || K > HEAD_KMAX || C % vw || ypitch % vw)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_head_fwd: bad argument (K<=4, C multiple of %d)", vw);
+  return head_conv_launch<true>(y, ypitch, w, b, out, dtype, N, C, K, (size_t)voxels, HeadPre{scale_shift, 0.f, 1}, (hipStream_t)s);
 }
 
 extern "C" int BRATS_API(brats_head_fwd)(const void* x, int xpitch, const float* w, const float* b, float* lowres, float* out,
@@ -263,7 +276,7 @@ extern "C" int BRATS_API(brats_head_fwd)(const void* x, int xpitch, const float*
   hipStream_t st = (hipStream_t)s;
   const size_t vox = (size_t)D * H * W;
   float* low = scale > 1 ? lowres : out;
-  if (int rc = head_conv_launch<false>(x, xpitch, w, b, low, dtype, N, C, K, vox, HeadPre{nullptr, 0.f}, st)) return rc;
+  if (int rc = head_conv_launch<false>(x, xpitch, w, b, low, dtype, N, C, K, vox, HeadPre{nullptr, 0.f, 0}, st)) return rc;
   if (scale > 1) {
     if ((W * scale) % 4) BRATS_FAIL(BRATS_E_UNSUPPORTED, "head_fwd: up-sampled width %d must be a multiple of 4", W * scale);
     const int items = H * scale * (W * scale / 4);

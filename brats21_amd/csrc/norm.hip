@@ -1104,7 +1104,7 @@ extern "C" int BRATS_API(brats_evonorm_se_fwd)(const void* x, int xpitch, const 
                                     float* ws, float* chansum_out, float* gate1p, float* hidden, int Ch, int dtype, int N,
                                     int voxels, int C, int groups, float* amax, brats_stream_t s) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
-  if (!x || !out || !mean_rstd || !gamma || !beta || !ws || !chansum_out || !gate1p || !hidden)
+  if (!x || !mean_rstd || !gamma || !beta || !ws || !chansum_out || !gate1p || !hidden)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_se_fwd: null pointer");
   if (C % vw || C % groups || xpitch % vw || opitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_se_fwd: bad argument (C, pitches multiples of %d)", vw);
@@ -1127,6 +1127,7 @@ extern "C" int BRATS_API(brats_evonorm_se_fwd)(const void* x, int xpitch, const 
   fold.numsum = ws; fold.mean_rstd = mean_rstd; fold.gamma = gamma; fold.beta = beta; fold.chansum_out = chansum_out;
   fold.groups = groups; fold.voxels = (float)voxels;
   if (int rc = brats_se_fwd_launch(nullptr, fold, 1.f / (float)voxels, w1, b1, w2, b2, gate1p, hidden, N, C, Ch, st)) return rc;
+  if (!out) return 0;  // (the consumer applies the gated EvoNorm on load: brats_evonorm_head_fwd)
   dim3 g2((unsigned)(gx < 1 ? 1 : (gx > CHAN_MAX_BLOCKS ? CHAN_MAX_BLOCKS : gx)), N);
   const size_t lds2 = (size_t)(2 * C + vl * C) * sizeof(float);
   if (big)

@@ -210,7 +210,9 @@ def _conv_evo_bwd(cx, rec, dz, need_dx=True, gscale=None, gadd=None):
     return _conv_any_bwd(cx, conv, saved, dy, need_dx, db=dcb)
 
 
-def _block_fwd(cx, blk, x, out=None):
+def _block_fwd(cx, blk, x, out=None, head=None):
+    """head: the 1x1x1 output head module when the block's output feeds nothing else -- the block then returns the head's
+    logits instead of its output tensor, which is recomputed on load inside the head kernel and never stored."""
     s = blk.conv_conv_se
     z1, _, r1 = _conv_evo_fwd(cx, s[0], s[1], x)
     # second conv + EvoNorm + ResidualSELayer (out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2)) as one call: a statistics
@@ -220,12 +222,18 @@ def _block_fwd(cx, blk, x, out=None):
     n, d, h, w, c = y.shape
     mr, chan = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
+    rec2 = (conv, evo, saved, y, mr, chan)
+    if head is not None:
+        _, cs, gate1p, hidden = ops.evonorm_se(y, mr, _flat(evo.gamma), _flat(evo.beta), fc1.weight, fc1.bias, fc2.weight, fc2.bias, 8,
+                                               apply=False)
+        logits = ops.evonorm_head(y, mr, _flat(evo.gamma), _flat(evo.beta), gate1p, head.weight, head.bias, 8)
+        return logits, (blk, r1, rec2, cs, hidden, gate1p)
     amax = cx.slot(y.device)
     o, cs, gate1p, hidden = ops.evonorm_se(y, mr, _flat(evo.gamma), _flat(evo.beta), fc1.weight, fc1.bias, fc2.weight, fc2.bias, 8,
                                            out=out, amax=amax)
     if amax is not None:
         o._amax = amax
-    return o, (blk, r1, (conv, evo, saved, y, mr, chan), cs, hidden, gate1p)
+    return o, (blk, r1, rec2, cs, hidden, gate1p)
 
 
 def _block_bwd(cx, rec, do, need_dx=True, head=None):
@@ -311,8 +319,18 @@ class _AsspFn(torch.autograd.Function):
         uc1, _, ru1 = _conv_evo_fwd(cx, m.upconv1.conv, m.upconv1.evo, up2)
         ops.upsample(uc1, 2, out=cat1[..., h0:])
         cat_amax(cat1, br1, uc1)
-        up1, rd1 = _block_fwd(cx, m.decoder1, cat1)
-        outs = [ops.head(up1, m.out_conv.weight, m.out_conv.bias, 1)]
+        # decoder1's output feeds only the output head: where the kernels for it are built the head recomputes it on load
+        # (ops.evonorm_head) and the backward folds the head in (ops.evonorm_se_bwd(head=...)) -- up1 is never stored
+        nk = m.out_conv.weight.shape[0]
+        fuse_top = m.fold_head_fwd and nk <= 4 and (not will_bwd or (m.fold_head_bwd and nk == 3))
+        if fuse_top:
+            logits, rd1 = _block_fwd(cx, m.decoder1, cat1, head=m.out_conv)
+            up1 = None
+            outs = [logits]
+        else:
+            up1, rd1 = _block_fwd(cx, m.decoder1, cat1)
+            outs = [ops.head(up1, m.out_conv.weight, m.out_conv.bias, 1)]
+        ctx.top_fused = fuse_top
         heads = [(m.out_conv, up1, 1)]
         if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
             for hd, src, sc in ((m.deep3[0], up3, 4), (m.deep2[0], up2, 2)):
@@ -336,7 +354,7 @@ class _AsspFn(torch.autograd.Function):
         for (hd, src, sc), dout in zip(ctx.heads, douts):
             if dout is None:
                 continue
-            if src is up1 and sc == 1 and m.fold_head_bwd and hd.weight.shape[0] == 3:
+            if hd is m.out_conv and (ctx.top_fused or (m.fold_head_bwd and hd.weight.shape[0] == 3)):
                 top = (hd, dout)
                 continue
             dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
@@ -393,6 +411,8 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
         # the output head's backward inside the backward of the decoder1 block (brats_evonorm_se_bwd with dlogits); 0: the
         # separate brats_head_bwd pass, for same-box A/B runs
         self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
+        # ... and its forward on the last block's raw convolution output (brats_evonorm_head_fwd): up1 is never stored
+        self.fold_head_fwd = os.environ.get("BRATS_FOLD_HEAD_FWD", os.environ.get("BRATS_FOLD_HEAD", "1")) != "0"
         self.skip_deep_heads_in_eval = False
         self._grad_sink = None
         self._grad_dest = None

@@ -887,16 +887,20 @@ def se_gate_bwd(dgate, chansum, voxels, hidden, gate1p, w1, w2):
     return gadd, dw1, db1, dw2, db2
 
 
-def evonorm_se(y, mean_rstd, gamma, beta, w1, b1, w2, b2, groups=8, out=None, amax=None):
+def evonorm_se(y, mean_rstd, gamma, beta, w1, b1, w2, b2, groups=8, out=None, amax=None, apply=True):
     """EvoNorm + ResidualSELayer in one call, the EvoNorm output never stored (csrc/se.hpp):
-    -> (out = z * (1 + gate), chansum [N, C] = sum_v z, gate1p [N, C], hidden [N, C/r])."""
+    -> (out = z * (1 + gate), chansum [N, C] = sum_v z, gate1p [N, C], hidden [N, C/r]).
+    apply=False: statistics pass + gate only (out = None): the consumer recomputes the output on load (evonorm_head)."""
     ptr, c, p = _desc(y)
     n, d, h, w, _ = y.shape
     ch = w1.shape[0]
     dev = y.device
-    if out is None:
-        out = new_act(n, d, h, w, c, y.dtype, dev)
-    optr, _, op = _desc(out)
+    if not apply:
+        out, optr, op = None, None, 0
+    else:
+        if out is None:
+            out = new_act(n, d, h, w, c, y.dtype, dev)
+        optr, _, op = _desc(out)
     ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 1), dtype=torch.float32, device=dev)
     cs = torch.empty((n, c), dtype=torch.float32, device=dev)
     gate1p = torch.empty((n, c), dtype=torch.float32, device=dev)
@@ -906,6 +910,22 @@ def evonorm_se(y, mean_rstd, gamma, beta, w1, b1, w2, b2, groups=8, out=None, am
                                                ws.data_ptr(), cs.data_ptr(), gate1p.data_ptr(), hidden.data_ptr(), ch,
                                                _code(y.dtype), n, d * h * w, c, groups, _f32(amax), _stream()), "evonorm_se_fwd")
     return out, cs, gate1p, hidden
+
+
+def evonorm_head(y, mean_rstd, gamma, beta, gate1p, weight, bias, groups=8):
+    """NCDHW f32 logits of the output head on the gated EvoNorm output of y without storing it
+    (include/brats_hip.h: brats_evonorm_head_fwd); bit-identical to head(evonorm_se(...)[0], weight, bias)."""
+    ptr, c, p = _desc(y)
+    n, d, h, w, _ = y.shape
+    k = weight.shape[0]
+    # the per-(n, channel) constants in the kernel's own order of operations: (rstd * gamma) * gate1p, beta * gate1p
+    rstd = mean_rstd[:, :, 1].repeat_interleave(c // groups, dim=1)
+    ss = torch.stack(((rstd * gamma.float()) * gate1p, beta.float() * gate1p), -1).contiguous()
+    wf = weight.detach().reshape(k, c).contiguous().float()
+    out = torch.empty((n, k, d, h, w), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().brats_evonorm_head_fwd(ptr, p, ss.data_ptr(), wf.data_ptr(), _f32(bias.detach()) if bias is not None else None,
+                                                 out.data_ptr(), _code(y.dtype), n, c, k, d * h * w, _stream()), "evonorm_head_fwd")
+    return out
 
 
 def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None, head=None):

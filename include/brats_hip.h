@@ -269,7 +269,7 @@ int brats_evonorm_se_bwd(const void* dout, int dopitch, const void* x, int xpitc
  * x*sigmoid(x) per (n, channel); sum_v z -- what the gate's global average pool reads -- is linear in those sums; pass 2
  * writes out = z * (1 + gate) directly (3 tensor passes instead of the 4 of brats_evonorm_fwd(chansum) + brats_se_fwd +
  * brats_channel_scale).  ws: brats_chan_ws_floats(N, C, 1) floats; chansum_out [N][C] = sum_v z, gate1p [N][C], hidden
- * [N][Ch]: kept for brats_evonorm_se_bwd. */
+ * [N][Ch]: kept for brats_evonorm_se_bwd.  out = NULL: pass 2 is skipped (the consumer recomputes it: brats_evonorm_head_fwd). */
 int brats_evonorm_se_fwd(const void* x, int xpitch, const float* mean_rstd, const float* gamma, const float* beta,
                          const float* w1, const float* b1, const float* w2, const float* b2, void* out, int opitch,
                          float* ws, float* chansum_out, float* gate1p, float* hidden, int Ch, int dtype, int N, int voxels,
@@ -334,6 +334,11 @@ int brats_head_fwd(const void* x, int xpitch, const float* w /*[K][C]*/, const f
  * brats_gn_act_bwd_head the activation is not needed by the backward pass either. */
 int brats_gn_head_fwd(const void* y, int ypitch, const float* scale_shift, int act, float slope, const float* w /*[K][C]*/,
                       const float* b, float* out, int dtype, int N, int C, int K, int voxels, brats_stream_t s);
+/* ... and on EquiUnetASSPEvo's last block (EvoNorm + ResidualSELayer -> out_conv, equiunet2021.py:192-209): logits =
+ * conv1x1(y * sigmoid(y) * scale + shift) + b, scale_shift [N][C][2] = { rstd_g * gamma_c * gate1p, beta_c * gate1p } with
+ * gate1p from brats_evonorm_se_fwd called with out = NULL (statistics pass + gate only): the block's output is never stored. */
+int brats_evonorm_head_fwd(const void* y, int ypitch, const float* scale_shift, const float* w /*[K][C]*/, const float* b,
+                           float* out, int dtype, int N, int C, int K, int voxels, brats_stream_t s);
 /* dout [N][K][Ds][Hs][Ws] f32 -> dx (NDHWC dtype, may be NULL), dw [K][C], db [K] (overwritten).
  * ws: f32 workspace of brats_head_bwd_ws_bytes() (up-sampling adjoint temporaries + per-block partial sums of dw / db,
  * added in a fixed order: no float atomics). */

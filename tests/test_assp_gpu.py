@@ -281,6 +281,31 @@ def test_evonorm_se_bwd_matches_three_call_composition(n, c, size):
         assert all(torch.equal(a, b) for a, b in zip(again, got) if a is not None)  # bitwise reproducible
 
 
+@pytest.mark.parametrize("n,c,size,k", [(2, 48, (6, 8, 16), 3), (1, 16, (5, 7, 9), 3), (2, 64, (4, 4, 8), 4), (1, 96, (4, 4, 4), 2)])
+def test_output_head_on_the_last_block_without_storing_its_output(n, c, size, k):
+    """brats_evonorm_head_fwd (the gated EvoNorm output recomputed on load, rounded to the storage type) == head(evonorm_se(y))
+    bit for bit, with gate / chansum / hidden from the statistics-only call (apply=False) equal to the full call's."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(41 + c)
+    ch = c // 2
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        y = torch.randn((n, *size, c), generator=g).to(dev).to(dt)
+        mr = torch.stack([torch.randn((n, 8), generator=g) * 0.1, torch.rand((n, 8), generator=g) + 0.5], -1).to(dev).contiguous()
+        gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(c, generator=g) * 0.3).to(dev)
+        w1, b1 = (torch.randn((ch, c), generator=g) * 0.3).to(dev), (torch.randn((ch,), generator=g) * 0.2).to(dev)
+        w2, b2 = (torch.randn((c, ch), generator=g) * 0.3).to(dev), (torch.randn((c,), generator=g) * 0.2).to(dev)
+        hw = (torch.randn((k, c, 1, 1, 1), generator=g) * 0.2).to(dev)
+        hb = (torch.randn((k,), generator=g) * 0.1).to(dev)
+        out, cs, gate1p, hidden = ops.evonorm_se(y, mr, gamma, beta, w1, b1, w2, b2, 8)
+        ref = ops.head(out, hw, hb, 1)
+        none, cs2, gate2, hidden2 = ops.evonorm_se(y, mr, gamma, beta, w1, b1, w2, b2, 8, apply=False)
+        assert none is None and torch.equal(cs2, cs) and torch.equal(gate2, gate1p) and torch.equal(hidden2, hidden)
+        got = ops.evonorm_head(y, mr, gamma, beta, gate2, hw, hb, 8)
+        assert torch.equal(got, ref), str(dt)
+
+
 @pytest.mark.parametrize("n,c,size", [(2, 48, (6, 8, 16)), (1, 16, (5, 7, 9))])
 def test_evonorm_se_bwd_with_folded_output_head(n, c, size):
     """brats_evonorm_se_bwd(dlogits) -- the decoder1 block's backward computing its output gradient W_head^T dlogits on the
