@@ -489,7 +489,43 @@ struct HeadFold {
   const float* dl = nullptr;  // [N][HK][voxels]
   const float* w = nullptr;   // [HK][C]
   float* hpart = nullptr;     // pass 1: per-block partials [n * gridDim.x + block][HK * C + HK]
+  // HK == -1 (brats_gn_act_bwd_pool): the layer ends an encoder level -- its output gradient is the skip connection's plus the
+  // max pool's, dz[v][c] = dskip[v][c] + (argmax[pv][c] == k(v) ? dpool[pv][c] : 0) with pv the voxel's 2x2x2 window and k(v)
+  // its index inside it: computed here from the pieces instead of being written by the pooling backward (403 MB at the
+  // 128^3 level) and read back by both passes.  Same arithmetic as maxpool2_bwd_idx_kernel ((0 + sel) + skip).
+  const void* dskip = nullptr;
+  const void* dpool = nullptr;
+  const uint8_t* argmax = nullptr;  // [N][D/2][H/2][W/2][C]
+  int dskip_pitch = 0, dpool_pitch = 0, D = 0, H = 0, W = 0;
 };
+// the pool-source gradient of one voxel: its channel vector from the three pieces (loads, then the arithmetic)
+template <typename T, int VW>
+DEVI void pool_dz(const HeadFold& hf, int n, size_t vox, int c0, int C, typename Raw16<T>::type& skr, typename Raw16<T>::type& dpr,
+                  uint32_t (&aw)[VW / 4], int& kk) {
+  const int x = (int)(vox % hf.W);
+  const size_t t = vox / hf.W;
+  const int yy = (int)(t % hf.H), z = (int)(t / hf.H);
+  const size_t pvox = (((size_t)n * (hf.D / 2) + (z >> 1)) * (hf.H / 2) + (yy >> 1)) * (hf.W / 2) + (x >> 1);
+  kk = ((z & 1) << 2) | ((yy & 1) << 1) | (x & 1);
+  skr = Raw16<T>::template load<false>((const T*)hf.dskip + ((size_t)n * hf.D * hf.H * hf.W + vox) * hf.dskip_pitch + c0);
+  dpr = Raw16<T>::template load<false>((const T*)hf.dpool + pvox * hf.dpool_pitch + c0);
+#pragma unroll
+  for (int q = 0; q < VW / 4; ++q) aw[q] = ((const uint32_t*)(hf.argmax + pvox * C + c0))[q];
+}
+template <typename T, int VW>
+DEVI void pool_dz_finish(const typename Raw16<T>::type& skr, const typename Raw16<T>::type& dpr, const uint32_t (&aw)[VW / 4], int kk,
+                         float* g) {
+  float sk[VW], dp[VW];
+  Raw16<T>::unpack(skr, sk);
+  Raw16<T>::unpack(dpr, dp);
+#pragma unroll
+  for (int j = 0; j < VW; ++j) {
+    const int am = (aw[j >> 2] >> (8 * (j & 3))) & 0xff;
+    float o = 0.f + (am == kk ? dp[j] : 0.f);
+    o += sk[j];
+    g[j] = o;
+  }
+}
 template <typename T, bool HEAVY, bool NT = false, int HK = 0>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ y,
                                                             int ypitch, const float* __restrict__ scale_shift,
@@ -530,7 +566,35 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
     const T* yb = y + (size_t)n * voxels * ypitch + c0;
     const size_t stride = (size_t)gridDim.x * vl_n;
     size_t vox = (size_t)blockIdx.x * vl_n + myvl;
-    if constexpr (HK > 0) {
+    if constexpr (HK < 0) {
+      const float nslope = act == BRATS_ACT_RELU ? 0.f : slope;
+      auto step = [&](size_t v0, auto cnt) {  // two voxels (2 x 3 loads of 16 bytes + the arg-max bytes) in flight per thread
+        constexpr int NVX = decltype(cnt)::value;
+        typename Raw16<T>::type yr[NVX], skr[NVX], dpr[NVX];
+        uint32_t aw[NVX][VW / 4];
+        int kk[NVX];
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+          yr[i] = Raw16<T>::template load<NT>(yb + (v0 + i * stride) * ypitch);
+          pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], aw[i], kk[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+          float yy[VW], g[VW];
+          Raw16<T>::unpack(yr[i], yy);
+          pool_dz_finish<T, VW>(skr[i], dpr[i], aw[i], kk[i], g);
+#pragma unroll
+          for (int j = 0; j < VW; ++j) {
+            const float pre = yy[j] * sc[j] + sh[j];
+            const float u = g[j] * (pre > 0.f ? 1.f : nslope);
+            a1[j] += u;
+            a2[j] += u * (yy[j] * rs[j] + mo[j]);
+          }
+        }
+      };
+      for (; vox + stride < (size_t)voxels; vox += 2 * stride) step(vox, std::integral_constant<int, 2>{});
+      for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+    } else if constexpr (HK > 0) {
       float wr[HKA][VW];
 #pragma unroll
       for (int k = 0; k < HK; ++k)
@@ -740,7 +804,38 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
       for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
     }
   };
-  if constexpr (HK > 0) {
+  if constexpr (HK < 0) {
+    const float nslope = act == BRATS_ACT_RELU ? 0.f : slope;
+    auto step = [&](size_t v0, auto cnt) {
+      constexpr int NVX = decltype(cnt)::value;
+      typename Raw16<T>::type yr[NVX], skr[NVX], dpr[NVX];
+      uint32_t aw[NVX][VW / 4];
+      int kk[NVX];
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) {
+        yr[i] = Raw16<T>::template load<NT>(yb + (v0 + i * stride) * ypitch);
+        pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], aw[i], kk[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) {
+        float yy[VW], g[VW], o[VW];
+        Raw16<T>::unpack(yr[i], yy);
+        pool_dz_finish<T, VW>(skr[i], dpr[i], aw[i], kk[i], g);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          const float u = g[j] * (yy[j] * sc[j] + sh[j] > 0.f ? 1.f : nslope);
+          o[j] = u * ca[j] + (yy[j] * cb[j] + ck[j]);
+        }
+        if (amax) {
+#pragma unroll
+          for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
+        }
+        vstore<T, VW, NT>(dyb + (v0 + i * stride) * dypitch, o);
+      }
+    };
+    for (; vox + stride < (size_t)voxels; vox += 2 * stride) step(vox, std::integral_constant<int, 2>{});
+    for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+  } else if constexpr (HK > 0) {
     float wr[HKA][VW];
 #pragma unroll
     for (int k = 0; k < HK; ++k)
@@ -830,12 +925,16 @@ static int gn_act_bwd_impl(const void* dz, int dzpitch, const void* y, int ypitc
   const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
   const int cap1 = big ? GN_BWD_MAX_BLOCKS : 512;
   dim3 g1(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx), N);
-  const size_t lds1 = (size_t)(vl * C * 2 + (K ? vl * K : 0)) * sizeof(float);
+  const size_t lds1 = (size_t)(vl * C * 2 + (K > 0 ? vl * K : 0)) * sizeof(float);
   dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
 #define GN_BWD_GO(T, HEAVY, NT, HK) gn_bwd_launch<T, HEAVY, NT, HK>(g1, g2, lds1, lds2, st, dz, dzpitch, y, ypitch, scale_shift, mean_rstd, \
                                                                   gamma, dy, dypitch, red, dgamma, dbeta, act, slope, N, voxels, C, groups, amax, hf)
-  if (K) {  // (relu / leakyrelu, three logit planes: checked by the caller)
+  if (K < 0) {  // the pool-source form (relu / leakyrelu: checked by the caller)
+    if (big) GN_BWD_GO(bf16_t, false, true, -1);
+    else if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, -1);
+    else GN_BWD_GO(float, false, false, -1);
+  } else if (K) {  // (relu / leakyrelu, three logit planes: checked by the caller)
     if (big) GN_BWD_GO(bf16_t, false, true, 3);
     else if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, 3);
     else GN_BWD_GO(float, false, false, 3);
@@ -882,6 +981,28 @@ extern "C" int BRATS_API(brats_gn_act_bwd_head)(const float* dlogits, const floa
                                  SlopeArg{slope_value, nullptr}, N, voxels, C, groups, amax, hf, K, (hipStream_t)s);
   if (nb < 0) return nb;
   return brats_ordered_sum2(hws, dhw, K * C, dhb, N * nb, K * C + K, (hipStream_t)s);  // totals straight into dhw [K][C], dhb [K]
+}
+
+// GroupNorm + activation backward of a layer that ends an encoder level (ConvBnRelu -> MaxPool3d(2, 2), its output also the
+// skip connection): the output gradient dz = dskip + maxpool-backward(dpool) is composed inside both passes from the skip
+// gradient, the pooled gradient and the arg-max bytes the pooling forward recorded (HeadFold, HK == -1).  Replaces
+// brats_maxpool2_bwd_idx + brats_gn_act_bwd for that layer; relu / leakyrelu, no MaxAvgPool.
+extern "C" int BRATS_API(brats_gn_act_bwd_pool)(const void* dskip, int dskip_pitch, const void* dpool, int dpool_pitch,
+                                     const unsigned char* argmax, const void* y, int ypitch, const float* scale_shift,
+                                     const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red, float* dgamma,
+                                     float* dbeta, int dtype, int act, float slope_value, int N, int D, int H, int W, int C,
+                                     int groups, float* amax, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dskip || !dpool || !argmax || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_pool: null pointer");
+  if (act > BRATS_ACT_LEAKY || ((D | H | W) & 1) || dskip_pitch % vw || dpool_pitch % vw)
+    BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_pool: relu / leakyrelu, even spatial dims, pitches multiples of %d (act=%d)", vw, act);
+  HeadFold hf;
+  hf.dskip = dskip; hf.dpool = dpool; hf.argmax = argmax; hf.dskip_pitch = dskip_pitch; hf.dpool_pitch = dpool_pitch;
+  hf.D = D; hf.H = H; hf.W = W;
+  const int rc = gn_act_bwd_impl(nullptr, vw, y, ypitch, scale_shift, mean_rstd, gamma, dy, dypitch, red, dgamma, dbeta, dtype, act,
+                                 SlopeArg{slope_value, nullptr}, N, D * H * W, C, groups, amax, hf, -1, (hipStream_t)s);
+  return rc < 0 ? rc : 0;
 }
 
 // =================================================================================================

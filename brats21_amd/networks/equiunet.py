@@ -158,7 +158,8 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
-def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None, head=None):
+def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None, head=None,
+             pool=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
     fp8 == "all": the input gradient (dgrad) and -- for the dilation-1 layers the all-taps kernel covers -- the weight
     gradient run on the e4m3 kernels too, scaled by the |max| of dy that the GroupNorm backward records (and the |max| of
@@ -187,6 +188,11 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
             grads[names[prm]] = g
             if sink is not None:
                 sink(names[prm], g)
+    elif pool is not None:
+        # the layer ends an encoder level: dz = skip gradient + max-pool backward, composed inside the GroupNorm backward from
+        # (d_skip, d_pooled, arg-max bytes) -- the pooling backward's output tensor is never written (ops.gn_act_bwd_pool)
+        dy, dgamma, dbeta = ops.gn_act_bwd_pool(pool[0], pool[1], pool[2], y, scale_shift, mean_rstd, unit.bn.weight.detach(),
+                                                unit.groups, kact, amax=amax)
     else:
         dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
                                            slope_t=slope_t)
@@ -326,8 +332,16 @@ class _EquiUnetFn(torch.autograd.Function):
         # buckets' copies and collectives are ordered against it
         side = ops.get_side_stream(douts[0].device) if (m.wgrad_stream and m._grad_sink is None) else None
 
-        def cbw(unit, dz, need_dx=True, head=None):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head)
+        def cbw(unit, dz, need_dx=True, head=None, pool=None):
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head, pool)
+
+        def level_bwd(unit, down, d_pooled, d_skip, need_dx=True):
+            """Backward of the last layer of an encoder level: its output gradient = d_skip + max-pool backward(d_pooled)."""
+            idx = getattr(down, "_pool_argmax", None)
+            kact, slope_t = _unit_act(unit, act)
+            if idx is not None and m.fold_pool_bwd and slope_t is None and kact in ("relu", "leakyrelu"):
+                return cbw(unit, None, need_dx, pool=(d_skip, d_pooled, idx))
+            return cbw(unit, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip), need_dx)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
@@ -365,12 +379,9 @@ class _EquiUnetFn(torch.autograd.Function):
         d_bottom = plus(d_bot, extra(bottom))
         d_down4 = d_skip4 + cbw(m.bottom.ConvBnRelu1, cbw(m.bottom.ConvBnRelu2, d_bottom))
         d_p3 = cbw(m.encoder4.ConvBnRelu1, cbw(m.encoder4.ConvBnRelu2, d_down4))
-        d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=d_skip3)
-        d_p2 = cbw(m.encoder3.ConvBnRelu1, cbw(m.encoder3.ConvBnRelu2, d_down3))
-        d_down2 = ops.maxpool2_bwd(down2, d_p2, dx_skip=d_skip2)
-        d_p1 = cbw(m.encoder2.ConvBnRelu1, cbw(m.encoder2.ConvBnRelu2, d_down2))
-        d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=d_skip1)
-        cbw(m.encoder1.ConvBnRelu1, cbw(m.encoder1.ConvBnRelu2, d_down1), need_dx=False)
+        d_p2 = cbw(m.encoder3.ConvBnRelu1, level_bwd(m.encoder3.ConvBnRelu2, down3, d_p3, d_skip3))
+        d_p1 = cbw(m.encoder2.ConvBnRelu1, level_bwd(m.encoder2.ConvBnRelu2, down2, d_p2, d_skip2))
+        cbw(m.encoder1.ConvBnRelu1, level_bwd(m.encoder1.ConvBnRelu2, down1, d_p1, d_skip1), need_dx=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)  # every weight gradient is complete before autograd hands them on
         ctx.tape = ctx.bufs = None
@@ -417,6 +428,8 @@ class EquiUnet(_PackedWeightsModule):
         # the output head's backward inside the GroupNorm backward of the last layer (brats_gn_act_bwd_head); 0: the two-call
         # path (brats_head_bwd + brats_gn_act_bwd) for same-box A/B runs
         self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
+        # the pooling backward + skip add inside the GroupNorm backward of the level's last layer (brats_gn_act_bwd_pool)
+        self.fold_pool_bwd = os.environ.get("BRATS_FOLD_POOL", "1") != "0"
         # ... and its forward on the last layer's raw convolution output (brats_gn_head_fwd): up1 is never stored
         self.fold_head_fwd = os.environ.get("BRATS_FOLD_HEAD_FWD", os.environ.get("BRATS_FOLD_HEAD", "1")) != "0"
         f = self.features

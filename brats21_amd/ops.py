@@ -669,6 +669,25 @@ def gn_act_bwd_head(dlogits, head_weight, y, scale_shift, mean_rstd, gamma, grou
     return dy, dgamma, dbeta, dhw.reshape(k, c, 1, 1, 1), dhb
 
 
+def gn_act_bwd_pool(dskip, dpool, argmax, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None):
+    """GroupNorm + activation backward of the layer that ends an encoder level, its output gradient dskip +
+    maxpool-backward(dpool) composed inside the two passes (include/brats_hip.h: brats_gn_act_bwd_pool): -> (dy, dgamma, dbeta)."""
+    yp, c, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    sp, _, spitch = _desc(dskip)
+    pp, _, ppitch = _desc(dpool)
+    dev = y.device
+    dy = new_act(n, d, h, w, c, y.dtype, dev)
+    red = torch.empty(_lib.lib().brats_gn_bwd_ws_floats(n, c), dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().brats_gn_act_bwd_pool(sp, spitch, pp, ppitch, argmax.data_ptr(), yp, ypitch, scale_shift.data_ptr(),
+                                                mean_rstd.data_ptr(), _f32(gamma), dy.data_ptr(), c, red.data_ptr(),
+                                                dgamma.data_ptr(), dbeta.data_ptr(), _code(y.dtype), ACTS[act], slope, n, d, h, w, c,
+                                                groups, _f32(amax), _stream()), "gn_act_bwd_pool")
+    return dy, dgamma, dbeta
+
+
 def head_fold_ok(head_weight, act, slope_t):
     """brats_gn_act_bwd_head is built for three logit planes and relu / leakyrelu without a learnable slope."""
     return head_weight.shape[0] == 3 and act in ("relu", "leakyrelu") and slope_t is None

@@ -206,6 +206,14 @@ int brats_gn_act_bwd_head(const float* dlogits, const float* hw, int K, const vo
                           const float* mean_rstd, const float* gamma, void* dy, int dypitch, float* red /* as above */,
                           float* hws, float* dgamma, float* dbeta, float* dhw, float* dhb, int dtype, int act, float slope,
                           int N, int voxels, int C, int groups, float* amax, brats_stream_t s);
+/* ... and for the layer that ends an encoder level (ConvBnRelu -> MaxPool3d(2, 2), its output also the skip connection,
+ * equiunet2020.py:469-475): dz = dskip + maxpool-backward(dpool) is composed inside both passes from the skip gradient, the
+ * pooled gradient and the arg-max bytes of brats_maxpool2_fwd / brats_affine_act_pool_fwd instead of being written by the
+ * pooling backward and read back twice.  Replaces brats_maxpool2_bwd_idx + brats_gn_act_bwd; relu / leakyrelu. */
+int brats_gn_act_bwd_pool(const void* dskip, int dskip_pitch, const void* dpool, int dpool_pitch, const unsigned char* argmax,
+                          const void* y, int ypitch, const float* scale_shift, const float* mean_rstd, const float* gamma,
+                          void* dy, int dypitch, float* red, float* dgamma, float* dbeta, int dtype, int act, float slope,
+                          int N, int D, int H, int W, int C, int groups, float* amax, brats_stream_t s);
 /* gradient of nn.PReLU's scalar slope: dslope[0] = sum dz * min(y*scale + shift, 0) over the whole tensor; ws = f32
  * workspace of brats_prelu_ws_floats(N) elements (block partials, added in block order) */
 size_t brats_prelu_ws_floats(int N);

@@ -153,6 +153,38 @@ def test_groupnorm_act_fwd_bwd(dtype, c, act):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c,act,size", [(48, "relu", (8, 8, 8)), (16, "leakyrelu", (4, 6, 10)), (96, "relu", (4, 4, 4))])
+def test_groupnorm_bwd_with_folded_pool_backward(dtype, c, act, size):
+    """brats_gn_act_bwd_pool (dz = skip gradient + max-pool backward composed inside the two GroupNorm-backward passes from
+    the pieces) against maxpool2_bwd (arg-max bytes) + gn_act_bwd: f32 bit for bit (the composed dz is the same f32 value the
+    pooling backward would store), 16-bit within the rounding of the dz tensor that is no longer stored."""
+    from brats21_amd import ops
+    dev = _dev()
+    n, cin, vox = 2, 8, size[0] * size[1] * size[2]
+    x = _q(_rand((n, cin, *size), 91), dtype)
+    w = _q(_rand((c, cin, 3, 3, 3), 92, 0.1), dtype)
+    gamma = 1.0 + 0.2 * _rand((c,), 93)
+    beta = 0.1 * _rand((c,), 94)
+    y, stats = ops.conv3d(_to_ndhwc(x, dtype, dev), ops.pack_weights(w.to(dev), dtype, ops.PACK_FWD), c, 3, 1, want_stats=True)
+    mr, ss = ops.gn_finalize(stats, n, c, 8, vox, gamma.to(dev), beta.to(dev))
+    z = ops.affine_act(y, ss, act)
+    ops.maxpool2(z, want_argmax=True)
+    dskip = _to_ndhwc(_q(_rand((n, c, *size), 95), dtype), dtype, dev)
+    dpool = _to_ndhwc(_q(_rand((n, c, size[0] // 2, size[1] // 2, size[2] // 2), 96), dtype), dtype, dev)
+    dz = ops.maxpool2_bwd(z, dpool, dx_skip=dskip)
+    ref = ops.gn_act_bwd(dz, y, ss, mr, gamma.to(dev), 8, act)
+    got = ops.gn_act_bwd_pool(dskip, dpool, z._pool_argmax, y, ss, mr, gamma.to(dev), 8, act)
+    for name, a, b in zip(("dy", "dgamma", "dbeta"), got, ref):
+        if dtype == torch.float32:
+            assert torch.equal(a, b), name
+        else:
+            scale = float(b.float().abs().max()) + 1e-30
+            assert float((a.float() - b.float()).abs().max()) <= 2e-2 * scale, name
+    again = ops.gn_act_bwd_pool(dskip, dpool, z._pool_argmax, y, ss, mr, gamma.to(dev), 8, act)
+    assert all(torch.equal(a, b) for a, b in zip(again, got))
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("c,act,size,k", [(48, "relu", (8, 8, 8), 3), (16, "leakyrelu", (4, 6, 10), 3), (8, "relu", (3, 5, 7), 4),
                                           (64, "relu", (4, 4, 8), 3), (96, "relu", (4, 4, 4), 2)])
 def test_output_head_on_raw_convolution_output_is_bit_identical(dtype, c, act, size, k):
