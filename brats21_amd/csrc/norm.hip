@@ -497,11 +497,12 @@ struct HeadFold {
   const void* dpool = nullptr;
   const uint8_t* argmax = nullptr;  // [N][D/2][H/2][W/2][C]
   int dskip_pitch = 0, dpool_pitch = 0, D = 0, H = 0, W = 0;
+  int with_avg = 0;  // MaxAvgPool: dpool holds [max | mean] gradients (2C channels), the mean's share is dpool[C + c] / 8
 };
 // the pool-source gradient of one voxel: its channel vector from the three pieces (loads, then the arithmetic)
 template <typename T, int VW>
 DEVI void pool_dz(const HeadFold& hf, int n, size_t vox, int c0, int C, typename Raw16<T>::type& skr, typename Raw16<T>::type& dpr,
-                  uint32_t (&aw)[VW / 4], int& kk) {
+                  typename Raw16<T>::type& avr, uint32_t (&aw)[VW / 4], int& kk) {
   const int x = (int)(vox % hf.W);
   const size_t t = vox / hf.W;
   const int yy = (int)(t % hf.H), z = (int)(t / hf.H);
@@ -509,19 +510,22 @@ DEVI void pool_dz(const HeadFold& hf, int n, size_t vox, int c0, int C, typename
   kk = ((z & 1) << 2) | ((yy & 1) << 1) | (x & 1);
   skr = Raw16<T>::template load<false>((const T*)hf.dskip + ((size_t)n * hf.D * hf.H * hf.W + vox) * hf.dskip_pitch + c0);
   dpr = Raw16<T>::template load<false>((const T*)hf.dpool + pvox * hf.dpool_pitch + c0);
+  if (hf.with_avg) avr = Raw16<T>::template load<false>((const T*)hf.dpool + pvox * hf.dpool_pitch + C + c0);
+  else avr = dpr;  // (unused)
 #pragma unroll
   for (int q = 0; q < VW / 4; ++q) aw[q] = ((const uint32_t*)(hf.argmax + pvox * C + c0))[q];
 }
 template <typename T, int VW>
-DEVI void pool_dz_finish(const typename Raw16<T>::type& skr, const typename Raw16<T>::type& dpr, const uint32_t (&aw)[VW / 4], int kk,
-                         float* g) {
-  float sk[VW], dp[VW];
+DEVI void pool_dz_finish(const typename Raw16<T>::type& skr, const typename Raw16<T>::type& dpr, const typename Raw16<T>::type& avr,
+                         int with_avg, const uint32_t (&aw)[VW / 4], int kk, float* g) {
+  float sk[VW], dp[VW], ga[VW];
   Raw16<T>::unpack(skr, sk);
   Raw16<T>::unpack(dpr, dp);
+  Raw16<T>::unpack(avr, ga);
 #pragma unroll
   for (int j = 0; j < VW; ++j) {
     const int am = (aw[j >> 2] >> (8 * (j & 3))) & 0xff;
-    float o = 0.f + (am == kk ? dp[j] : 0.f);
+    float o = (with_avg ? ga[j] * 0.125f : 0.f) + (am == kk ? dp[j] : 0.f);
     o += sk[j];
     g[j] = o;
   }
@@ -570,19 +574,19 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const T* __restrict_
       const float nslope = act == BRATS_ACT_RELU ? 0.f : slope;
       auto step = [&](size_t v0, auto cnt) {  // two voxels (2 x 3 loads of 16 bytes + the arg-max bytes) in flight per thread
         constexpr int NVX = decltype(cnt)::value;
-        typename Raw16<T>::type yr[NVX], skr[NVX], dpr[NVX];
+        typename Raw16<T>::type yr[NVX], skr[NVX], dpr[NVX], avr[NVX];
         uint32_t aw[NVX][VW / 4];
         int kk[NVX];
 #pragma unroll
         for (int i = 0; i < NVX; ++i) {
           yr[i] = Raw16<T>::template load<NT>(yb + (v0 + i * stride) * ypitch);
-          pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], aw[i], kk[i]);
+          pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], avr[i], aw[i], kk[i]);
         }
 #pragma unroll
         for (int i = 0; i < NVX; ++i) {
           float yy[VW], g[VW];
           Raw16<T>::unpack(yr[i], yy);
-          pool_dz_finish<T, VW>(skr[i], dpr[i], aw[i], kk[i], g);
+          pool_dz_finish<T, VW>(skr[i], dpr[i], avr[i], hf.with_avg, aw[i], kk[i], g);
 #pragma unroll
           for (int j = 0; j < VW; ++j) {
             const float pre = yy[j] * sc[j] + sh[j];
@@ -808,19 +812,19 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
     const float nslope = act == BRATS_ACT_RELU ? 0.f : slope;
     auto step = [&](size_t v0, auto cnt) {
       constexpr int NVX = decltype(cnt)::value;
-      typename Raw16<T>::type yr[NVX], skr[NVX], dpr[NVX];
+      typename Raw16<T>::type yr[NVX], skr[NVX], dpr[NVX], avr[NVX];
       uint32_t aw[NVX][VW / 4];
       int kk[NVX];
 #pragma unroll
       for (int i = 0; i < NVX; ++i) {
         yr[i] = Raw16<T>::template load<NT>(yb + (v0 + i * stride) * ypitch);
-        pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], aw[i], kk[i]);
+        pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], avr[i], aw[i], kk[i]);
       }
 #pragma unroll
       for (int i = 0; i < NVX; ++i) {
         float yy[VW], g[VW], o[VW];
         Raw16<T>::unpack(yr[i], yy);
-        pool_dz_finish<T, VW>(skr[i], dpr[i], aw[i], kk[i], g);
+        pool_dz_finish<T, VW>(skr[i], dpr[i], avr[i], hf.with_avg, aw[i], kk[i], g);
 #pragma unroll
         for (int j = 0; j < VW; ++j) {
           const float u = g[j] * (yy[j] * sc[j] + sh[j] > 0.f ? 1.f : nslope);
@@ -1287,7 +1291,7 @@ __global__ void __launch_bounds__(256) evonorm_bwd_reduce_kernel(const T* __rest
   constexpr int VW = 16 / sizeof(T);
   constexpr int NV = RAW5 ? 5 : 3;
   constexpr int HKA = HK > 0 ? HK : 1;
-  static_assert(HK == 0 || RAW5, "the head fold exists for the five-sum pass only");
+  static_assert(HK == 0 || RAW5, "the head / pool folds exist for the five-sum pass only");
   extern __shared__ float sm[];
   const int n = blockIdx.y;
   const int cv = C / VW, vl_n = blockDim.x / cv;
@@ -1331,7 +1335,28 @@ __global__ void __launch_bounds__(256) evonorm_bwd_reduce_kernel(const T* __rest
     };
     const size_t stride = (size_t)gridDim.x * vl_n;
     size_t vox = (size_t)blockIdx.x * vl_n + myvl;
-    if constexpr (HK > 0) {
+    if constexpr (HK < 0) {  // do = skip gradient + MaxAvgPool backward, composed from the pieces (HeadFold, pool_dz)
+      auto step = [&](size_t v0, auto cnt) {
+        constexpr int NVX = decltype(cnt)::value;
+        typename Raw16<T>::type xr[NVX], skr[NVX], dpr[NVX], avr[NVX];
+        uint32_t aw8[NVX][VW / 4];
+        int kk[NVX];
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+          xr[i] = Raw16<T>::template load<NT>(xb + (v0 + i * stride) * xpitch + c0);
+          pool_dz<T, VW>(eh.hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], avr[i], aw8[i], kk[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NVX; ++i) {
+          float xx[VW], g[VW];
+          Raw16<T>::unpack(xr[i], xx);
+          pool_dz_finish<T, VW>(skr[i], dpr[i], avr[i], eh.hf.with_avg, aw8[i], kk[i], g);
+          body(g, xx);
+        }
+      };
+      for (; vox + stride < (size_t)voxels; vox += 2 * stride) step(vox, std::integral_constant<int, 2>{});
+      for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+    } else if constexpr (HK > 0) {
       float wr[HKA][VW];
 #pragma unroll
       for (int k = 0; k < HK; ++k)
@@ -1500,7 +1525,29 @@ __global__ void __launch_bounds__(256) evonorm_bwd_apply_kernel(const T* __restr
   };
   const size_t stride = (size_t)gridDim.x * vl_n;
   size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
-  if constexpr (HK > 0) {
+  if constexpr (HK < 0) {
+    auto step = [&](size_t v0, auto cnt) {
+      constexpr int NVX = decltype(cnt)::value;
+      typename Raw16<T>::type xr[NVX], skr[NVX], dpr[NVX], avr[NVX];
+      uint32_t aw8[NVX][VW / 4];
+      int kk[NVX];
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) {
+        xr[i] = Raw16<T>::template load<NT>(xb + (v0 + i * stride) * xpitch);
+        pool_dz<T, VW>(hf, n, v0 + i * stride, c0, C, skr[i], dpr[i], avr[i], aw8[i], kk[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NVX; ++i) {
+        float xx[VW], g[VW], o[VW];
+        Raw16<T>::unpack(xr[i], xx);
+        pool_dz_finish<T, VW>(skr[i], dpr[i], avr[i], hf.with_avg, aw8[i], kk[i], g);
+        body(g, xx, o);
+        vstore<T, VW, NT>(dxb + (v0 + i * stride) * dxpitch, o);
+      }
+    };
+    for (; vox + stride < (size_t)voxels; vox += 2 * stride) step(vox, std::integral_constant<int, 2>{});
+    for (; vox < (size_t)voxels; vox += stride) step(vox, std::integral_constant<int, 1>{});
+  } else if constexpr (HK > 0) {
     float wr[HKA][VW];
 #pragma unroll
     for (int k = 0; k < HK; ++k)
@@ -1605,23 +1652,19 @@ extern "C" int BRATS_API(brats_evonorm_bwd)(const void* dz, int dzpitch, const v
 // dlogits != NULL (then dout may be NULL): the block's output feeds only the 1x1x1 output head with K = 3 logit planes -- the
 // head's backward is folded in as in brats_gn_act_bwd_head (dout = W_head^T dlogits on the fly; dhw [K][C], dhb [K] out of
 // pass 1); hws: brats_gn_bwd_head_ws_floats(N, C, K) floats.
-extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, const void* x, int xpitch, const float* mean_rstd,
-                                    const float* gamma, const float* beta, void* dx, int dxpitch, float* ws, float* dgamma,
-                                    float* dbeta, const double* chan_sums, float* dconvbias, const float* se_chansum,
-                                    const float* hidden, const float* gate1p, const float* w1, const float* w2, float* gadd,
-                                    float* dw1, float* db1, float* dw2, float* db2, int Ch, const float* dlogits, const float* hw,
-                                    int K, float* hws, float* dhw, float* dhb, int dtype, int N, int voxels, int C, int groups,
-                                    float* amax, brats_stream_t s) {
+// mode: 0 = dout given, 3 = head fold (dlogits), -1 = pool fold (eh.hf.dskip / dpool / argmax)
+static int evonorm_se_bwd_impl(const void* dout, int dopitch, const void* x, int xpitch, const float* mean_rstd, const float* gamma,
+                               const float* beta, void* dx, int dxpitch, float* ws, float* dgamma, float* dbeta,
+                               const double* chan_sums, float* dconvbias, const float* se_chansum, const float* hidden,
+                               const float* gate1p, const float* w1, const float* w2, float* gadd, float* dw1, float* db1, float* dw2,
+                               float* db2, int Ch, EvoHead eh, int mode, int K, float* dhw, float* dhb, int dtype, int N, int voxels,
+                               int C, int groups, float* amax, hipStream_t st) {
   const int vw = dtype == BRATS_BF16 ? 8 : 4;
-  const bool head = dlogits != nullptr;
-  if ((!dout && !head) || !x || !dx || !ws || !mean_rstd || !gamma || !beta || !gate1p || !gadd)
-    BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: null pointer");
-  if (head && (!hw || !hws || !dhw || !dhb)) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: incomplete head arguments");
-  if (head && K != 3) BRATS_FAIL(BRATS_E_UNSUPPORTED, "evonorm_se_bwd: the head fold is built for K = 3 logit planes (K=%d)", K);
+  const bool head = mode > 0;
+  if (!x || !dx || !ws || !mean_rstd || !gamma || !beta || !gate1p || !gadd) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: null pointer");
   if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: dconvbias needs the forward per-channel sums");
-  if (C % vw || C % groups || (!head && dopitch % vw) || xpitch % vw || dxpitch % vw || C / vw > 256)
+  if (C % vw || C % groups || (mode == 0 && dopitch % vw) || xpitch % vw || dxpitch % vw || C / vw > 256)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: C=%d / pitches must be multiples of %d", C, vw);
-  hipStream_t st = (hipStream_t)s;
   const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
   const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
@@ -1632,8 +1675,6 @@ extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, co
   const size_t lds2 = (size_t)3 * C * sizeof(float);
   float* raw5 = ws;
   float* red3 = ws + (size_t)(1 + CHAN_MAX_BLOCKS) * N * C * 5;
-  EvoHead eh;
-  eh.hf.dl = dlogits; eh.hf.w = hw; eh.hf.hpart = hws;
   eh.mean_rstd = mean_rstd; eh.gamma = gamma; eh.beta = beta; eh.gate1p = gate1p; eh.groups = groups;
   const float* nof = nullptr;
 #define EVO_P1(T, NT, HK) hipLaunchKernelGGL((evonorm_bwd_reduce_kernel<T, NT, true, HK>), g1, dim3(256), lds1, st, (const T*)dout, dopitch, \
@@ -1641,29 +1682,66 @@ extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, co
 #define EVO_P2(T, NT, HK) hipLaunchKernelGGL((evonorm_bwd_apply_kernel<T, NT, HK>), g2, dim3(256), lds2, st, (const T*)dout, dopitch, \
                                              (const T*)x, xpitch, mean_rstd, gamma, red3, (T*)dx, dxpitch, dgamma, dbeta, chan_sums, \
                                              dconvbias, N, voxels, C, groups, (uint32_t*)amax, gate1p, gadd, eh.hf)
-  if (head) {
-    if (big) EVO_P1(bf16_t, true, 3); else if (dtype == BRATS_BF16) EVO_P1(bf16_t, false, 3); else EVO_P1(float, false, 3);
-  } else {
-    if (big) EVO_P1(bf16_t, true, 0); else if (dtype == BRATS_BF16) EVO_P1(bf16_t, false, 0); else EVO_P1(float, false, 0);
-  }
+#define EVO_ALL(P, HK) do { if (big) P(bf16_t, true, HK); else if (dtype == BRATS_BF16) P(bf16_t, false, HK); else P(float, false, HK); } while (0)
+  if (mode > 0) EVO_ALL(EVO_P1, 3); else if (mode < 0) EVO_ALL(EVO_P1, -1); else EVO_ALL(EVO_P1, 0);
   BRATS_CHECK_LAUNCH();
   brats_ordered_sum(raw5 + (size_t)N * C * 5, raw5, (int)g1.x, N * C * 5, st);
-  if (head) brats_ordered_sum2(hws, dhw, K * C, dhb, N * (int)g1.x, K * C + K, st);  // totals straight into dhw [K][C], dhb [K]
+  if (head) brats_ordered_sum2(eh.hf.hpart, dhw, K * C, dhb, N * (int)g1.x, K * C + K, st);  // totals into dhw [K][C], dhb [K]
   SeFold fold;
   fold.raw5 = raw5; fold.mean_rstd = mean_rstd; fold.gamma = gamma; fold.beta = beta; fold.red3 = red3; fold.groups = groups;
   fold.voxels = (float)voxels;
   if (int rc = brats_se_bwd_launch(nullptr, fold, se_chansum, 1.f / (float)voxels, hidden, gate1p, w1, w2, gadd, dw1, db1, dw2, db2,
                                    N, C, Ch, st))
     return rc;
-  if (head) {
-    if (big) EVO_P2(bf16_t, true, 3); else if (dtype == BRATS_BF16) EVO_P2(bf16_t, false, 3); else EVO_P2(float, false, 3);
-  } else {
-    if (big) EVO_P2(bf16_t, true, 0); else if (dtype == BRATS_BF16) EVO_P2(bf16_t, false, 0); else EVO_P2(float, false, 0);
-  }
+  if (mode > 0) EVO_ALL(EVO_P2, 3); else if (mode < 0) EVO_ALL(EVO_P2, -1); else EVO_ALL(EVO_P2, 0);
+#undef EVO_ALL
 #undef EVO_P1
 #undef EVO_P2
   BRATS_CHECK_LAUNCH();
   return 0;
+}
+
+// dlogits != NULL (then dout may be NULL): the block's output feeds only the 1x1x1 output head with K = 3 logit planes -- the
+// head's backward is folded in as in brats_gn_act_bwd_head (dout = W_head^T dlogits on the fly; dhw [K][C], dhb [K] out of
+// pass 1); hws: brats_gn_bwd_head_ws_floats(N, C, K) floats.
+extern "C" int BRATS_API(brats_evonorm_se_bwd)(const void* dout, int dopitch, const void* x, int xpitch, const float* mean_rstd,
+                                    const float* gamma, const float* beta, void* dx, int dxpitch, float* ws, float* dgamma,
+                                    float* dbeta, const double* chan_sums, float* dconvbias, const float* se_chansum,
+                                    const float* hidden, const float* gate1p, const float* w1, const float* w2, float* gadd,
+                                    float* dw1, float* db1, float* dw2, float* db2, int Ch, const float* dlogits, const float* hw,
+                                    int K, float* hws, float* dhw, float* dhb, int dtype, int N, int voxels, int C, int groups,
+                                    float* amax, brats_stream_t s) {
+  const bool head = dlogits != nullptr;
+  if (!dout && !head) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: null pointer");
+  if (head && (!hw || !hws || !dhw || !dhb)) BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd: incomplete head arguments");
+  if (head && K != 3) BRATS_FAIL(BRATS_E_UNSUPPORTED, "evonorm_se_bwd: the head fold is built for K = 3 logit planes (K=%d)", K);
+  EvoHead eh;
+  eh.hf.dl = dlogits; eh.hf.w = hw; eh.hf.hpart = hws;
+  return evonorm_se_bwd_impl(dout, dopitch, x, xpitch, mean_rstd, gamma, beta, dx, dxpitch, ws, dgamma, dbeta, chan_sums, dconvbias,
+                             se_chansum, hidden, gate1p, w1, w2, gadd, dw1, db1, dw2, db2, Ch, eh, head ? 3 : 0, K, dhw, dhb, dtype, N,
+                             voxels, C, groups, amax, (hipStream_t)s);
+}
+
+// The same for a block that ends an encoder level (block -> MaxAvgPool / MaxPool3d, its output also the skip connection): the
+// block's output gradient = dskip + pooling-backward(dpool) is composed inside both passes from the pieces and the arg-max
+// bytes of brats_maxpool2_fwd (with_avg: dpool holds [max | mean], 2C channels) -- replaces brats_maxpool2_bwd_idx +
+// brats_evonorm_se_bwd(dout).
+extern "C" int BRATS_API(brats_evonorm_se_bwd_pool)(const void* dskip, int dskip_pitch, const void* dpool, int dpool_pitch,
+                                         const unsigned char* argmax, int with_avg, int D, int H, int W, const void* x, int xpitch,
+                                         const float* mean_rstd, const float* gamma, const float* beta, void* dx, int dxpitch,
+                                         float* ws, float* dgamma, float* dbeta, const double* chan_sums, float* dconvbias,
+                                         const float* se_chansum, const float* hidden, const float* gate1p, const float* w1,
+                                         const float* w2, float* gadd, float* dw1, float* db1, float* dw2, float* db2, int Ch,
+                                         int dtype, int N, int C, int groups, float* amax, brats_stream_t s) {
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (!dskip || !dpool || !argmax || ((D | H | W) & 1) || dskip_pitch % vw || dpool_pitch % vw)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_se_bwd_pool: null pointer / odd spatial size / pitch not a multiple of %d", vw);
+  EvoHead eh;
+  eh.hf.dskip = dskip; eh.hf.dpool = dpool; eh.hf.argmax = argmax; eh.hf.dskip_pitch = dskip_pitch; eh.hf.dpool_pitch = dpool_pitch;
+  eh.hf.D = D; eh.hf.H = H; eh.hf.W = W; eh.hf.with_avg = with_avg;
+  return evonorm_se_bwd_impl(nullptr, vw, x, xpitch, mean_rstd, gamma, beta, dx, dxpitch, ws, dgamma, dbeta, chan_sums, dconvbias,
+                             se_chansum, hidden, gate1p, w1, w2, gadd, dw1, db1, dw2, db2, Ch, eh, -1, 0, nullptr, nullptr, dtype, N,
+                             D * H * W, C, groups, amax, (hipStream_t)s);
 }
 
 // per-(n, channel) reduction over voxels: out[n][c] = sum_v a[v][c] * (b ? b[v][c] : 1)

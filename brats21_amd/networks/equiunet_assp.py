@@ -236,7 +236,7 @@ def _block_fwd(cx, blk, x, out=None, head=None):
     return o, (blk, r1, rec2, cs, hidden, gate1p)
 
 
-def _block_bwd(cx, rec, do, need_dx=True, head=None):
+def _block_bwd(cx, rec, do, need_dx=True, head=None, pool=None):
     """head = (head module, dlogits) instead of `do`: the block's output feeds only the 1x1x1 output head, whose backward is
     folded into the same call (d(up1) is never written)."""
     blk, r1, r2, cs, hidden, gate1p = rec
@@ -247,7 +247,7 @@ def _block_bwd(cx, rec, do, need_dx=True, head=None):
     conv, evo, saved, y, mr, chan = r2
     amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
     res = ops.evonorm_se_bwd(do, y, mr, _flat(evo.gamma), _flat(evo.beta), cs, hidden, gate1p, fc1.weight, fc2.weight, 8, chan=chan,
-                             amax=amax, head=(head[0].weight, head[1]) if head is not None else None)
+                             amax=amax, head=(head[0].weight, head[1]) if head is not None else None, pool=pool)
     dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2 = res[:8]
     if head is not None:
         cx.put(head[0].weight, res[8])
@@ -374,13 +374,18 @@ class _AsspFn(torch.autograd.Function):
         d_assp = _conv_evo_bwd(cx, R["ru3"], ops.upsample_bwd(dcat3[..., h2:], 2))
         d_acat = _conv_evo_bwd(cx, R["rk1"], d_assp)
         d_down4 = _aspp_bwd(cx, m.aspp, R["ra"], d_acat)
+        def level_bwd(rec, down, d_pooled, d_skip, need_dx=True):
+            """Backward of an encoder block: its output gradient = d_skip (bridge) + MaxAvgPool backward(d_pooled), composed
+            inside the block's EvoNorm / SE backward where the pooling forward recorded its arg-max bytes."""
+            idx = getattr(down, "_pool_argmax", None)
+            if idx is not None and m.fold_pool_bwd:
+                return _block_bwd(cx, rec, None, need_dx, pool=(d_skip, d_pooled, idx, True))
+            return _block_bwd(cx, rec, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip, with_avg=True), need_dx)
+
         d_p3 = _block_bwd(cx, R["rb4"], d_down4)
-        d_down3 = ops.maxpool2_bwd(down3, d_p3, dx_skip=_conv_evo_bwd(cx, R["rbr3"], dcat3[..., :h2]), with_avg=True)
-        d_p2 = _block_bwd(cx, R["rb3"], d_down3)
-        d_down2 = ops.maxpool2_bwd(down2, d_p2, dx_skip=_conv_evo_bwd(cx, R["rbr2"], dcat2[..., :h1]), with_avg=True)
-        d_p1 = _block_bwd(cx, R["rb2"], d_down2)
-        d_down1 = ops.maxpool2_bwd(down1, d_p1, dx_skip=_conv_evo_bwd(cx, R["rbr1"], dcat1[..., :h0]), with_avg=True)
-        _block_bwd(cx, R["rb1"], d_down1, need_dx=False)
+        d_p2 = level_bwd(R["rb3"], down3, d_p3, _conv_evo_bwd(cx, R["rbr3"], dcat3[..., :h2]))
+        d_p1 = level_bwd(R["rb2"], down2, d_p2, _conv_evo_bwd(cx, R["rbr2"], dcat2[..., :h1]))
+        level_bwd(R["rb1"], down1, d_p1, _conv_evo_bwd(cx, R["rbr1"], dcat1[..., :h0]), need_dx=False)
         grads = cx.grads
         ctx.recs = ctx.bufs = ctx.cx = None
         return (None, None, None) + tuple(grads.get(i) for i in range(ctx.nparams))
@@ -411,6 +416,8 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
         # the output head's backward inside the backward of the decoder1 block (brats_evonorm_se_bwd with dlogits); 0: the
         # separate brats_head_bwd pass, for same-box A/B runs
         self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
+        # the pooling backward + bridge-gradient add inside the block's EvoNorm / SE backward (brats_evonorm_se_bwd_pool)
+        self.fold_pool_bwd = os.environ.get("BRATS_FOLD_POOL", "1") != "0"
         # ... and its forward on the last block's raw convolution output (brats_evonorm_head_fwd): up1 is never stored
         self.fold_head_fwd = os.environ.get("BRATS_FOLD_HEAD_FWD", os.environ.get("BRATS_FOLD_HEAD", "1")) != "0"
         self.skip_deep_heads_in_eval = False

@@ -947,15 +947,39 @@ def evonorm_head(y, mean_rstd, gamma, beta, gate1p, weight, bias, groups=8):
     return out
 
 
-def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None, head=None):
+def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1, w2, groups=8, chan=None, amax=None, head=None,
+                   pool=None):
     """EvoNorm backward of the layer under a ResidualSELayer with the SE backward folded in (csrc/se.hpp): `do` is the
     gradient of the SE block's OUTPUT.  -> (dy, dgamma, dbeta, dconvbias|None, dW1, db1, dW2, db2).
     head = (head_weight [K,C,1,1,1], dlogits [N,K,D,H,W]) instead of `do` (None): the block feeds only the 1x1x1 output head,
-    whose backward is folded in too; two more results: dhead_weight [K,C,1,1,1], dhead_bias [K]."""
+    whose backward is folded in too; two more results: dhead_weight [K,C,1,1,1], dhead_bias [K].
+    pool = (d_skip, d_pooled, argmax bytes, with_avg) instead of `do` (None): the block ends an encoder level, `do` = d_skip +
+    pooling-backward(d_pooled) is composed inside the passes (brats_evonorm_se_bwd_pool)."""
     yp, c, ypitch = _desc(y)
     n, d, h, w, _ = y.shape
     ch = w1.shape[0]
     dev = y.device
+    if pool is not None:
+        dy = new_act(n, d, h, w, c, y.dtype, dev)
+        ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 5) + n * c * 3, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dcb = torch.empty(c, dtype=torch.float32, device=dev) if chan is not None else None
+        gadd = torch.empty((n, c), dtype=torch.float32, device=dev)
+        dw1, db1 = torch.empty((ch, c), dtype=torch.float32, device=dev), torch.empty((ch,), dtype=torch.float32, device=dev)
+        dw2, db2 = torch.empty((c, ch), dtype=torch.float32, device=dev), torch.empty((c,), dtype=torch.float32, device=dev)
+        sp, _, spitch = _desc(pool[0])
+        pp, _, ppitch = _desc(pool[1])
+        _lib.check(_lib.lib().brats_evonorm_se_bwd_pool(sp, spitch, pp, ppitch, pool[2].data_ptr(), int(pool[3]), d, h, w, yp, ypitch,
+                                                        mean_rstd.data_ptr(), _f32(gamma), _f32(beta), dy.data_ptr(), c, ws.data_ptr(),
+                                                        dgamma.data_ptr(), dbeta.data_ptr(),
+                                                        chan.data_ptr() if chan is not None else None,
+                                                        dcb.data_ptr() if dcb is not None else None, _f32(se_chansum.contiguous()),
+                                                        _f32(hidden), _f32(gate1p), _f32(w1.detach().contiguous()),
+                                                        _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(),
+                                                        db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ch, _code(y.dtype), n, c,
+                                                        groups, _f32(amax), _stream()), "evonorm_se_bwd_pool")
+        return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2
     if head is None:
         dop, _, dopitch = _desc(do)
         dl = hw = hws = dhw = dhb = None

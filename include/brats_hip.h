@@ -273,6 +273,17 @@ int brats_evonorm_se_bwd(const void* dout, int dopitch, const void* x, int xpitc
                          const float* hw /* [K][C] */, int K, float* hws /* brats_gn_bwd_head_ws_floats(N, C, K) floats */,
                          float* dhw /* [K][C] */, float* dhb /* [K] */,
                          int dtype, int N, int voxels, int C, int groups, float* amax, brats_stream_t s);
+/* The same for a block that ends an encoder level (block -> MaxAvgPool, equiunet2021.py:261; its output is also the skip
+ * connection): the block's output gradient dskip + pooling-backward(dpool) is composed inside both passes from the pieces and
+ * the arg-max bytes of brats_maxpool2_fwd (with_avg: dpool holds [max | mean], 2C channels).  Replaces
+ * brats_maxpool2_bwd_idx + brats_evonorm_se_bwd(dout): the block's output gradient is never written. */
+int brats_evonorm_se_bwd_pool(const void* dskip, int dskip_pitch, const void* dpool, int dpool_pitch, const unsigned char* argmax,
+                              int with_avg, int D, int H, int W, const void* x, int xpitch, const float* mean_rstd,
+                              const float* gamma, const float* beta, void* dx, int dxpitch, float* ws, float* dgamma,
+                              float* dbeta, const double* chan_sums, float* dconvbias, const float* se_chansum,
+                              const float* hidden, const float* gate1p, const float* w1, const float* w2, float* gadd,
+                              float* dw1, float* db1, float* dw2, float* db2, int Ch, int dtype, int N, int C, int groups,
+                              float* amax, brats_stream_t s);
 /* The forward counterpart: EvoNorm + ResidualSELayer without storing the EvoNorm output z.  Pass 1 reads x and sums
  * x*sigmoid(x) per (n, channel); sum_v z -- what the gate's global average pool reads -- is linear in those sums; pass 2
  * writes out = z * (1 + gate) directly (3 tensor passes instead of the 4 of brats_evonorm_fwd(chansum) + brats_se_fwd +

@@ -281,6 +281,41 @@ def test_evonorm_se_bwd_matches_three_call_composition(n, c, size):
         assert all(torch.equal(a, b) for a, b in zip(again, got) if a is not None)  # bitwise reproducible
 
 
+@pytest.mark.parametrize("n,c,size,with_avg", [(2, 48, (6, 8, 16), True), (1, 16, (4, 6, 10), True), (2, 96, (4, 4, 4), False)])
+def test_evonorm_se_bwd_with_folded_pool_backward(n, c, size, with_avg):
+    """brats_evonorm_se_bwd_pool (the block's output gradient = skip gradient + MaxAvgPool backward composed inside the passes
+    from the pieces and the arg-max bytes) against maxpool2_bwd + evonorm_se_bwd(dout): f32 bit for bit, 16-bit within the
+    rounding of the gradient tensor that is no longer stored."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(51 + c)
+    ch = c // 2
+    for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)):
+        y = torch.randn((n, *size, c), generator=g).to(dev).to(dt)
+        mr = torch.stack([torch.randn((n, 8), generator=g) * 0.1, torch.rand((n, 8), generator=g) + 0.5], -1).to(dev).contiguous()
+        gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+        beta = (torch.randn(c, generator=g) * 0.3).to(dev)
+        w1, b1 = (torch.randn((ch, c), generator=g) * 0.3).to(dev), (torch.randn((ch,), generator=g) * 0.2).to(dev)
+        w2, b2 = (torch.randn((c, ch), generator=g) * 0.3).to(dev), (torch.randn((c,), generator=g) * 0.2).to(dev)
+        out, cs, gate1p, hidden = ops.evonorm_se(y, mr, gamma, beta, w1, b1, w2, b2, 8)
+        ops.maxpool2(out, with_avg, want_argmax=True)
+        dskip = (torch.randn((n, *size, c), generator=g) * 0.1).to(dev).to(dt)
+        dpool = (torch.randn((n, size[0] // 2, size[1] // 2, size[2] // 2, c * (2 if with_avg else 1)), generator=g) * 0.1).to(dev).to(dt)
+        do = ops.maxpool2_bwd(out, dpool, dx_skip=dskip, with_avg=with_avg)
+        ref = ops.evonorm_se_bwd(do, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8)
+        got = ops.evonorm_se_bwd(None, y, mr, gamma, beta, cs, hidden, gate1p, w1, w2, 8, pool=(dskip, dpool, out._pool_argmax, with_avg))
+        names = ("dy", "dgamma", "dbeta", "dcb", "dw1", "db1", "dw2", "db2")
+        for name, a, b in zip(names, got, ref):
+            if b is None:
+                assert a is None
+                continue
+            if tol == 0.0:
+                assert torch.equal(a, b), name
+            else:
+                scale = float(b.float().abs().max()) + 1e-30
+                assert float((a.float() - b.float()).abs().max()) <= tol * scale, (name, str(dt))
+
+
 @pytest.mark.parametrize("n,c,size,k", [(2, 48, (6, 8, 16), 3), (1, 16, (5, 7, 9), 3), (2, 64, (4, 4, 8), 4), (1, 96, (4, 4, 4), 2)])
 def test_output_head_on_the_last_block_without_storing_its_output(n, c, size, k):
     """brats_evonorm_head_fwd (the gated EvoNorm output recomputed on load, rounded to the storage type) == head(evonorm_se(y))
