@@ -44,6 +44,33 @@ def test_host_side_queries_and_argument_errors():
     assert rc == -1 and b"conv3d_fwd" in l.brats_last_error()
     rc = l.brats_maxpool2_fwd(None, 8, None, 8, None, _lib.BF16, 1, 8, 8, 8, 8, 0, None)
     assert rc == -1
+    # the round-3 fold entry points: NULL tensors are argument errors with their own message, unsupported shapes say so
+    P = ctypes.c_void_p
+    one = (ctypes.c_float * 16)()
+    ptr = ctypes.cast(one, P)
+    rc = l.brats_gn_act_bwd_head(None, None, 3, None, 8, None, None, None, None, 8, None, None, None, None, None, None, _lib.BF16,
+                                 1, 0.01, 1, 64, 8, 8, None, None)
+    assert rc == -1 and b"gn_act_bwd_head" in l.brats_last_error()
+    rc = l.brats_gn_act_bwd_head(ptr, ptr, 4, ptr, 8, ptr, ptr, ptr, ptr, 8, ptr, ptr, ptr, ptr, ptr, ptr, _lib.BF16, 1, 0.01, 1, 64, 8,
+                                 8, None, None)
+    assert rc == -2 and b"K = 3" in l.brats_last_error()  # (four logit planes: the two-call path is the one to use)
+    rc = l.brats_gn_head_fwd(None, 8, None, 1, 0.01, None, None, None, _lib.BF16, 1, 8, 3, 64, None)
+    assert rc == -1 and b"gn_head_fwd" in l.brats_last_error()
+    rc = l.brats_gn_head_fwd(ptr, 8, ptr, 4, 0.01, ptr, None, ptr, _lib.BF16, 1, 8, 3, 64, None)
+    assert rc == -2 and b"relu" in l.brats_last_error()  # (swish: not an activation this fold is built for)
+    rc = l.brats_gn_act_bwd_pool(None, 8, None, 8, None, None, 8, None, None, None, None, 8, None, None, None, _lib.BF16, 1, 0.01, 1, 8,
+                                 8, 8, 8, 8, None, None)
+    assert rc == -1 and b"gn_act_bwd_pool" in l.brats_last_error()
+    rc = l.brats_affine_act_pool_fwd(None, 8, None, None, 8, None, 8, None, _lib.BF16, 1, 0.01, None, 1, 8, 8, 8, 8, 0, None, None)
+    assert rc == -1 and b"affine_act_pool_fwd" in l.brats_last_error()
+    rc = l.brats_maxpool2_bwd_idx(None, None, 8, None, 8, None, 8, _lib.BF16, 1, 8, 8, 8, 8, 0, None)
+    assert rc == -1 and b"maxpool2_bwd_idx" in l.brats_last_error()
+    rc = l.brats_evonorm_se_fwd(None, 8, None, None, None, None, None, None, None, None, 8, None, None, None, None, 4, _lib.BF16, 1,
+                                64, 8, 8, None, None)
+    assert rc == -1 and b"evonorm_se_fwd" in l.brats_last_error()
+    rc = l.brats_se_fwd(None, 1.0, None, None, None, None, None, None, 1, 8, 4, None)
+    assert rc == -1 and b"se_fwd" in l.brats_last_error()
+    assert l.brats_gn_bwd_head_ws_floats(2, 48, 3) == 2 * 2048 * (3 * 48 + 3)
 
 
 def test_state_dict_contract_and_factory_errors():
