@@ -959,27 +959,26 @@ def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1
     n, d, h, w, _ = y.shape
     ch = w1.shape[0]
     dev = y.device
+
+    def f32(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+
+    dy = new_act(n, d, h, w, c, y.dtype, dev)
+    ws = f32(_lib.lib().brats_chan_ws_floats(n, c, 5) + n * c * 3)
+    dgamma, dbeta, dcb = f32(c), f32(c), (f32(c) if chan is not None else None)
+    gadd, dw1, db1, dw2, db2 = f32(n, c), f32(ch, c), f32(ch), f32(c, ch), f32(c)
+    # the arguments the two entry points share, in their order
+    norm = (yp, ypitch, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), dy.data_ptr(), c, ws.data_ptr(), dgamma.data_ptr(),
+            dbeta.data_ptr(), chan.data_ptr() if chan is not None else None, dcb.data_ptr() if dcb is not None else None,
+            _f32(se_chansum.contiguous()), _f32(hidden), _f32(gate1p), _f32(w1.detach().contiguous()),
+            _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ch)
+    res = (dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2)
     if pool is not None:
-        dy = new_act(n, d, h, w, c, y.dtype, dev)
-        ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 5) + n * c * 3, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-        dcb = torch.empty(c, dtype=torch.float32, device=dev) if chan is not None else None
-        gadd = torch.empty((n, c), dtype=torch.float32, device=dev)
-        dw1, db1 = torch.empty((ch, c), dtype=torch.float32, device=dev), torch.empty((ch,), dtype=torch.float32, device=dev)
-        dw2, db2 = torch.empty((c, ch), dtype=torch.float32, device=dev), torch.empty((c,), dtype=torch.float32, device=dev)
         sp, _, spitch = _desc(pool[0])
         pp, _, ppitch = _desc(pool[1])
-        _lib.check(_lib.lib().brats_evonorm_se_bwd_pool(sp, spitch, pp, ppitch, pool[2].data_ptr(), int(pool[3]), d, h, w, yp, ypitch,
-                                                        mean_rstd.data_ptr(), _f32(gamma), _f32(beta), dy.data_ptr(), c, ws.data_ptr(),
-                                                        dgamma.data_ptr(), dbeta.data_ptr(),
-                                                        chan.data_ptr() if chan is not None else None,
-                                                        dcb.data_ptr() if dcb is not None else None, _f32(se_chansum.contiguous()),
-                                                        _f32(hidden), _f32(gate1p), _f32(w1.detach().contiguous()),
-                                                        _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(),
-                                                        db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), ch, _code(y.dtype), n, c,
-                                                        groups, _f32(amax), _stream()), "evonorm_se_bwd_pool")
-        return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2
+        _lib.check(_lib.lib().brats_evonorm_se_bwd_pool(sp, spitch, pp, ppitch, pool[2].data_ptr(), int(pool[3]), d, h, w, *norm,
+                                                        _code(y.dtype), n, c, groups, _f32(amax), _stream()), "evonorm_se_bwd_pool")
+        return res
     if head is None:
         dop, _, dopitch = _desc(do)
         dl = hw = hws = dhw = dhb = None
@@ -989,29 +988,10 @@ def evonorm_se_bwd(do, y, mean_rstd, gamma, beta, se_chansum, hidden, gate1p, w1
         k = head[0].shape[0]
         hw = head[0].detach().reshape(k, c).contiguous().float()
         dl = head[1].contiguous().float()
-        hws = torch.empty(_lib.lib().brats_gn_bwd_head_ws_floats(n, c, k), dtype=torch.float32, device=dev)
-        dhw = torch.empty((k, c), dtype=torch.float32, device=dev)
-        dhb = torch.empty(k, dtype=torch.float32, device=dev)
-    dy = new_act(n, d, h, w, c, y.dtype, dev)
-    ws = torch.empty(_lib.lib().brats_chan_ws_floats(n, c, 5) + n * c * 3, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
-    dcb = torch.empty(c, dtype=torch.float32, device=dev) if chan is not None else None
-    gadd = torch.empty((n, c), dtype=torch.float32, device=dev)
-    dw1, db1 = torch.empty((ch, c), dtype=torch.float32, device=dev), torch.empty((ch,), dtype=torch.float32, device=dev)
-    dw2, db2 = torch.empty((c, ch), dtype=torch.float32, device=dev), torch.empty((c,), dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().brats_evonorm_se_bwd(dop, dopitch, yp, ypitch, mean_rstd.data_ptr(), _f32(gamma), _f32(beta), dy.data_ptr(), c,
-                                               ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                               chan.data_ptr() if chan is not None else None,
-                                               dcb.data_ptr() if dcb is not None else None, _f32(se_chansum.contiguous()),
-                                               _f32(hidden), _f32(gate1p), _f32(w1.detach().contiguous()),
-                                               _f32(w2.detach().contiguous()), gadd.data_ptr(), dw1.data_ptr(), db1.data_ptr(),
-                                               dw2.data_ptr(), db2.data_ptr(), ch, _f32(dl), _f32(hw), k, _f32(hws), _f32(dhw),
-                                               _f32(dhb), _code(y.dtype), n, d * h * w, c, groups, _f32(amax), _stream()),
-               "evonorm_se_bwd")
-    if head is None:
-        return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2
-    return dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2, dhw.reshape(k, c, 1, 1, 1), dhb
+        hws, dhw, dhb = f32(_lib.lib().brats_gn_bwd_head_ws_floats(n, c, k)), f32(k, c), f32(k)
+    _lib.check(_lib.lib().brats_evonorm_se_bwd(dop, dopitch, *norm, _f32(dl), _f32(hw), k, _f32(hws), _f32(dhw), _f32(dhb),
+                                               _code(y.dtype), n, d * h * w, c, groups, _f32(amax), _stream()), "evonorm_se_bwd")
+    return res if head is None else res + (dhw.reshape(k, c, 1, 1, 1), dhb)
 
 
 _DCONV_JOB = np.dtype([("term", [("x", "<u8"), ("w", "<u8"), ("xpitch", "<i4"), ("cin", "<i4"), ("ksize", "<i4"), ("dil", "<i4")], (4,)),
