@@ -314,6 +314,48 @@ def test_prelu_network_vs_reference_golden_and_oracle(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fold_forms_leave_the_step_unchanged(name, precision):
+    """The round-3 fold forms (output head inside the last layer's normalisation passes, pooling backward inside the next
+    normalisation backward: model.fold_head_fwd / fold_head_bwd / fold_pool_bwd) against the separate kernels they replace:
+    the forward is bit-identical (logits of all heads); the gradients are equal up to the rounding of the tensors that are no
+    longer stored (none in f32 but the summation order of two reductions; one bf16 rounding of two gradient tensors)."""
+    import argparse, contextlib, copy, io
+    from brats21_amd import get_model, synth
+    from brats21_amd.losses import DiceLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ns = argparse.Namespace(model=name, width=16, norm="group", act="relu", num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = get_model(ns).to(dev).train()
+    base.precision = precision
+    x = synth.random_image(2, 4, (32, 32, 32), seed=7, device=dev)
+    t = synth.nested_spheres(2, (32, 32, 32), device=dev)
+    crit = DiceLoss().to(dev)
+
+    def run(fold):
+        model = copy.deepcopy(base)
+        model.fold_head_fwd = model.fold_head_bwd = model.fold_pool_bwd = fold
+        out, deep = model(x)
+        loss = crit(out.float(), t) + sum(crit(d.float(), t) for d in deep)
+        loss.backward()
+        return ([out.detach()] + [d.detach() for d in deep],
+                [p.grad.detach().clone() if p.grad is not None else None for p in model.parameters()])
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(o1, o0))
+    tol = 2e-4 if precision == "fp32" else 4e-2
+    names = [n for n, _ in base.named_parameters()]
+    for n, a, b in zip(names, g1, g0):
+        assert (a is None) == (b is None), n
+        if a is None:  # (a parameter the forward does not use)
+            continue
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= tol * scale, (n, float((a - b).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
 def test_multi_tensor_weight_packing_is_transparent(name):
     """ops.PackPlan (one packing launch per training step) must not change a single bit: three optimizer steps with and
     without it, from the same initial weights; the plan must follow in-place updates (version counters) and survive
