@@ -937,8 +937,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
   const size_t i4 = (size_t)blockIdx.x * 32 + e;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i4 < per4)
-    for (int k = g; k < nsplit; k += 8) s += *(const f32x4*)(ws + (size_t)k * per + i4 * 4);
+  if (i4 < per4) {
+    // eight slabs in flight per thread, added in slab order (the one-load loop hipcc makes of the plain form waits for every
+    // load before it issues the next: 32 serial HBM round trips per thread at 256 slabs, 49 us for 64 MB)
+    const float* src = ws + i4 * 4;
+    int k = g;
+    for (; k + 56 < nsplit; k += 64) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(src + (size_t)(k + 8 * u) * per);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; k += 8) s += *(const f32x4*)(src + (size_t)k * per);
+  }
   __shared__ f32x4 part[8][32];
   part[g][e] = s;
   __syncthreads();
@@ -952,6 +964,62 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) dw[((size_t)co * cin + ci + j) * taps + tap] = s[j];
   }
+}
+
+// The same reduction for layers with many (co, ci) pairs (and therefore few slabs): a block owns 128 consecutive (co, ci)
+// positions and ALL taps; thread (e, g) sums the slabs of taps g, g + 8, g + 16, g + 24 in slab order -- up to 4 x 8 loads
+// in flight, no cross-thread step -- into an LDS tile [taps][128]; the 128 x taps floats of dw, one contiguous run in the
+// [co][ci][tap] layout, then go out with coalesced stores.  (The plain kernel's stores are 4-byte pieces at a 108-byte stride:
+// 4 M of them for a 384 x 384 layer, 54 us for 16 MB; a first all-taps form that kept the 8 split groups took 27 serial round
+// trips per block -- with 4 slabs only half of its threads had a load at all: 26 us.)  Fixed order: bitwise reproducible.
+__global__ void __launch_bounds__(256) wgrad_reduce_taps_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
+                                                                int cout, int cin, int taps) {
+  extern __shared__ __attribute__((aligned(16))) float red_tile[];  // [taps][128]
+  const size_t per = (size_t)taps * cout * cin, pairs4 = (size_t)cout * cin / 4;
+  const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const size_t p4 = (size_t)blockIdx.x * 32 + e;  // f32x4 index among the (co, ci) pairs
+  if (p4 < pairs4) {
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nsplit; k0 += 8) {
+      f32x4 v[4][8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int tap = g + 8 * t;
+        const float* src = ws + ((size_t)(tap < taps ? tap : 0) * cout * cin + p4 * 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[t][u] = (tap < taps && k0 + u < nsplit) ? *(const f32x4*)(src + (size_t)(k0 + u) * per) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < nsplit) s[t] += v[t][u];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (g + 8 * t < taps) *(f32x4*)(red_tile + (g + 8 * t) * 128 + e * 4) = s[t];
+  }
+  __syncthreads();
+  // dw[(pair) * taps + tap] for the block's 128 pairs: 128 * taps consecutive floats
+  const size_t pair0 = (size_t)blockIdx.x * 128, npairs = (size_t)cout * cin;
+  float* dst = dw + pair0 * taps;
+  for (int i = threadIdx.x; i < 128 * taps; i += blockDim.x) {
+    const int pr = i / taps, tap = i % taps;
+    if (pair0 + pr < npairs) dst[i] = red_tile[tap * 128 + pr];
+  }
+}
+
+static void wgrad_reduce_launch(const float* ws, float* dw, int nsplit, int cout, int cin, int taps, hipStream_t st) {
+  const size_t per = (size_t)taps * cout * cin;
+  const size_t tblocks = ((size_t)cout * cin / 4 + 31) / 32;
+  if (taps > 1 && taps <= 32 && tblocks >= 256)  // enough (co, ci) pairs for a grid of all-taps blocks: coalesced stores
+    hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)tblocks), dim3(256), (size_t)taps * 128 * sizeof(float), st, ws, dw,
+                       nsplit, cout, cin, taps);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per / 4 + 31) / 32)), dim3(256), 0, st, ws, dw, nsplit, cout, cin, taps);
 }
 
 // dbias[c] = sum_v dy[v][c]
@@ -1134,9 +1202,7 @@ extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1,
   } else if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
   else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);
   if (rc) return rc;
-  const size_t per = (size_t)27 * cout * p.cin;
-  const size_t blocks = (per / 4 + 31) / 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, p.cin, 27);
+  wgrad_reduce_launch((const float*)ws, dw, p.nsplit, cout, p.cin, 27, st);
   if (dbias) {
     const size_t vox = (size_t)N * D * H * W;
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
@@ -1201,9 +1267,7 @@ extern "C" int BRATS_API(brats_conv3d_wgrad_shift)(const void* x, int cin, int x
   dim3 grid(p.ntaps * p.nsplit, cot, cit);
   const int rc = dtype == BRATS_BF16 ? wgrad_dispatch<bf16_t, 1, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 1, 1>(p, cof, cif, grid, st);
   if (rc) return rc;
-  const size_t per = (size_t)p.ntaps * cout * cin;
-  const size_t blocks = (per / 4 + 31) / 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, cin, p.ntaps);
+  wgrad_reduce_launch((const float*)ws, dw, p.nsplit, cout, cin, p.ntaps, st);
   if (dbias) {
     const size_t vox = (size_t)N * D * H * W;
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
@@ -1283,9 +1347,7 @@ extern "C" int BRATS_API(brats_conv3d_wgrad_f8)(const void* x1, int c1, int pitc
   hipStream_t st = (hipStream_t)s;
   const int rc = cof == 3 ? wgrad_f8_launch<3, 3>(pp, st) : wgrad_f8_launch<4, 2>(pp, st);
   if (rc) return rc;
-  const size_t per = (size_t)27 * cout * p.cin;
-  const size_t blocks = (per / 4 + 31) / 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, dw, p.nsplit, cout, p.cin, 27);
+  wgrad_reduce_launch((const float*)ws, dw, p.nsplit, cout, p.cin, 27, st);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
