@@ -52,8 +52,17 @@ __global__ void __launch_bounds__(256) ordered_sum_kernel(const float* __restric
   const int i = blockIdx.x * 8 + e;
   float s = 0.f;
   if (i < total) {
-#pragma unroll 4
-    for (int b = g; b < nb; b += 32) s += part[(size_t)b * total + i];
+    // eight partials in flight, added in block order (hipcc turns the plain loop into load - wait - add, one round trip each)
+    const float* src = part + i;
+    int b = g;
+    for (; b + 7 * 32 < nb; b += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 32 * u) * total];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nb; b += 32) s += src[(size_t)b * total];
   }
   __shared__ float sm[32][8];
   sm[g][e] = s;

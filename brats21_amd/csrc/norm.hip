@@ -724,8 +724,17 @@ __global__ void __launch_bounds__(256) gn_bwd_finish_kernel(float* __restrict__ 
   const float* part = red + total;
   float s = 0.f;
   if (i < total) {
-#pragma unroll 4
-    for (int b = g; b < nb; b += 32) s += part[(size_t)b * total + i];
+    // eight partials in flight, added in block order (the plain loop compiles to one round trip per partial)
+    const float* src = part + i;
+    int b = g;
+    for (; b + 7 * 32 < nb; b += 8 * 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + 32 * u) * total];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nb; b += 32) s += src[(size_t)b * total];
   }
   __shared__ float sm[32][8];
   sm[g][e] = s;
