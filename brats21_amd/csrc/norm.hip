@@ -109,6 +109,89 @@ __global__ void gn_finalize_kernel(double* __restrict__ chan, int splits, int N,
   }
 }
 
+// Both stages in ONE launch when a group's partials are few enough for one workgroup to take in a handful of load batches
+// (tiles x channels-per-group <= 64 k pairs: every layer of the published widths): block (n, group) of 1024 threads, thread
+// (channel cl, tile lane tl) adds the tiles tl, tl + TL, ... in f64 (eight loads in flight), the TL lane sums of a channel are
+// added in lane order through LDS, then the group finishes as above.  One ~5 us launch instead of two (10 us): 17 - 21 such
+// pairs per training step, 17 per patch forward of the sliding-window inference.
+__global__ void __launch_bounds__(1024) gn_finalize_direct_kernel(const float* __restrict__ stats, int tps, double* __restrict__ chan,
+                                                                  int N, int C, int groups, double count_per_channel, float eps,
+                                                                  int unbiased, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ mean_rstd,
+                                                                  float* __restrict__ scale_shift) {
+  const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cpg = C / groups;
+  __shared__ double r1[1024], r2[1024];
+  const int TL = 1024 / cpg;  // >= 4 (cpg <= 256)
+  const int cl = threadIdx.x % cpg, tl = threadIdx.x / cpg;
+  double p1 = 0.0, p2 = 0.0;
+  if (tl < TL) {
+    const float* src = stats + (((size_t)n * tps) * C + g * cpg + cl) * 2;
+    int t = tl;
+    for (; t + 7 * TL < tps; t += 8 * TL) {
+      f32x2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x2*)(src + (size_t)(t + u * TL) * C * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { p1 += v[u][0]; p2 += v[u][1]; }
+    }
+    for (; t < tps; t += TL) {
+      const f32x2 v = *(const f32x2*)(src + (size_t)t * C * 2);
+      p1 += v[0];
+      p2 += v[1];
+    }
+  }
+  r1[threadIdx.x] = p1;
+  r2[threadIdx.x] = p2;
+  __syncthreads();
+  double s1 = 0.0, s2 = 0.0;
+  if ((int)threadIdx.x < cpg) {
+    for (int z = 0; z < TL; ++z) { s1 += r1[z * cpg + threadIdx.x]; s2 += r2[z * cpg + threadIdx.x]; }
+    const int c = g * cpg + threadIdx.x;
+    chan[((size_t)n * C + c) * 2] = s1;  // per-channel totals (EvoNorm's backward reads them)
+    chan[((size_t)n * C + c) * 2 + 1] = s2;
+  }
+  __syncthreads();
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int m = 128; m > 0; m >>= 1) {  // (only the first cpg <= 256 entries are non-zero)
+    if ((int)threadIdx.x < m) { r1[threadIdx.x] += r1[threadIdx.x + m]; r2[threadIdx.x] += r2[threadIdx.x + m]; }
+    __syncthreads();
+  }
+  const double M = count_per_channel * cpg;
+  const double mean = r1[0] / M;
+  double var = r2[0] / M - mean * mean;
+  if (unbiased) var = var * M / (M - 1.0);
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    mean_rstd[(n * groups + g) * 2] = (float)mean;
+    mean_rstd[(n * groups + g) * 2 + 1] = rstd;
+  }
+  if (scale_shift && (int)threadIdx.x < cpg) {
+    const int c = g * cpg + threadIdx.x;
+    const float sc = rstd * gamma[c];
+    scale_shift[((size_t)n * C + c) * 2] = sc;
+    scale_shift[((size_t)n * C + c) * 2 + 1] = beta[c] - (float)mean * sc;
+  }
+}
+
+static int gn_finalize_launch(const float* stats, int tps, int N, int C, int groups, double count_per_channel, float eps, int unbiased,
+                              const float* gamma, const float* beta, float* mean_rstd, float* scale_shift, double* chan_ws,
+                              hipStream_t st) {
+  if ((size_t)tps * (C / groups) <= 65536) {
+    hipLaunchKernelGGL(gn_finalize_direct_kernel, dim3(N * groups), dim3(1024), 0, st, stats, tps, chan_ws, N, C, groups,
+                       count_per_channel, eps, unbiased, gamma, beta, mean_rstd, scale_shift);
+  } else {
+    if (int rc = chan_reduce_launch(stats, tps, N, C, chan_ws, st)) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, st, chan_ws, gn_splits(tps), N, C, groups, count_per_channel,
+                       eps, unbiased, gamma, beta, mean_rstd, scale_shift);
+  }
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" size_t BRATS_API(brats_gn_ws_doubles)(int N, int C) { return (size_t)(1 + GN_MAX_SPLITS) * N * C * 2; }
 
 extern "C" int BRATS_API(brats_gn_finalize)(const float* stats, int tiles_per_sample, int N, int C, int groups,
@@ -116,11 +199,8 @@ extern "C" int BRATS_API(brats_gn_finalize)(const float* stats, int tiles_per_sa
                                  float* mean_rstd, float* scale_shift, double* chan_ws, brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: bad argument");
   if (scale_shift && (!gamma || !beta)) BRATS_FAIL(BRATS_E_ARG, "gn_finalize: scale_shift needs gamma/beta");
-  if (int rc = chan_reduce_launch(stats, tiles_per_sample, N, C, chan_ws, (hipStream_t)s)) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, chan_ws, gn_splits(tiles_per_sample), N, C,
-                     groups, count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift);
-  BRATS_CHECK_LAUNCH();
-  return 0;
+  return gn_finalize_launch(stats, tiles_per_sample, N, C, groups, count_per_channel, eps, 0, gamma, beta, mean_rstd, scale_shift, chan_ws,
+                            (hipStream_t)s);
 }
 
 // ---- z = act(y*scale + shift) ------------------------------------------------------------------
@@ -1086,11 +1166,8 @@ extern "C" int BRATS_API(brats_evonorm_finalize)(const float* stats, int tiles_p
                                       double count_per_channel, float eps, float* mean_rstd, double* chan_ws,
                                       brats_stream_t s) {
   if (!stats || !mean_rstd || !chan_ws || C % groups || C / groups > 256) BRATS_FAIL(BRATS_E_ARG, "evonorm_finalize: bad argument");
-  if (int rc = chan_reduce_launch(stats, tiles_per_sample, N, C, chan_ws, (hipStream_t)s)) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)s, chan_ws, gn_splits(tiles_per_sample), N, C,
-                     groups, count_per_channel, eps, 1, (const float*)nullptr, (const float*)nullptr, mean_rstd, (float*)nullptr);
-  BRATS_CHECK_LAUNCH();
-  return 0;
+  return gn_finalize_launch(stats, tiles_per_sample, N, C, groups, count_per_channel, eps, 1, nullptr, nullptr, mean_rstd, nullptr, chan_ws,
+                            (hipStream_t)s);
 }
 
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup): the three
