@@ -110,7 +110,7 @@ __global__ void gn_finalize_kernel(double* __restrict__ chan, int splits, int N,
 }
 
 // Both stages in ONE launch when a group's partials are few enough for one workgroup to take in a handful of load batches
-// (tiles x channels-per-group <= 64 k pairs: every layer of the published widths): block (n, group) of 1024 threads, thread
+// (tiles x channels-per-group <= 32 k pairs: every layer below the 128^3 level; with 48 k pairs the one block per group took 27 us): block (n, group) of 1024 threads, thread
 // (channel cl, tile lane tl) adds the tiles tl, tl + TL, ... in f64 (eight loads in flight), the TL lane sums of a channel are
 // added in lane order through LDS, then the group finishes as above.  One ~5 us launch instead of two (10 us): 17 - 21 such
 // pairs per training step, 17 per patch forward of the sliding-window inference.
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(1024) gn_finalize_direct_kernel(const float* _
 static int gn_finalize_launch(const float* stats, int tps, int N, int C, int groups, double count_per_channel, float eps, int unbiased,
                               const float* gamma, const float* beta, float* mean_rstd, float* scale_shift, double* chan_ws,
                               hipStream_t st) {
-  if ((size_t)tps * (C / groups) <= 65536) {
+  if ((size_t)tps * (C / groups) <= 32768) {
     hipLaunchKernelGGL(gn_finalize_direct_kernel, dim3(N * groups), dim3(1024), 0, st, stats, tps, chan_ws, N, C, groups,
                        count_per_channel, eps, unbiased, gamma, beta, mean_rstd, scale_shift);
   } else {
