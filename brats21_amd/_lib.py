@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRATS_HIP_LIB") or os.path.join(_HERE, "libbrats_hip.so")  # override: A/B builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "brats_hip.h")
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, X3_BF16, X3_F16 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_SWISH, ACT_MISH = 0, 1, 2, 3, 4, 5
 PACK_FWD, PACK_DGRAD = 0, 1
 

@@ -152,6 +152,18 @@ DEVI float f8_scale_from_amax(float amax) {
 }
 
 
+// ---- split precision (conv_igemm_x3.hpp, wgrad_x3): a tensor whose values lie far outside fp16's range (gradients) is
+// multiplied by a power of two on its way into the fp16 hi / lo split so that its |max| lands in [2^14, 2^15); the result is
+// multiplied by the inverse.  Both are exact.  amax = 0 / inf / NaN: scale 1 (non-finite values propagate as they are).
+DEVI float x3_scale_from_amax(float amax) {
+  const uint32_t e = (__float_as_uint(amax) >> 23) & 0xffu;
+  if (e == 0u || e == 255u) return 1.f;
+  uint32_t se = 268u - e;        // 2^(14 - (e - 127))
+  se = se > 227u ? 227u : se;    // (|max| < 2^-86: 2^100 at most, so that 1 / scale stays a normal number)
+  return __uint_as_float(se << 23);
+}
+DEVI float x3_inv_scale(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }  // scale = 2^k -> 2^-k
+
 // ---- LDS-DMA (buffer_load ... lds) helpers shared by the weight-gradient and the loader-wave convolution kernels ----
 // a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop
 // into registers the accumulators need.  (The host pass of hipcc instantiates the kernel template's generic lambdas too

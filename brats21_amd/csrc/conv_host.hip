@@ -1,7 +1,7 @@
 // C-ABI entry points for the implicit-GEMM convolution: weight packing + forward/dgrad launch.
 #include <stdlib.h>
 #include "twin_begin.hpp"
-#include "conv_igemm.hpp"
+#include "conv_igemm_x3.hpp"
 
 // ---- chunk selection ---------------------------------------------------------------------------
 int g_conv_vs8_mode = -1;
@@ -20,6 +20,14 @@ static int conv_vs8_enabled() {
 }
 
 extern "C" int BRATS_API(brats_conv3d_chunk)(int dtype, int ksize, int dil, int c1, int c2, int cout) {
+  if (dtype == BRATS_X3_BF16) {
+    // split precision (conv_igemm_x3.hpp): hi + lo LDS tiles = the f32 tile's bytes; 24 channels keep two workgroups per CU
+    if (ksize != 3) return 0;
+    static const int x3[] = {24, 16, 8};
+    for (int i = 0; i < 3; ++i)
+      if (c1 % x3[i] == 0 && (c2 <= 0 || c2 % x3[i] == 0)) return x3[i];
+    return 0;
+  }
   // Cout = 48 (mod 96), bf16, 3x3x3 dilation 1: 24-channel chunks for the 4x8x16-tile kernel (conv_igemm_vs8.hpp)
   if (dtype == BRATS_BF16 && ksize == 3 && dil == 1 && cout > 0 && conv_vs8_enabled() && conv_vsplit_enabled()) {
     const int rows16 = ceil_div(cout, 16);
@@ -41,19 +49,21 @@ extern "C" int BRATS_API(brats_conv3d_chunk)(int dtype, int ksize, int dil, int 
 
 static int macro_steps(int dtype, int ksize, int ck) {
   const int taps = ksize * ksize * ksize;
-  if (dtype == BRATS_BF16) return (taps * (ck / 8) + 3) / 4;
+  if (dtype == BRATS_BF16 || dtype == BRATS_X3_BF16) return (taps * (ck / 8) + 3) / 4;
   return (taps * ck / 4 + 3) / 4;
 }
 
 extern "C" size_t BRATS_API(brats_conv3d_packed_bytes)(int dtype, int ksize, int cin, int cout, int ck) {
   if (ck <= 0 || cin % ck) return 0;
   const int rows16 = ceil_div(cout, 16);
-  return (size_t)(cin / ck) * macro_steps(dtype, ksize, ck) * rows16 * 64 * 16;
+  // (split precision: a hi and a lo fragment per (macro-step, row16))
+  return (size_t)(cin / ck) * macro_steps(dtype, ksize, ck) * rows16 * 64 * 16 * (dtype == BRATS_X3_BF16 ? 2 : 1);
 }
 
 // ---- weight packing ----------------------------------------------------------------------------
 // out[chunk][ms][row16][lane][16 B]; see conv_igemm.hpp for the unit -> (tap, channel) map.
-template <typename T>
+// X3 (split precision, conv_igemm_x3.hpp): out[chunk][ms][row16][hi | lo][lane][16 B], hi = rn16(w), lo = rn16(w - hi)
+template <typename T, bool X3 = false>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int taps,
                                     int cin_w, int cin_off, int rows, int rows16, int kdim, int ck, int ms_n,
                                     size_t total) {
@@ -64,6 +74,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   const int e = idx % EPL;
   size_t t = idx / EPL;
   const int lane = t % 64; t /= 64;
+  int hl = 0;
+  if (X3) { hl = t % 2; t /= 2; }
   const int ft = t % rows16; t /= rows16;
   const int ms = t % ms_n;
   const int chunk = t / ms_n;
@@ -86,6 +98,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     if (mode == BRATS_PACK_FWD) val = w[((size_t)row * cin_w + cin_off + kc) * taps + tap];
     else val = w[((size_t)kc * cin_w + cin_off + row) * taps + (taps - 1 - tap)];
   }
+  if (X3 && hl) val -= to_f<T>(from_f<T>(val));
   out[idx] = from_f<T>(val);
 }
 
@@ -99,11 +112,14 @@ extern "C" int BRATS_API(brats_conv3d_pack_weights)(const float* w, void* packed
   if (kdim % ck) BRATS_FAIL(BRATS_E_ARG, "pack_weights: K channels %d not a multiple of chunk %d", kdim, ck);
   const int rows16 = ceil_div(rows, 16);
   const int ms = macro_steps(dtype, ksize, ck);
-  const int epl = dtype == BRATS_BF16 ? 8 : 4;
-  const size_t total = (size_t)(kdim / ck) * ms * rows16 * 64 * epl;
+  const int epl = dtype == BRATS_F32 ? 4 : 8;
+  const size_t total = (size_t)(kdim / ck) * ms * rows16 * 64 * epl * (dtype == BRATS_X3_BF16 ? 2 : 1);
   const int blocks = (int)((total + 255) / 256);
   if (dtype == BRATS_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, mode,
+                       taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
+  else if (dtype == BRATS_X3_BF16)
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, mode,
                        taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
   else
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)packed, mode,
@@ -150,11 +166,14 @@ __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const brats_pac
   const brats_pack_job J = jobs[blocks[blockIdx.x * 2]];
   const size_t base = (size_t)blocks[blockIdx.x * 2 + 1] * PACK_BLOCK + (size_t)threadIdx.x * (PACK_BLOCK / 256);
   if (base >= J.total) return;
-  if (J.dtype == BRATS_BF16) {
+  if (J.dtype == BRATS_BF16 || J.dtype == BRATS_X3_BF16) {
     // a thread owns one lane's 8 elements of a fragment (= 8 consecutive K channels of one tap): index math once, one
-    // 16-byte store
+    // 16-byte store.  (split precision: hi and lo fragments side by side, see pack_weights_kernel)
+    const bool x3 = J.dtype == BRATS_X3_BF16;
     size_t t = base / 8;
     const int lane = t % 64; t /= 64;
+    int hl = 0;
+    if (x3) { hl = t % 2; t /= 2; }
     const int ft = t % J.rows16; t /= J.rows16;
     const int ms = t % J.ms_n;
     const int chunk = t / J.ms_n;
@@ -170,7 +189,7 @@ __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const brats_pac
         if (J.mode == BRATS_PACK_FWD) { if (J.cin_off + kc < J.cin_real) val = J.w[((size_t)row * J.cin_real + J.cin_off + kc) * J.taps + tap]; }
         else { if (J.cin_off + row < J.cin_real) val = J.w[((size_t)kc * J.cin_real + J.cin_off + row) * J.taps + (J.taps - 1 - tap)]; }
       }
-      v[e] = val;
+      v[e] = hl ? val - bf2f(f2bf(val)) : val;
     }
     Vec<bf16_t, 8>::store((bf16_t*)J.out + base, v);
   } else {
@@ -194,10 +213,10 @@ extern "C" int BRATS_API(brats_conv3d_tiles_per_sample)(int D, int H, int W) {
   return ceil_div(D, CONV_TZ) * ceil_div(H, CONV_TY) * ceil_div(W, CONV_TX);
 }
 
-extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
-                                const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
-                                int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
-                                int cout, brats_stream_t s) {
+static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const float* xamax,
+                         const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
+                         int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
+                         int cout, brats_stream_t s) {
   if (!x1 || !packed_w || !y || c1 <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0)
     BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: null pointer or non-positive size");
   if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: c2 > 0 but x2 is NULL");
@@ -206,6 +225,8 @@ extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, c
   const int align = dtype == BRATS_BF16 ? 8 : 4;
   if (pitch1 % align || (c2 && pitch2 % align) || ypitch % 4)
     BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: channel pitches must keep 16-byte loads / 4-channel stores aligned");
+  if (dtype == BRATS_X3_BF16 && (ksize != 3 || ((size_t)x1 & 15) || (c2 && ((size_t)x2 & 15))))
+    BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: the split-precision kernel is 3x3x3 only, on 16-byte aligned f32 tensors");
   {  // staged pieces are addressed by 32-bit byte offsets inside one sample (buffer_load voffset)
     const int mp = pitch1 > pitch2 ? pitch1 : pitch2;
     if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
@@ -216,7 +237,7 @@ extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, c
   ConvParams p;
   p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
   p.wpk = packed_w; p.bias = bias; p.y = y; p.ypitch = ypitch; p.stats = stats;
-  p.y2 = y2; p.y2pitch = y2pitch; p.ysplit = ysplit;
+  p.y2 = y2; p.y2pitch = y2pitch; p.ysplit = ysplit; p.xamax = xamax;
   if (y2) {
     const ConvTileChoice tc = conv_choose_tile(ceil_div(cout, 16));
     if (ysplit <= 0 || ysplit >= cout || ysplit % (tc.nf * 16) || y2pitch % 4)
@@ -235,10 +256,31 @@ extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, c
   if (ksize == 3 && dil == 2) return conv_launch<T, 3, 2>(p, ck, st); \
   if (ksize == 1) return conv_launch<T, 1, 1>(p, ck, st);
   if (dtype == BRATS_BF16) { GO(bf16_t) }
+  else if (dtype == BRATS_X3_BF16) {
+    if (dil == 1) return conv_x3_launch<1>(p, ck, st);
+    if (dil == 2) return conv_x3_launch<2>(p, ck, st);
+  }
 #ifndef BRATS_FP16  // (the f32 kernels live in translation units of their own that are not built twice)
   else if (dtype == BRATS_F32) { GO(float) }
 #endif
 #undef GO
   BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd: unsupported dtype=%d ksize=%d dilation=%d", dtype, ksize, dil);
+}
+
+extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
+                                const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
+                                int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
+                                int cout, brats_stream_t s) {
+  return conv_fwd_impl(x1, c1, pitch1, x2, c2, pitch2, nullptr, packed_w, bias, y, ypitch, y2, y2pitch, ysplit, stats, dtype, ksize,
+                       dil, N, D, H, W, cout, s);
+}
+
+extern "C" int BRATS_API(brats_conv3d_x3_fwd)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
+                                   const float* xamax, const void* packed_w, const float* bias, void* y, int ypitch, void* y2,
+                                   int y2pitch, int ysplit, float* stats, int dtype, int dil, int N, int D, int H, int W,
+                                   int cout, brats_stream_t s) {
+  if (dtype != BRATS_X3_BF16) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_fwd: dtype must be BRATS_X3_F16 or BRATS_X3_BF16");
+  return conv_fwd_impl(x1, c1, pitch1, x2, c2, pitch2, xamax, packed_w, bias, y, ypitch, y2, y2pitch, ysplit, stats, dtype, 3, dil,
+                       N, D, H, W, cout, s);
 }
 #include "twin_end.hpp"

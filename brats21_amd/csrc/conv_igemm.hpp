@@ -25,6 +25,7 @@ struct ConvParams {
   void* y2; int y2pitch; int ysplit;  // optional second destination for output channels >= ysplit (dgrad of a concat input)
   int N, D, H, W, cout, rows16, nchunks;
   int tz, ty, tx;
+  const float* xamax;  // split-precision kernels only (conv_igemm_x3.hpp): device scalar max|x| -> input scale; NULL = 1
 #ifdef BRATS_VS8_STAMPS
   long long* stamps;  // diagnostic build only
 #endif

@@ -930,8 +930,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_f8_kernel(const Wgr
 // A block = 32 consecutive f32x4 elements x 8 split groups: thread (e, g) adds splits g, g+8, ... and the 8 partial
 // sums are combined in group order through LDS (one thread per element deep the kernel had 61 workgroups, each
 // lane walking all ~256 slabs serially).
+// amax (split precision only, else NULL): the device scalar the dY operand was scaled by (x3_scale_from_amax) -- undone here
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                           int cout, int cin, int taps) {
+                                                           int cout, int cin, int taps, const float* __restrict__ amax) {
   const size_t per = (size_t)taps * cout * cin;
   const size_t per4 = per / 4;  // cin % 4 == 0
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -957,6 +958,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   if (g == 0 && i4 < per4) {
 #pragma unroll
     for (int k = 1; k < 8; ++k) s += part[k][e];
+    if (amax) s *= x3_inv_scale(x3_scale_from_amax(*amax));
     const size_t i = i4 * 4;
     const int ci = i % cin;
     const int co = (i / cin) % cout;
@@ -973,7 +975,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // 4 M of them for a 384 x 384 layer, 54 us for 16 MB; a first all-taps form that kept the 8 split groups took 27 serial round
 // trips per block -- with 4 slabs only half of its threads had a load at all: 26 us.)  Fixed order: bitwise reproducible.
 __global__ void __launch_bounds__(256) wgrad_reduce_taps_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit,
-                                                                int cout, int cin, int taps) {
+                                                                int cout, int cin, int taps, const float* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) float red_tile[];  // [taps][128]
   const size_t per = (size_t)taps * cout * cin, pairs4 = (size_t)cout * cin / 4;
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -1006,20 +1008,22 @@ __global__ void __launch_bounds__(256) wgrad_reduce_taps_kernel(const float* __r
   // dw[(pair) * taps + tap] for the block's 128 pairs: 128 * taps consecutive floats
   const size_t pair0 = (size_t)blockIdx.x * 128, npairs = (size_t)cout * cin;
   float* dst = dw + pair0 * taps;
+  const float isc = amax ? x3_inv_scale(x3_scale_from_amax(*amax)) : 1.f;
   for (int i = threadIdx.x; i < 128 * taps; i += blockDim.x) {
     const int pr = i / taps, tap = i % taps;
-    if (pair0 + pr < npairs) dst[i] = red_tile[tap * 128 + pr];
+    if (pair0 + pr < npairs) dst[i] = red_tile[tap * 128 + pr] * isc;
   }
 }
 
-static void wgrad_reduce_launch(const float* ws, float* dw, int nsplit, int cout, int cin, int taps, hipStream_t st) {
+static void wgrad_reduce_launch(const float* ws, float* dw, int nsplit, int cout, int cin, int taps, hipStream_t st,
+                                const float* amax = nullptr) {
   const size_t per = (size_t)taps * cout * cin;
   const size_t tblocks = ((size_t)cout * cin / 4 + 31) / 32;
   if (taps > 1 && taps <= 32 && tblocks >= 256)  // enough (co, ci) pairs for a grid of all-taps blocks: coalesced stores
     hipLaunchKernelGGL(wgrad_reduce_taps_kernel, dim3((unsigned)tblocks), dim3(256), (size_t)taps * 128 * sizeof(float), st, ws, dw,
-                       nsplit, cout, cin, taps);
+                       nsplit, cout, cin, taps, amax);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per / 4 + 31) / 32)), dim3(256), 0, st, ws, dw, nsplit, cout, cin, taps);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((per / 4 + 31) / 32)), dim3(256), 0, st, ws, dw, nsplit, cout, cin, taps, amax);
 }
 
 // dbias[c] = sum_v dy[v][c]
@@ -1102,8 +1106,16 @@ extern "C" int BRATS_API(brats_conv3d_set_wgrad_alltaps)(int mode) {
   return old;
 }
 
+static size_t x3_align(size_t b);
 extern "C" size_t BRATS_API(brats_conv3d_wgrad_ws_bytes)(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout) {
   if (ksize != 3) return 0;
+  if (dtype == BRATS_X3_BF16) {
+    // split precision: three groups of 16-bit slabs + the hi / lo tensors of x1, x2 and dy (wgrad_x3)
+    const size_t vox = (size_t)N * D * H * W;
+    const size_t slab = BRATS_API(brats_conv3d_wgrad_ws_bytes)(BRATS_BF16, 3, N, D, H, W, c1, c2, cout) * 3;
+    auto sp = [&](int c) { return c > 0 ? 2 * x3_align(vox * c * 2) : (size_t)0; };
+    return x3_align(slab) + sp(c1) + sp(c2) + sp(cout);
+  }
   int cof, cif;
   wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
   const int ntiles = N * ceil_div(D, WG_TZ) * ceil_div(H, WG_TY) * ceil_div(W, WG_TX);
@@ -1136,21 +1148,10 @@ static int wgrad_dispatch(const WgradParams& p, int cof, int cif, dim3 grid, hip
   BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: unsupported tile %dx%d", cof, cif);
 }
 
-extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy,
-                                  int dypitch, float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N,
-                                  int D, int H, int W, int cout, brats_stream_t s) {
-  if (!x1 || !dy || !ws || !dw || c1 <= 0 || cout <= 0) BRATS_FAIL(BRATS_E_ARG, "wgrad: null pointer / bad size");
-  if (ksize != 3 || (dil != 1 && dil != 2)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: ksize=%d dil=%d unsupported", ksize, dil);
-  if (c2 < 0) c2 = 0;
-  if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "wgrad: c2 > 0 but x2 NULL");
-  const int epl = dtype == BRATS_BF16 ? 8 : 4;
-  if (pitch1 % epl || (c2 && pitch2 % epl) || dypitch % epl || c1 % epl || c2 % epl || cout % epl)
-    BRATS_FAIL(BRATS_E_ARG, "wgrad: channel counts / pitches must be multiples of %d", epl);
-  {  // staged pieces are addressed by 32-bit byte offsets inside one sample (buffer_load voffset)
-    const int mp = pitch1 > pitch2 ? (pitch1 > dypitch ? pitch1 : dypitch) : (pitch2 > dypitch ? pitch2 : dypitch);
-    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
-      BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
-  }
+// launches the MFMA kernel of one weight-gradient problem (16-bit or f32 operands as `dtype` says) into the split-K slabs at
+// ws; *nsplit_out = number of slabs written ([split][27][cout][cin] f32 each)
+static int wgrad_mfma(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch, float* ws,
+                      int dtype, int dil, int N, int D, int H, int W, int cout, hipStream_t st, int* nsplit_out) {
   int cof, cif;
   wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
   WgradParams p;
@@ -1165,7 +1166,6 @@ extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1,
   p.nlane = wgrad_nlane(p.ntiles);
   // ci tiles of x2 start at tile index ceil(c1/CI_T): only exact when c1 % CI_T == 0 or c2 == 0
   if (c2 > 0 && c1 % (16 * cif)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: c1=%d must be a multiple of the ci tile %d", c1, 16 * cif);
-  hipStream_t st = (hipStream_t)s;
   int g8a = 0, wide = 0;
   const bool alltaps = wgrad_alltaps_ok(dtype, dil, c1, c2, cout, p.ntiles, &g8a, &wide);
   // tap-plane kernel: slab entries of padded ci / co lanes are never written: clear the slab
@@ -1202,7 +1202,108 @@ extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1,
   } else if (dtype == BRATS_BF16) rc = dil == 1 ? wgrad_dispatch<bf16_t, 1>(p, cof, cif, grid, st) : wgrad_dispatch<bf16_t, 2>(p, cof, cif, grid, st);
   else rc = dil == 1 ? wgrad_dispatch<float, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 2>(p, cof, cif, grid, st);
   if (rc) return rc;
-  wgrad_reduce_launch((const float*)ws, dw, p.nsplit, cout, p.cin, 27, st);
+  BRATS_CHECK_LAUNCH();
+  *nsplit_out = p.nsplit;
+  return 0;
+}
+
+// ---- split precision (BRATS_X3_*): f32 X and dY, three 16-bit MFMA products -----------------------------------------
+// dW = Xhi (x) dYhi + Xhi (x) dYlo + Xlo (x) dYhi with x = hi + lo split into two 16-bit values (conv_igemm_x3.hpp has the
+// error analysis).  Unlike the forward kernel the split is NOT done while staging: the all-taps kernel fills its LDS by
+// DMA (which cannot transform data) and its hi + lo tiles (2 x 87 KB) would not fit a CU.  One streaming pass writes the
+// hi / lo tensors (dense, 16-bit) into the workspace, the UNCHANGED 16-bit kernels run three times into three groups of
+// split-K slabs, and the one fixed-order reduction sums all of them (bitwise reproducible).  Price: 12 extra bytes of HBM
+// traffic per operand element and three tile stagings instead of one.
+template <int V>
+__global__ void __launch_bounds__(256) x3_split_kernel(const float* __restrict__ src, int pitch, bf16_t* __restrict__ hi,
+                                                       bf16_t* __restrict__ lo, size_t voxels, int C, const float* __restrict__ amax) {
+  // a thread owns 8 consecutive channels of one voxel (C % 8 == 0)
+  const float sc = amax ? x3_scale_from_amax(*amax) : 1.f;
+  const int cv = C / 8;
+  const size_t total = voxels * cv;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t vox = i / cv;
+    const int c = (int)(i % cv) * 8;
+    float x[8], h[8], l[8];
+    Vec<float, 4>::load(src + vox * pitch + c, x);
+    Vec<float, 4>::load(src + vox * pitch + c + 4, x + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x[e] *= sc;
+      h[e] = bf2f(f2bf(x[e]));
+      l[e] = x[e] - h[e];
+    }
+    Vec<bf16_t, 8>::store(hi + vox * C + c, h);
+    Vec<bf16_t, 8>::store(lo + vox * C + c, l);
+  }
+}
+static size_t x3_align(size_t b) { return (b + 255) / 256 * 256; }
+static size_t wgrad_x3_split_bytes(size_t voxels, int c) { return c > 0 ? x3_align(voxels * c * 2) : 0; }  // one of hi / lo
+
+static int wgrad_x3(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch,
+                    const float* amax_dy, float* ws, float* dw, size_t slab_bytes, int dil, int N, int D, int H, int W, int cout,
+                    hipStream_t st) {
+  const size_t vox = (size_t)N * D * H * W;
+  char* b = (char*)ws + x3_align(slab_bytes);
+  bf16_t* h1 = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, c1);
+  bf16_t* l1 = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, c1);
+  bf16_t* h2 = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, c2);
+  bf16_t* l2 = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, c2);
+  bf16_t* hy = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, cout);
+  bf16_t* ly = (bf16_t*)b;
+  auto split = [&](const void* src, int pitch, bf16_t* hi, bf16_t* lo, int c, const float* amax) {
+    const size_t total = vox * (c / 8);
+    const unsigned blocks = (unsigned)(total / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(x3_split_kernel<0>, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const float*)src, pitch, hi, lo, vox, c, amax);
+  };
+  split(x1, pitch1, h1, l1, c1, nullptr);
+  if (c2 > 0) split(x2, pitch2, h2, l2, c2, nullptr);
+  split(dy, dypitch, hy, ly, cout, amax_dy);  // (dY * 2^k: undone by the reduction)
+  BRATS_CHECK_LAUNCH();
+  int ns = 0, total = 0;
+  const size_t per = (size_t)27 * cout * (c1 + c2);
+  // (small terms first: the reduction adds the slabs in this order)
+  int rc = wgrad_mfma(l1, c1, c1, c2 > 0 ? l2 : nullptr, c2, c2, hy, cout, ws, BRATS_BF16, dil, N, D, H, W, cout, st, &ns);
+  if (rc) return rc;
+  total += ns;
+  rc = wgrad_mfma(h1, c1, c1, c2 > 0 ? h2 : nullptr, c2, c2, ly, cout, ws + (size_t)total * per, BRATS_BF16, dil, N, D, H, W, cout, st, &ns);
+  if (rc) return rc;
+  total += ns;
+  rc = wgrad_mfma(h1, c1, c1, c2 > 0 ? h2 : nullptr, c2, c2, hy, cout, ws + (size_t)total * per, BRATS_BF16, dil, N, D, H, W, cout, st, &ns);
+  if (rc) return rc;
+  total += ns;
+  wgrad_reduce_launch((const float*)ws, dw, total, cout, c1 + c2, 27, st, amax_dy);
+  return 0;
+}
+
+static int wgrad_impl(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch,
+                      const float* amax_dy, float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N, int D, int H,
+                      int W, int cout, brats_stream_t s) {
+  if (!x1 || !dy || !ws || !dw || c1 <= 0 || cout <= 0) BRATS_FAIL(BRATS_E_ARG, "wgrad: null pointer / bad size");
+  if (ksize != 3 || (dil != 1 && dil != 2)) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: ksize=%d dil=%d unsupported", ksize, dil);
+  if (c2 < 0) c2 = 0;
+  if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "wgrad: c2 > 0 but x2 NULL");
+  const bool x3 = dtype == BRATS_X3_BF16;
+  const int epl = dtype == BRATS_BF16 ? 8 : 4;
+  if (pitch1 % epl || (c2 && pitch2 % epl) || dypitch % epl || c1 % epl || c2 % epl || cout % epl)
+    BRATS_FAIL(BRATS_E_ARG, "wgrad: channel counts / pitches must be multiples of %d", epl);
+  if (x3 && (c1 % 8 || c2 % 8 || cout % 8)) BRATS_FAIL(BRATS_E_ARG, "wgrad (split precision): channel counts must be multiples of 8");
+  {  // staged pieces are addressed by 32-bit byte offsets inside one sample (buffer_load voffset)
+    const int mp = pitch1 > pitch2 ? (pitch1 > dypitch ? pitch1 : dypitch) : (pitch2 > dypitch ? pitch2 : dypitch);
+    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
+  }
+  hipStream_t st = (hipStream_t)s;
+  if (x3) {
+    const size_t slab = BRATS_API(brats_conv3d_wgrad_ws_bytes)(BRATS_BF16, 3, N, D, H, W, c1, c2, cout) * 3;
+    const int rc = wgrad_x3(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, amax_dy, ws, dw, slab, dil, N, D, H, W, cout, st);
+    if (rc) return rc;
+  } else {
+    int nsplit = 0;
+    const int rc = wgrad_mfma(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, ws, dtype, dil, N, D, H, W, cout, st, &nsplit);
+    if (rc) return rc;
+    wgrad_reduce_launch((const float*)ws, dw, nsplit, cout, c1 + c2, 27, st);
+  }
   if (dbias) {
     const size_t vox = (size_t)N * D * H * W;
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
@@ -1210,6 +1311,18 @@ extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1,
   }
   BRATS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int BRATS_API(brats_conv3d_wgrad)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy,
+                                  int dypitch, float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N,
+                                  int D, int H, int W, int cout, brats_stream_t s) {
+  return wgrad_impl(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, nullptr, ws, dw, dbias, dtype, ksize, dil, N, D, H, W, cout, s);
+}
+extern "C" int BRATS_API(brats_conv3d_x3_wgrad)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy,
+                                     int dypitch, const float* amax_dy, float* ws, float* dw, float* dbias, int dtype, int dil,
+                                     int N, int D, int H, int W, int cout, brats_stream_t s) {
+  if (dtype != BRATS_X3_BF16) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_wgrad: dtype must be BRATS_X3_F16 or BRATS_X3_BF16");
+  return wgrad_impl(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, amax_dy, ws, dw, dbias, dtype, 3, dil, N, D, H, W, cout, s);
 }
 
 // ---- shifted-tap form: 1x1x1 convolutions, and 3x3x3 convolutions at any dilation (ASPP d = 4, 6) ------------------

@@ -172,7 +172,9 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     ax, ax2 = getattr(x, "_amax", None), (getattr(x2, "_amax", None) if x2 is not None else None)
     w8 = (all8 and unit.dilation == 1 and ax is not None and (x2 is None or ax2 is not None) and ops.is16(y.dtype)
           and ops.conv3d_wgrad_f8_ok(x, y, x2))
-    amax = slots.take() if ((f8 or w8) and slots is not None) else None
+    # split precision on fp16 pairs: dy (values of 1e-6 and below) is scaled by a power of two taken from its recorded |max|
+    x3s = ops.x3_mode() == ops.X3F and dtype == torch.float32
+    amax = slots.take() if ((f8 or w8 or x3s) and slots is not None) else None
     kact, slope_t = _unit_act(unit, act)
     if slope_t is not None:
         grads[names[unit.prelu.weight]] = ops.prelu_slope_grad(dz, y, scale_shift)
@@ -204,9 +206,9 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         if w8 and amax is not None:
             dw = ops.conv3d_wgrad_f8(x, dy, ax, amax, x2=x2, amax2=ax2, out=wdst)
         elif x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
-            dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation)
+            dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation, amax_dy=amax if x3s else None)
         else:
-            dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2, out=wdst)
+            dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2, out=wdst, amax_dy=amax if x3s else None)
         dw = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
         on_side(dw)
     grads[names[unit.conv.weight]] = dw
@@ -226,7 +228,7 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
 
         def dgrad(**kw):
-            return ops.conv3d(dy, wpk, cin, 3, unit.dilation, **kw)
+            return ops.conv3d(dy, wpk, cin, 3, unit.dilation, amax=amax if x3s else None, **kw)
     if x2 is None:
         dx, _ = dgrad()
         return dx
@@ -243,12 +245,13 @@ class _EquiUnetFn(torch.autograd.Function):
     def forward(ctx, model, x, dtype, *params):
         # training: the module packed all layers' weights up front (ops.plan_for); pack_weights() then returns views
         ctx.plan = ops._PLANS.get(model) if (model.training and model.pack_plan) else None
-        with ops.use_plan(ctx.plan):
+        ctx.x3 = model._x3_modes() if dtype == torch.float32 else (None, None)
+        with ops.use_plan(ctx.plan), ops.split_precision(ctx.x3[0]):
             return _EquiUnetFn._forward(ctx, model, x, dtype, *params)
 
     @staticmethod
     def backward(ctx, *douts):
-        with ops.use_plan(ctx.plan):
+        with ops.use_plan(ctx.plan), ops.split_precision(ctx.x3[1]):
             return _EquiUnetFn._backward(ctx, *douts)
 
     @staticmethod
@@ -274,7 +277,7 @@ class _EquiUnetFn(torch.autograd.Function):
         def up(t):
             return _inherit_amax(ops.upsample(t, 2), t)
 
-        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if ops.is16(dtype) else 4)
+        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if (ops.is16(dtype) or ops.x3_active()) else 4)
         # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
         # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
         # (the last layer of a level writes its activation -- the skip connection -- and the max-pooled tensor in one pass)
@@ -326,7 +329,7 @@ class _EquiUnetFn(torch.autograd.Function):
         rec = {r[0]: r for r in tape}
 
         fp8 = m.conv_fp8 if ops.is16(dtype) else None
-        slots = _AmaxSlots(32, douts[0].device) if fp8 == "all" else None
+        slots = _AmaxSlots(32, douts[0].device) if (fp8 == "all" or ops.x3_mode() == ops.X3F) else None
 
         # weight gradients on a side stream (model.wgrad_stream); with gradient buckets they stay on the main stream: the
         # buckets' copies and collectives are ordered against it
@@ -460,11 +463,25 @@ class EquiUnet(_PackedWeightsModule):
             return torch.bfloat16
         if self.precision == "fp16":
             return torch.float16
-        if self.precision == "fp32":
+        if self.precision in ("fp32", "x3", "fp16x3", "bf16x3", "x3fwd", "x3bwd"):
             return torch.float32
         if torch.is_autocast_enabled():  # the reference's switch (learning/engine.py:304): its autocast dtype is fp16
             return torch.float16 if torch.get_autocast_dtype("cuda") == torch.float16 else torch.bfloat16
         return torch.float32
+
+    def _x3_modes(self):
+        """(forward, backward) split of the 3x3x3 convolutions when the activations are f32 (ops.split_precision):
+        precision "x3" (= "fp16x3") = fp16 pairs (f32-class: 2^-22 per product) forward AND backward -- dY, whose values lie far
+        below fp16's range, is scaled by a power of two from the |max| its producer kernel records (brats_conv3d_x3_fwd /
+        _x3_wgrad; the reference needs a GradScaler for the same reason); "bf16x3" = bf16 pairs everywhere (2^-16 per product:
+        logits ~5e-4, gradients ~5e-3 from f64 -- measured, tests/test_x3_gpu.py); anything else = the exact-f32 MFMA kernels."""
+        if self.precision in ("x3", "fp16x3"):
+            return ops.X3F, ops.X3F
+        if self.precision == "bf16x3":
+            return ops.X3B, ops.X3B
+        if self.precision in ("x3fwd", "x3bwd"):  # (diagnostic: one pass split, the other exact f32)
+            return (ops.X3F, None) if self.precision == "x3fwd" else (None, ops.X3F)
+        return None, None
 
     def forward(self, x):
         if not x.is_cuda:

@@ -82,12 +82,14 @@ class _Ctx:
         # e4m3 convolutions (EquiUnet.conv_fp8 semantics): the EvoNorm / SE kernels record the |max| of what they write
         # into slots taken here; a tensor without a recorded |max| falls back to ops.absmax inside ops.conv3d_f8
         self.fp8 = getattr(model, "conv_fp8", None) if ops.is16(dtype) else None
+        # split precision on fp16 pairs (backward): dy is scaled by a power of two from its recorded |max| (EquiUnet._x3_modes)
+        self.x3s = ops.x3_mode() == ops.X3F and dtype == torch.float32
         self.slots = None
         self.names = {p: i for i, p in enumerate(model.parameters())}
         self.grads = {}
 
-    def slot(self, device):
-        if not self.fp8:
+    def slot(self, device, force=False):
+        if not self.fp8 and not force:
             return None
         if self.slots is None or self.slots.i >= self.slots.buf.numel():
             self.slots = _AmaxSlots(64, device)
@@ -125,6 +127,8 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
     if db is None:
         db = ops.channel_dot(dy).sum(0)
+    if cx.x3s and k == 3 and getattr(dy, "_amax", None) is None:
+        dy._amax = ops.absmax(dy)  # (a producer that records no |max|: one extra pass)
     if k == 1:
         dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1, out=cx.dest(conv.weight))  # a GEMM over the voxels: shifted-tap kernel, 1 tap
         cx.put(conv.weight, dw)
@@ -133,7 +137,7 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
         if cx.fp8 == "all" and dil == 1 and ax is not None and ady is not None and ops.conv3d_wgrad_f8_ok(xin, dy):
             dw = ops.conv3d_wgrad_f8(xin, dy, ax, ady, out=cx.dest(conv.weight))  # e4m3 operands, scales from the recorded |max|
         else:
-            dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil, out=cx.dest(conv.weight))
+            dw, _ = ops.conv3d_wgrad(xin, dy, 3, dil, out=cx.dest(conv.weight), amax_dy=ady if cx.x3s else None)
         cx.put(conv.weight, dw[:, :cin].contiguous() if dw.shape[1] != cin else dw)
     cx.put(conv.bias, db)
     if not need_dx:
@@ -141,7 +145,8 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     if cx.fp8 == "all" and k == 3 and ops.conv_f8_chunk(cout) > 0:
         dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil, amax=getattr(dy, "_amax", None))
         return dx
-    dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil)
+    dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil,
+                       amax=getattr(dy, "_amax", None) if (cx.x3s and k == 3) else None)
     return dx
 
 
@@ -201,7 +206,7 @@ def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
 
 def _conv_evo_bwd(cx, rec, dz, need_dx=True, gscale=None, gadd=None):
     conv, evo, saved, y, mr, chan = rec
-    amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
+    amax = cx.slot(y.device, cx.x3s) if (cx.fp8 == "all" or cx.x3s) else None  # scale source of the e4m3 / fp16-pair gradients
     dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax, gscale=gscale, gadd=gadd)
     if amax is not None:
         dy._amax = amax
@@ -245,7 +250,7 @@ def _block_bwd(cx, rec, do, need_dx=True, head=None, pool=None):
     # one call: pass 1 of the EvoNorm backward over (do, y) also yields d loss / d gate = sum_v do * z2 (linear in its sums),
     # the SE backward runs on those, pass 2 reads the gradient as do * (1 + gate) + dgap / V  (csrc/se.hpp)
     conv, evo, saved, y, mr, chan = r2
-    amax = cx.slot(y.device) if cx.fp8 == "all" else None  # scale source of the e4m3 input AND weight gradients
+    amax = cx.slot(y.device, cx.x3s) if (cx.fp8 == "all" or cx.x3s) else None  # scale source of the e4m3 / fp16-pair gradients
     res = ops.evonorm_se_bwd(do, y, mr, _flat(evo.gamma), _flat(evo.beta), cs, hidden, gate1p, fc1.weight, fc2.weight, 8, chan=chan,
                              amax=amax, head=(head[0].weight, head[1]) if head is not None else None, pool=pool)
     dy, dgamma, dbeta, dcb, dw1, db1, dw2, db2 = res[:8]
@@ -265,12 +270,13 @@ class _AsspFn(torch.autograd.Function):
     def forward(ctx, model, x, dtype, *params):
         # training: the module packed all layers' weights up front (ops.plan_for); pack_weights() then returns views
         ctx.plan = ops._PLANS.get(model) if (model.training and model.pack_plan) else None
-        with ops.use_plan(ctx.plan):
+        ctx.x3 = model._x3_modes() if dtype == torch.float32 else (None, None)
+        with ops.use_plan(ctx.plan), ops.split_precision(ctx.x3[0]):
             return _AsspFn._forward(ctx, model, x, dtype, *params)
 
     @staticmethod
     def backward(ctx, *douts):
-        with ops.use_plan(ctx.plan):
+        with ops.use_plan(ctx.plan), ops.split_precision(ctx.x3[1]):
             return _AsspFn._backward(ctx, *douts)
 
     @staticmethod
@@ -281,7 +287,7 @@ class _AsspFn(torch.autograd.Function):
         n, _, d, h, w = x.shape
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
-        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if ops.is16(dtype) else 4)
+        x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if (ops.is16(dtype) or ops.x3_active()) else 4)
         will_bwd = any(ctx.needs_input_grad)
 
         def pool(t):  # max and average of a 2x2x2 cell never exceed the |max| of the input
@@ -346,6 +352,7 @@ class _AsspFn(torch.autograd.Function):
     def _backward(ctx, *douts):
         cx, R = ctx.cx, ctx.recs
         m = cx.m
+        cx.x3s = ops.x3_mode() == ops.X3F and cx.dtype == torch.float32  # (the BACKWARD split decides about the dy scales)
         f = m.features
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
         down1, down2, down3, up3, up2, up1 = ctx.bufs
@@ -449,11 +456,22 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
             return torch.bfloat16
         if self.precision == "fp16":
             return torch.float16
-        if self.precision == "fp32":
+        if self.precision in ("fp32", "x3", "fp16x3", "bf16x3", "x3fwd", "x3bwd"):
             return torch.float32
         if torch.is_autocast_enabled():  # the reference's switch (learning/engine.py:304): its autocast dtype is fp16
             return torch.float16 if torch.get_autocast_dtype("cuda") == torch.float16 else torch.bfloat16
         return torch.float32
+
+    def _x3_modes(self):
+        """(forward, backward) split of the 3x3x3 convolutions when the activations are f32 (ops.split_precision):
+        see EquiUnet._x3_modes."""
+        if self.precision in ("x3", "fp16x3"):
+            return ops.X3F, ops.X3F
+        if self.precision == "bf16x3":
+            return ops.X3B, ops.X3B
+        if self.precision in ("x3fwd", "x3bwd"):  # (diagnostic: one pass split, the other exact f32)
+            return (ops.X3F, None) if self.precision == "x3fwd" else (None, ops.X3F)
+        return None, None
 
     def forward(self, x):
         if not x.is_cuda:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F16, F32, PACK_DGRAD, PACK_FWD  # noqa: F401
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, BF16, F16, F32, PACK_DGRAD, PACK_FWD, X3_BF16, X3_F16  # noqa: F401
 
 ACTS = {"none": ACT_NONE, "relu": ACT_RELU, "leakyrelu": ACT_LEAKY, "elu": _lib.ACT_ELU, "swish": _lib.ACT_SWISH,
         "mish": _lib.ACT_MISH}
@@ -106,7 +106,47 @@ def side_stream(side, *inputs):
             t.record_stream(side)
 
 
+# ---- split precision ("x3"): f32 tensors, 3x3x3 convolutions on three 16-bit MFMA products (csrc/conv_igemm_x3.hpp) ----
+X3F = "x3_f16"    # operands split into fp16 pairs: f32-class products inside fp16's range (the forward pass)
+X3B = "x3_bf16"   # ... into bf16 pairs: 2^-16 per product over f32's whole range (the gradients)
+_X3 = None        # the split the 3x3x3 convolutions of f32 tensors use inside a split_precision() block; None = exact f32
+
+
+@contextlib.contextmanager
+def split_precision(mode):
+    """Inside the block conv3d / conv3d_wgrad / pack_weights run f32 tensors' 3x3x3 convolutions on the split-precision
+    kernels (mode = ops.X3F or ops.X3B; None = the exact-f32 MFMA kernels).  The network programs open it around their
+    forward (X3F) and backward (X3B) when model.precision = "x3"."""
+    global _X3
+    if mode not in (None, X3F, X3B):
+        raise _lib.BratsHipError(f"split_precision: unknown mode {mode!r}")
+    old, _X3 = _X3, mode
+    try:
+        yield
+    finally:
+        _X3 = old
+
+
+def x3_active():
+    return _X3 is not None
+
+
+def x3_mode():
+    return _X3
+
+
+def _conv_dtype(dtype, ksize):
+    """The kernel family a convolution of `dtype` tensors runs on: the dtype itself, or the active split mode."""
+    if _X3 is not None and dtype == torch.float32 and ksize == 3:
+        return _X3
+    return dtype
+
+
 def _code(dtype):
+    if dtype == X3F:
+        return X3_F16
+    if dtype == X3B:
+        return X3_BF16
     if dtype == torch.bfloat16:
         return BF16
     if dtype == torch.float32:
@@ -269,12 +309,13 @@ class PackPlan:
             code = _code(dtype)
             nbytes = _lib.lib().brats_conv3d_packed_bytes(code, k, kdim, rows, ck)
             rows16 = (rows + 15) // 16
-            ms_n = nbytes // ((kdim // ck) * rows16 * 1024)
-            total = nbytes // (2 if code in (BF16, F16) else 4)
+            x3 = code in (X3_BF16, X3_F16)  # (hi and lo fragments side by side)
+            ms_n = nbytes // ((kdim // ck) * rows16 * (2048 if x3 else 1024))
+            total = nbytes // (4 if code == F32 else 2)
             entries[key] = [wref, w.data_ptr(), off, nbytes, -1]
-            fl = code == F16
-            jobs[fl].append((w.data_ptr(), off, BF16 if fl else code, mode, k ** 3, cin_w, cin_real, cin_off, rows, rows16, kdim, ck,
-                             ms_n, 0, total))
+            fl = code in (F16, X3_F16)
+            jobs[fl].append((w.data_ptr(), off, {F16: BF16, X3_F16: X3_BF16}.get(code, code), mode, k ** 3, cin_w, cin_real, cin_off,
+                             rows, rows16, kdim, ck, ms_n, 0, total))
             j = len(jobs[fl]) - 1
             blocks[fl].extend((j, b) for b in range((total + pb - 1) // pb))
             off += (nbytes + 255) // 256 * 256
@@ -348,6 +389,7 @@ def pack_weights(w, dtype, mode, cin_pad=None, cin_off=0, cin_cnt=None, dil=1, c
     (``invalidate_packed_weights``: every training forward and train()/eval() switch of the modules -- that covers
     optimizers that write through ``p.data``, like the reference's Ranger2020)."""
     key = None
+    dtype = _conv_dtype(dtype, w.shape[2])
     if ACTIVE_PLAN is not None:
         pkey = (id(w), str(dtype), mode, cin_pad, cin_off, cin_cnt, dil, c1)
         v = ACTIVE_PLAN.lookup(pkey, w)
@@ -409,11 +451,13 @@ def tiles_per_sample(d, h, w):
     return _lib.lib().brats_conv3d_tiles_per_sample(d, h, w)
 
 
-def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False, x2=None, split=None):
+def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False, x2=None, split=None, amax=None):
     """y[N,D,H,W,cout] = conv([x | x2]) with weights from pack_weights().  Returns (y, stats|None) where
     stats = [N, tiles, cout, 2] per-tile per-channel (sum, sum of squares) of the f32 result.
     x2: optional second input (virtual concat, no torch.cat).  split: write output channels
-    [0, split) and [split, cout) to two dense tensors (returns (y, y2) as y)."""
+    [0, split) and [split, cout) to two dense tensors (returns (y, y2) as y).
+    amax (split precision only): 1-element f32 device tensor holding max|x| -- the input is scaled into fp16's range by the
+    matching power of two and the result scaled back (brats_conv3d_x3_fwd: the input gradient, whose x = dY is tiny)."""
     ptr, c, p = _desc(x)
     n, d, h, w, _ = x.shape
     ptr2, c2, p2 = (None, 0, 0)
@@ -431,11 +475,20 @@ def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=Fa
     stats = None
     if want_stats:
         stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
-    with _span("conv_igemm", c + c2, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+    kd = _conv_dtype(x.dtype, ksize)  # (split precision: f32 tensors, weights packed under the same mode)
+    if amax is not None and kd in (X3F, X3B):
+        with _span("conv_igemm", c + c2, cout, ksize, dil, n, d, h, w, str(kd)):
+            _lib.check(_lib.lib().brats_conv3d_x3_fwd(ptr, c, p, ptr2, c2, p2, _f32(amax), packed_w.data_ptr(), _f32(bias), optr, op,
+                                                      y2.data_ptr() if y2 is not None else None,
+                                                      (cout - split) if y2 is not None else 0, split or 0,
+                                                      stats.data_ptr() if stats is not None else None, _code(kd), dil, n, d, h, w,
+                                                      cout, _stream()), "conv3d_x3_fwd")
+        return ((out, y2) if y2 is not None else out), stats
+    with _span("conv_igemm", c + c2, cout, ksize, dil, n, d, h, w, str(kd)):
         _lib.check(_lib.lib().brats_conv3d_fwd(ptr, c, p, ptr2, c2, p2, packed_w.data_ptr(), _f32(bias), optr, op,
                                                y2.data_ptr() if y2 is not None else None,
                                                (cout - split) if y2 is not None else 0, split or 0,
-                                               stats.data_ptr() if stats is not None else None, _code(x.dtype), ksize,
+                                               stats.data_ptr() if stats is not None else None, _code(kd), ksize,
                                                dil, n, d, h, w, cout, _stream()), "conv3d_fwd")
     return ((out, y2) if y2 is not None else out), stats
 
@@ -536,20 +589,30 @@ def _grad_out(out, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None, out=None):
-    """dW [cout, cin (+cin2), k,k,k] f32 (and dbias) from the layer input [x | x2] and the output gradient dy."""
+def conv3d_wgrad(x, dy, ksize=3, dil=1, want_dbias=False, x2=None, out=None, amax_dy=None):
+    """dW [cout, cin (+cin2), k,k,k] f32 (and dbias) from the layer input [x | x2] and the output gradient dy.
+    amax_dy (split precision only): 1-element f32 device tensor holding max|dy| (see conv3d's amax)."""
     ptr, c, p = _desc(x)
     ptr2, c2, p2 = (None, 0, 0)
     if x2 is not None:
         ptr2, c2, p2 = _desc(x2)
     dptr, cout, dp = _desc(dy)
     n, d, h, w, _ = x.shape
-    code = _code(x.dtype)
+    kd = _conv_dtype(x.dtype, ksize)
+    if kd in (X3F, X3B) and (c % 8 or c2 % 8 or cout % 8):
+        kd = x.dtype  # (narrow test widths: the 16-bit kernels behind the split form want multiples of 8 channels)
+    code = _code(kd)
     nbytes = _lib.lib().brats_conv3d_wgrad_ws_bytes(code, ksize, n, d, h, w, c, c2, cout)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
     dw = _grad_out(out, (cout, c + c2, ksize, ksize, ksize), x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
-    with _span("conv_wgrad", c + c2, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+    if amax_dy is not None and kd in (X3F, X3B):
+        with _span("conv_wgrad", c + c2, cout, ksize, dil, n, d, h, w, str(kd)):
+            _lib.check(_lib.lib().brats_conv3d_x3_wgrad(ptr, c, p, ptr2, c2, p2, dptr, dp, _f32(amax_dy), ws.data_ptr(), dw.data_ptr(),
+                                                        db.data_ptr() if db is not None else None, code, dil, n, d, h, w, cout,
+                                                        _stream()), "conv3d_x3_wgrad")
+        return dw, db
+    with _span("conv_wgrad", c + c2, cout, ksize, dil, n, d, h, w, str(kd)):
         _lib.check(_lib.lib().brats_conv3d_wgrad(ptr, c, p, ptr2, c2, p2, dptr, dp, ws.data_ptr(), dw.data_ptr(),
                                                  db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
                                                  cout, _stream()), "conv3d_wgrad")

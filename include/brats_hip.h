@@ -17,6 +17,13 @@
  *     Statistics / gradients of parameters are always f32.  Every entry point with a `dtype`
  *     argument accepts all three; the few that move 16-bit data WITHOUT a dtype argument exist
  *     twice: brats_x (bf16) and brats_x_f16.
+ *     BRATS_X3_F16 = 4 / BRATS_X3_BF16 = 3 ("split precision"; accepted by the 3x3x3 convolution entry points
+ *     brats_conv3d_chunk / _packed_bytes / _pack_weights(_multi) / _fwd / _wgrad(_ws_bytes) only): activations are F32
+ *     tensors in HBM, each operand is split on its way into the MFMA as x = hi + lo (two fp16 / bf16 values) and the
+ *     product taken as hi*hi + lo*hi + hi*lo on the 16-bit MFMA with f32 accumulation -- f32-class results (fp16 split:
+ *     per-product error 2^-22, operands must lie inside fp16's range: the forward pass; bf16 split: 2^-16 over f32's
+ *     whole range: the gradients) at 3/16 of the exact-f32 MFMA's cost.  The 1e-3-logit parity configuration at usable
+ *     speed (model.precision = "x3").
  *   - every pointer is a DEVICE pointer owned by the caller (incl. workspaces); the library never
  *     allocates, never synchronises, launches only on the stream passed in (graph-capturable).
  *   - return 0 on success; <0 = BRATS_E_* (message via brats_last_error()).  Never throws.
@@ -33,14 +40,14 @@ extern "C" {
 
 typedef void* brats_stream_t; /* hipStream_t */
 
-enum { BRATS_F32 = 0, BRATS_BF16 = 1, BRATS_F16 = 2 };
+enum { BRATS_F32 = 0, BRATS_BF16 = 1, BRATS_F16 = 2, BRATS_X3_BF16 = 3, BRATS_X3_F16 = 4 };
 enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
 /* --act of the reference (src/arguments_train.py:49-50; MONAI Act factory): relu, leakyrelu(slope), elu(alpha=1),
  * swish = x*sigmoid(x), mish = x*tanh(softplus(x)).  prelu = BRATS_ACT_LEAKY with the learnable slope read from device
  * memory (`slope_dev` of brats_affine_act / brats_gn_bwd_apply) + brats_prelu_slope_grad for its gradient. */
 enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_ELU = 3, BRATS_ACT_SWISH = 4, BRATS_ACT_MISH = 5 };
 
-int brats_abi_version(void); /* 2 since round 3: a changed signature (brats_maxpool2_fwd) bumps it */
+int brats_abi_version(void); /* 2 since round 3: a changed signature (brats_maxpool2_fwd) bumps it; 3 in round 4 (additions only) */
 const char* brats_last_error(void);
 
 /* ---- layout ---------------------------------------------------------------------------------
@@ -103,6 +110,15 @@ int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2,
                      void* y2, int y2pitch, int ysplit, float* stats,
                      int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                      brats_stream_t s);
+/* Split-precision form with an input scale (dtype BRATS_X3_F16 / BRATS_X3_BF16 only; 3x3x3): `xamax` (may be NULL = no
+ * scaling) is a device scalar holding max|x| of the input -- written by the kernel that produced the tensor
+ * (brats_gn_bwd_apply & co., brats_absmax).  The input is multiplied by the power of two that puts |max| into [2^14, 2^15)
+ * before it is split into 16-bit pairs and the result by its inverse (both exact): this is how the INPUT GRADIENT
+ * (weights packed BRATS_PACK_DGRAD, x = dY, values of 1e-6 and below) keeps f32-class accuracy on fp16 pairs, where the
+ * reference needs a GradScaler (learning/engine.py:117-122).  Same nn.Conv3d call sites as brats_conv3d_fwd. */
+int brats_conv3d_x3_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const float* xamax,
+                        const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch, int ysplit,
+                        float* stats, int dtype, int dil, int N, int D, int H, int W, int cout, brats_stream_t s);
 /* ---- fp8 (OCP e4m3) variant of the 3x3x3 convolution (BASELINE.json configs[4], "fp8 MFMA conv path"): bf16 NDHWC
  * activations in and out; the input is quantised to e4m3 while it is staged (x / 2^e, round-to-nearest-even, e chosen
  * from the tensor's |max| so that it lands in [128, 256)), the weights are packed as e4m3 with one power-of-two scale
@@ -137,6 +153,12 @@ int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c
                        const void* dy, int dypitch, float* ws, float* dw, float* dbias,
                        int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                        brats_stream_t s);
+/* Split-precision weight gradient with a scale for dY (dtype BRATS_X3_F16 / BRATS_X3_BF16; `amax_dy` = device scalar
+ * max|dy|, may be NULL): dY * 2^k is split into 16-bit pairs, dw is multiplied by 2^-k in the slab reduction.  Workspace:
+ * brats_conv3d_wgrad_ws_bytes(dtype, 3, ...). */
+int brats_conv3d_x3_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch,
+                          const float* amax_dy, float* ws, float* dw, float* dbias, int dtype, int dil, int N, int D, int H,
+                          int W, int cout, brats_stream_t s);
 /* e4m3 weight gradient (BASELINE.json configs[4]; model.conv_fp8 = "all"): X and dY (bf16 in HBM) are quantised to e4m3
  * while they are staged (power-of-two scales from their |max|, the device scalars amax*: as brats_conv3d_f8_fwd; one
  * scale for [x1 | x2]), the MMA is v_mfma_scale_f32_16x16x128_f8f6f4, dw is f32.  Built as the all-taps kernel only

@@ -1,0 +1,247 @@
+"""-m gpu: the split-precision ("x3") convolution path -- f32 tensors, every operand split into a 16-bit hi + lo pair, three
+16-bit MFMA products per pair (csrc/conv_igemm_x3.hpp, wgrad_x3 in csrc/conv_wgrad.hip) -- against float64 references.
+
+Bars (stated where they are asserted): the fp16 split (forward) must be f32-class -- its error is measured beside the
+exact-f32 MFMA kernel's on the same problem and may not exceed it by more than a small factor; the bf16 split (gradients)
+must hold 2^-16-class relative error.  Network level: model.precision = "x3" against the reference goldens and the CPU
+oracle at the north-star bar (logits 1e-3 abs), gradients against the f64 oracle within 1e-3 relative.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth, unet
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+LOGIT_ATOL = 1e-3
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _nd(x):  # CPU NCDHW f32 -> device NDHWC f32
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+
+
+def _nc(t):
+    return t.double().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _relmax(a, ref):
+    return float((a - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize("cin,cin2,cout,dil,size", [
+    (8, 0, 48, 1, (8, 8, 16)),      # first layer (input padded 4 -> 8), CK = 8, y-split roles
+    (24, 0, 24, 1, (8, 12, 16)),    # EquiUnetASSPEvo-48 half widths: CK = 24, NF = 2 (padded cout fragments)
+    (48, 0, 48, 1, (8, 16, 16)),    # the dominant layer's channel roles: 2 chunks of 24, NF = 3 y-split
+    (48, 48, 48, 1, (8, 8, 16)),    # decoder: two sources
+    (48, 0, 96, 1, (8, 8, 32)),     # cout-half roles (NF = 3, 8 x-rows per wave)
+    (96, 0, 96, 2, (8, 8, 16)),     # dilation 2 (bottom block)
+    (32, 0, 64, 1, (5, 6, 7)),      # ragged volume, CK = 16, NF = 2 cout-half roles
+    (16, 0, 16, 1, (4, 4, 4)),      # tile larger than the volume, NF = 1
+])
+def test_conv3d_x3_fwd_dgrad_wgrad_vs_f64(cin, cin2, cout, dil, size):
+    from brats21_amd import ops
+    n = 2
+    ct = cin + cin2
+    x = _rand((n, ct, *size), 1)
+    w = _rand((cout, ct, 3, 3, 3), 2, (2.0 / (ct * 27)) ** 0.5)
+    dy = _rand((n, cout, *size), 3) * 1e-4  # (gradient-sized values: far below fp16's normal range after two layers)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, None, 1, dil, dil)
+    y_ref.backward(dy.double())
+    y_ref = y_ref.detach()
+    xd1, xd2 = _nd(x[:, :cin]), (_nd(x[:, cin:]) if cin2 else None)
+    wd, dyd = w.to(DEV), _nd(dy)
+    c1 = cin if cin2 else None
+
+    def run(mode):
+        amax = ops.absmax(dyd) if mode is not None else None  # (the network takes it from the kernel that produced dy)
+        with ops.split_precision(mode):
+            wpk = ops.pack_weights(wd, torch.float32, ops.PACK_FWD, dil=dil, c1=c1)
+            y, stats = ops.conv3d(xd1, wpk, cout, 3, dil, want_stats=True, x2=xd2)
+            wpd = ops.pack_weights(wd, torch.float32, ops.PACK_DGRAD, dil=dil)
+            if cin2 and cin % ops.split_granule(ct) == 0:
+                (d1, d2), _ = ops.conv3d(dyd, wpd, ct, 3, dil, split=cin, amax=amax)
+                dx = torch.cat([d1, d2], -1)
+            else:
+                dx, _ = ops.conv3d(dyd, wpd, ct, 3, dil, amax=amax)
+            dw, _ = ops.conv3d_wgrad(xd1, dyd, 3, dil, x2=xd2, amax_dy=amax)
+        torch.cuda.synchronize()
+        return _nc(y), stats.double().sum(1).cpu(), _nc(dx), dw.double().cpu()
+
+    exact = run(None)
+    refs = (y_ref, None, xr.grad, wr.grad)
+    # fp16 pairs (dy ~ 1e-4 scaled into fp16's range by the power of two its |max| gives): f32-class in all three, i.e. within
+    # a small factor of the exact-f32 MFMA kernel's own error; bf16 pairs: 2^-16-class
+    for mode, bars in ((ops.X3F, (4.0, 3e-6)), (ops.X3B, (None, 6e-5))):
+        got = run(mode)
+        for name, i in (("fwd", 0), ("dgrad", 2), ("wgrad", 3)):
+            e, e0 = _relmax(got[i], refs[i]), _relmax(exact[i], refs[i])
+            print(f"{mode} {name}: rel-to-max err {e:.2e} (exact-f32 MFMA kernel: {e0:.2e})")
+            assert e < bars[1], (mode, name, e)
+            if bars[0] is not None:
+                assert e < bars[0] * max(e0, 3e-7), (mode, name, e, e0)
+        # tile statistics = sums over the kernel's own f32 outputs
+        s = got[1]
+        torch.testing.assert_close(s[..., 0], got[0].sum((2, 3, 4)), atol=1e-3 * y_ref[0, 0].numel() ** 0.5, rtol=1e-4)
+        torch.testing.assert_close(s[..., 1], (got[0] ** 2).sum((2, 3, 4)), atol=1e-2, rtol=1e-4)
+
+
+def test_conv3d_x3_small_operands_keep_their_low_halves():
+    """fp16 split of operands in [2^-10, 2^-7]: every lo half is an fp16 SUBNORMAL.  A matrix pipe that flushed subnormal
+    inputs (MI200 did) would leave the plain fp16 product (2^-11 relative); gfx950 keeps them, so the result must stay at
+    the 2^-20 level.  Also: bias, channel-slice input / output views."""
+    from brats21_amd import ops
+    n, cin, cout, size = 1, 48, 48, (4, 8, 16)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand((n, cin, *size), generator=g) * 7 + 1) * 2.0 ** -10 * (torch.randint(0, 2, (n, cin, *size), generator=g) * 2 - 1)
+    w = _rand((cout, cin, 3, 3, 3), 8, 0.03)
+    b = _rand((cout,), 9, 0.01) * 2.0 ** -10
+    ref = F.conv3d(x.double(), w.double(), b.double(), 1, 1, 1)
+    buf = torch.full((n, *size, 80), 5.0, device=DEV)
+    buf[..., 16:64] = _nd(x)
+    out = torch.full((n, *size, 64), 3.0, device=DEV)
+    with ops.split_precision(ops.X3F):
+        wpk = ops.pack_weights(w.to(DEV), torch.float32, ops.PACK_FWD)
+        ops.conv3d(buf[..., 16:64], wpk, cout, 3, 1, bias=b.to(DEV), out=out[..., 8:56])
+    torch.cuda.synchronize()
+    e = _relmax(_nc(out[..., 8:56]), ref)
+    print(f"fp16 split on subnormal-lo operands: rel-to-max err {e:.2e}")
+    assert e < 4e-6, e
+    assert float(out[..., :8].min()) == 3.0 and float(out[..., 56:].max()) == 3.0
+
+
+def _get(model, width, seed=0, norm="group"):
+    from brats21_amd import get_model
+    torch.manual_seed(seed)
+    ns = argparse.Namespace(model=model, width=width, norm=norm, act="relu", num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return get_model(ns)
+
+
+@pytest.mark.parametrize("fname", ["equiunet_w8_32.npz", "equiunet_w8_64.npz", "equiunet_w8_32_instance.npz"])
+def test_equiunet_x3_matches_reference_golden(golden_dir, fname):
+    """The reference's own outputs (tests/golden/make_golden.py) at the north-star bar, model.precision = "x3"."""
+    g = np.load(os.path.join(golden_dir, fname), allow_pickle=False)
+    meta = json.loads(str(g["meta"]))
+    size, s = tuple(meta["size"]), meta["sub"]
+    sd = synth.fill_state_dict(unet.equiunet_state_shapes(meta["width"]))
+    m = _get("equiunet", meta["width"], norm="instance" if "instance" in fname else "group")
+    m.load_state_dict(sd, strict=True)
+    m.precision = "x3"
+    m = m.to(DEV).train()
+    x = synth.closed_form_image(1, 4, size).to(DEV)
+    t = synth.nested_spheres(1, size).to(DEV)
+    out, deeps = m(x)
+    err = np.abs(out.detach().cpu().numpy()[:, :, ::s, ::s, ::s] - g["logits"]).max()
+    assert err < LOGIT_ATOL, f"logit max abs err {err}"
+    for i, d in enumerate(deeps):
+        e = np.abs(d.detach().cpu().numpy()[:, :, ::2 * s, ::2 * s, ::2 * s] - g[f"deep{i}"]).max()
+        assert e < LOGIT_ATOL, f"deep head {i} max abs err {e}"
+    loss = unet.deep_supervision_loss((out, deeps), t)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    names = json.loads(str(g["grad_names"]))
+    params = dict(m.named_parameters())
+    norms = np.array([float(params[k].grad.double().norm()) for k in names])
+    # 1e-2 where the exact-f32 mode holds 2e-3: the closed-form volume is constant outside its ellipsoid, i.e. full of EXACT
+    # max-pool / ReLU ties that the exact-f32 kernels break like the reference does and a 1e-7 perturbation does not
+    # (measured: <= 4.7e-3 on 6..8 of 61 parameters; flip-free evidence: test_x3_backward_arithmetic_matches_exact_f32_backward)
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=1e-2, atol=1e-7)
+    print(f"\n{fname} x3: logits err {err:.2e}")
+
+
+@pytest.mark.parametrize("size", [64, 128])
+def test_equiunet48_x3_vs_oracle(size):
+    """BASELINE.json configs[1]'s network at 1x4x64^3 / 1x4x128^3 against the CPU oracle: logits and deep heads within 1e-3
+    in the split-precision mode, printed beside the exact-f32 mode's error on the same input."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    m = _get("equiunet", 48)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    s3 = (size,) * 3
+    x = synth.random_image(1, 4, s3, seed=1234)
+    with torch.no_grad():
+        ref, ref_deeps = unet.equiunet_forward(sd, x)
+        errs = {}
+        for prec in ("fp32", "x3", "bf16x3"):
+            m.precision = prec
+            out, deeps = m(x.to(DEV))
+            errs[prec] = (float((out.cpu() - ref).abs().max()), max(float((d.cpu() - r).abs().max()) for d, r in zip(deeps, ref_deeps)))
+    print(f"\nEquiUnet-48 @{size}^3 max abs logit error (main, deep heads) vs the CPU oracle: {errs} (|logits| max {float(ref.abs().max()):.2f})")
+    assert errs["x3"][0] < LOGIT_ATOL and errs["x3"][1] < LOGIT_ATOL, errs
+    assert errs["x3"][0] < 4 * max(errs["fp32"][0], 5e-5), errs  # f32-class, not merely under the bar
+
+
+def _step_grads(m, prec, x, t):
+    m.zero_grad()
+    m.precision = prec
+    out, deeps = m(x)
+    unet.deep_supervision_loss((out, deeps), t).backward()
+    return out.detach(), {k: p.grad.double().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def _perturbed(name, width):
+    m = _get(name, width)
+    g = torch.Generator().manual_seed(3)
+    sd = {k: (v.detach().clone() + (0.02 * torch.randn(v.shape, generator=g) if v.dtype.is_floating_point and k.endswith(("gamma", "beta", "bn.weight", "bn.bias")) else 0))
+          for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    return m.to(DEV).train(), sd
+
+
+@pytest.mark.parametrize("name,width,size", [("equiunet", 48, 32), ("equiunet_assp_evo", 48, 32), ("equiunet", 8, 32)])
+def test_x3_backward_arithmetic_matches_exact_f32_backward(name, width, size):
+    """The backward program on fp16 pairs (dY scaled from its recorded |max|) against the exact-f32 MFMA backward ON THE SAME
+    FORWARD (precision "x3bwd": forward exact f32, backward split) -- no ReLU / max-pool decision can differ, so every
+    parameter gradient must agree to f32 round-off: 1e-4 relative (measured 2e-6 .. 6e-6)."""
+    m, _ = _perturbed(name, width)
+    s3 = (size,) * 3
+    x, t = synth.random_image(1, 4, s3, seed=5).to(DEV), synth.nested_spheres(1, s3).to(DEV)
+    _, g0 = _step_grads(m, "fp32", x, t)
+    _, g1 = _step_grads(m, "x3bwd", x, t)
+    rel = sorted(((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0), reverse=True)
+    print(f"\n{name}-{width} @{size}^3 split backward vs exact-f32 backward, worst per-parameter rel diff: {rel[:3]}")
+    assert rel[0][0] < 1e-4, rel[:5]
+
+
+@pytest.mark.parametrize("name,width,size", [("equiunet", 48, 32), ("equiunet_assp_evo", 48, 32)])
+def test_x3_gradients_vs_f64_oracle(name, width, size):
+    """Per-parameter gradients of the whole split-precision training step against the oracle in float64, beside the exact-f32
+    mode's on the same problem.  What limits BOTH is not arithmetic: a forward value that moves by 1e-6 can flip a max-pool
+    arg-max or a ReLU mask, and one flip moves the gradients of every layer upstream of it by ~5e-3 (the f32 CPU oracle is
+    2e-3..4e-3 off the f64 one for the same reason, tests/test_equiunet_gpu.py) -- a lottery with ~1e5 windows per level.
+    Hence: the MEDIAN parameter must hold 1e-3 with a wide margin (2e-4), the worst must stay in the flip regime (2e-2), and
+    the arithmetic itself is pinned flip-free by test_x3_backward_arithmetic_matches_exact_f32_backward and the conv tests."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    m, sd = _perturbed(name, width)
+    s3 = (size,) * 3
+    x = synth.random_image(1, 4, s3, seed=5)
+    t = synth.nested_spheres(1, s3)
+    sd_ref = {k: (v.clone().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    fwd = unet.equiunet_forward if name == "equiunet" else unet.assp_evo_forward
+    out_ref = fwd(sd_ref, x.double())
+    unet.deep_supervision_loss(out_ref, t.double()).backward()
+    res = {}
+    for prec in ("fp32", "x3"):
+        out, gr = _step_grads(m, prec, x.to(DEV), t.to(DEV))
+        err = float((out.cpu().double() - out_ref[0].detach()).abs().max())
+        rel = sorted(((float((gr[k] - sd_ref[k].grad).norm() / (sd_ref[k].grad.norm() + 1e-30)), k) for k in gr), reverse=True)
+        res[prec] = (err, rel[0], rel[len(rel) // 2][0])
+    print(f"\n{name}-{width} @{size}^3 vs f64 (logit err, worst per-parameter gradient rel err, median): {res}")
+    assert res["x3"][0] < LOGIT_ATOL, res
+    assert res["x3"][2] < 2e-4 and res["x3"][1][0] < 2e-2, res
