@@ -32,9 +32,8 @@ def conv_flops(cin, cout, k, n, d, h, w):
 def cpu_baseline(width, cores):
     """The CPU oracle (plain torch fp32 restatement of the reference's CPU path, oracle/unet.py) timed on the GPU box's
     host cores on a bounded sample of the bench workload: ONE real 4x128^3 patch of the width-48 network, forward + Dice
-    loss + backward, 2 warm-ups + 5 timed repetitions, MEDIAN (BASELINE.md section 3 asks for >= 3 warm-ups + >= 5 timed; the
-    third warm-up is dropped to keep the default run within the contract's few minutes: the mkldnn primitive cache and the
-    allocator are warm after the first repetition, repetitions 2.. differ by < 2 %).  Reported in the metric's unit
+    loss + backward, 3 warm-ups + 5 timed repetitions, MEDIAN (>= 3 warm-ups + >= 5 timed; the
+    counts are also machine-readable fields of the record).  Reported in the metric's unit
     (128^3-patches/s).  Threads: torch/mkldnn 3D convolutions scale to ~16 threads on this host and get SLOWER beyond
     (measured on the GPU box, scripts/cpu_threads.py: 8 thr 0.14 s, 16 thr 0.10 s, 32 thr 0.15 s, 64 thr 0.43 s, 128 thr
     2.1 s per 32^3 patch), so the baseline uses min(16, cores) threads."""
@@ -56,17 +55,21 @@ def cpu_baseline(width, cores):
                 times.append(time.perf_counter() - t0)
         return times
 
-    t128 = sorted(run((128, 128, 128), 2, 5))
-    med = t128[2]
-    return {"value": round(1.0 / med, 5), "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"1 patch of 4x128^3, fwd+Dice+bwd fp32 torch CPU (oracle/unet.py), 2 warm-ups + 5 timed, median {med:.2f} s "
+    warm, timed = 3, 5
+    t128 = sorted(run((128, 128, 128), warm, timed))
+    med = t128[timed // 2]
+    return {"value": round(1.0 / med, 5), "unit": "patches/s", "cores": threads, "kind": "port", "warmup_reps": warm, "timed_reps": timed,
+            "sample": f"1 patch of 4x128^3, fwd+Dice+bwd fp32 torch CPU (oracle/unet.py), {warm} warm-ups + {timed} timed, median {med:.2f} s "
                       f"(min {t128[0]:.2f}, max {t128[-1]:.2f}); host has {cores} cores, {threads} threads used (fastest setting)"}
 
 
 def parity_mode_leg(args, dev, x, t):
-    """The 1e-3-logit-parity configuration of the SAME workload: model.precision = "fp32" (exact-f32 MFMA kernels,
-    v_mfma_f32_16x16x4_f32), 2 warm-up + 5 timed training steps, plus the logit error of that mode against the CPU oracle
-    on one patch of the bench's own image with the bench's own initial weights (the oracle is only the checker here)."""
+    """The 1e-3-logit-parity configurations of the SAME workload, 2 warm-up + 5 timed training steps each, plus the logit
+    error of each mode against the CPU oracle on one patch of the bench's own image with the bench's own initial weights
+    (the oracle is only the checker here):
+      * model.precision = "x3": f32 tensors, the 3x3x3 convolutions as three fp16-pair MFMA products with f32 accumulation
+        (csrc/conv_igemm_x3.hpp; dY scaled from its recorded |max| in the backward) -- the reported parity mode;
+      * model.precision = "fp32": the exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32), kept beside it as "fp32_exact"."""
     import argparse as _ap, contextlib, io
     from brats21_amd import get_model
     from brats21_amd.engine import TrainStep
@@ -78,30 +81,38 @@ def parity_mode_leg(args, dev, x, t):
         m = get_model(ns)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.to(dev)
-    m.precision = "fp32"
-    m.eval()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    fwd = unet.equiunet_forward if args.model == "equiunet" else unet.assp_evo_forward
     with torch.no_grad():
-        out = m(x[:1])[0].float().cpu()
-        torch.set_num_threads(min(16, os.cpu_count() or 1))
-        fwd = unet.equiunet_forward if args.model == "equiunet" else unet.assp_evo_forward
         ref = fwd(sd, x[:1].float().cpu())[0]
-    err = float((out - ref).abs().max())
-    m.train()
-    with contextlib.redirect_stdout(io.StringIO()):
-        opt = Ranger2020(m.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5)
-    step = TrainStep(m, opt, criterion=None, amp=False)
-    for _ in range(2):
-        step(x, t)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        step(x, t)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 5 * 1e3
-    return {"dtype": "fp32", "ms_per_step": round(ms, 2), "patches_per_s": round(x.shape[0] / ms * 1e3, 2),
-            "logit_err": float(f"{err:.3e}"), "logit_bar": 1e-3, "logit_absmax": round(float(ref.abs().max()), 2),
-            "note": "model.precision='fp32' (exact-f32 MFMA), same batch / optimizer, 2 warm-up + 5 timed steps; logit_err = max abs "
-                    "difference of the main head to the CPU oracle (oracle/unet.py) on patch 0 with the initial weights"}
+    legs = {}
+    for prec in ("x3", "fp32"):
+        m.load_state_dict(sd)
+        m.precision = prec
+        m.eval()
+        with torch.no_grad():
+            err = float((m(x[:1])[0].float().cpu() - ref).abs().max())
+        m.train()
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = Ranger2020(m.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5)
+        step = TrainStep(m, opt, criterion=None, amp=False)
+        for _ in range(2):
+            step(x, t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step(x, t)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        legs[prec] = {"dtype": prec, "ms_per_step": round(ms, 2), "patches_per_s": round(x.shape[0] / ms * 1e3, 2),
+                      "logit_err": float(f"{err:.3e}")}
+    out = dict(legs["x3"])
+    out.update({"dtype": "x3 (f32 storage; 3x3x3 convolutions = 3 fp16-pair MFMA products, f32 accumulate)", "logit_bar": 1e-3,
+                "logit_absmax": round(float(ref.abs().max()), 2), "fp32_exact": legs["fp32"],
+                "note": "model.precision='x3' (csrc/conv_igemm_x3.hpp) beside 'fp32' (exact-f32 MFMA): same batch / optimizer, 2 warm-up "
+                        "+ 5 timed steps; logit_err = max abs difference of the main head to the CPU oracle (oracle/unet.py) on "
+                        "patch 0 with the initial weights"})
+    return out
 
 
 def kernel_source_sha():
@@ -191,6 +202,50 @@ def inference_bench(model, dev, args):
     return legs
 
 
+def launch_ranks(n, argv, dry_run=False):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv> as a child process; its stdout (rank
+    0's one JSON line) and stderr are relayed, its exit code returned.  Called before any HIP call of this process."""
+    import socket
+    import subprocess
+    if not dry_run:
+        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if have < n:
+            print(f"bench.py: --gpus {n} but this node has {have} GPU(s)", file=sys.stderr)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():  # stdout carries the JSON line only; library chatter of the ranks goes to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    return proc.returncode
+
+
+def dry_run(args):
+    """--dry-run: rendezvous + one CPU all-reduce over gloo, no GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has WORLD_SIZE={world}")
+    total = 1.0
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        v = torch.ones(1)
+        dist.all_reduce(v)
+        total = float(v.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run", "n_gpus": world, "dry_run": True, "ranks_seen": int(total)}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,7 +275,17 @@ def main():
                     help="NOT the headline configuration: run the 3x3x3 convolutions forward (fwd) or forward + input "
                          "gradients (all) on the e4m3 MFMA kernel (BASELINE.json configs[4]); weight gradients stay bf16")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only: every rank joins the process group (gloo on CPU), one all-reduce, rank 0 "
+                         "prints {n_gpus, dry_run}; no GPU is touched (tests/test_bench_launch_cpu.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare with --gpus N: start the N ranks ourselves, as a CHILD process, before anything touches the GPU (a
+        # process that has initialised the GPU must never exec another program on this pool), and relay rank 0's JSON line
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run))
+    if args.dry_run:
+        return dry_run(args)
 
     from brats21_amd import get_model, ops, LIB_PATH
     from brats21_amd import synth
@@ -231,7 +296,8 @@ def main():
 
     assert os.path.exists(LIB_PATH), "HIP extension missing"
     rank, world, local = init_process_group_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:  # never measure world 1 under an n_gpus = N label
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has WORLD_SIZE={world}")
     local = local % max(torch.cuda.device_count(), 1)  # (two ranks may share one GPU under BRATS_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -270,6 +336,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # what THIS box delivers right now (dense bf16 MFMA rate with every SIMD issuing, bf16 read + write stream): ~50 ms of
+    # probes right before the timed region, so that a reader can tell a slower box from slower code (roofline.frac_of_box)
+    box = ops.probe_box(dev) if rank == 0 else None
     timer = ops.KernelTimer() if rank == 0 and not args.graph and not os.environ.get("BRATS_BENCH_NO_TIMER") else None
     # per-kernel HIP events cost GPU time themselves (0.28 ms per step when every conv launch of every step is bracketed):
     # they are recorded in two of the timed steps only (at 1/3 and 2/3 of the run), inside the timed region
@@ -341,8 +410,13 @@ def main():
       fl = conv_flops(cin, cout, k, n, d, h, w)
       peak = PEAK_FP8_TFLOPS if dt == "e4m3" else (PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS)
       achieved = fl / (avg_ms * 1e-3) / 1e12
+      # frac_of_box: against the matrix rate this chip SUSTAINED in the probe right before the timed region (dense operands, every
+      # SIMD issuing; e4m3 runs at twice, exact f32 at 1/16 of the 16-bit pipe rate) -- comparable across the boxes of a pool,
+      # which frac (against the nominal peak at 2.4 GHz) is not
+      box_peak = box["mfma_TFLOPs"] * (2.0 if dt == "e4m3" else (1.0 if use_amp else PEAK_F32_TFLOPS / PEAK_BF16_TFLOPS))
       roofline = {"bound": "mfma", "kernel": f"{kind} cin={cin} cout={cout} k={k} dil={dil} @{n}x{d}x{h}x{w}",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                  "frac_of_box": round(achieved / box_peak, 4),
                   "traffic": None, "launches": cnt, "avg_ms": round(avg_ms, 4),
                   "sampled_steps": sampled,
                   "families": {f: {"ms_per_step": round(v[0] / sampled, 3), "TFLOPs": round(v[1] / (v[0] * 1e-3) / 1e12, 1)}
@@ -377,7 +451,7 @@ def main():
                                 " (BASELINE.json configs[2], per-GPU share)" if (args.model, args.width, args.fp8) == ("equiunet_assp_evo", 48, None) else
                                 f" (BASELINE.json configs[4], per-GPU share at {args.batch} patches, {args.precision} storage)" if (args.model, args.width) == ("equiunet_assp_evo", 64) and args.fp8 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
-        "roofline": roofline,
+        "roofline": roofline, "box": box,
     }
     if ddp_info is not None:
         res["ddp"] = ddp_info

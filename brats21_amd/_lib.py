@@ -82,8 +82,24 @@ def lib():
             continue
         fn.restype = ctypes.c_char_p if res == "s" else _C[res]
         fn.argtypes = [_C[c] for c in spec]
+    # the binding above is derived from THIS tree's header: a library of another ABI version (an older A/B build loaded
+    # through BRATS_HIP_LIB whose entry points changed signature) would be called with the wrong argument lists
+    want = _header_abi_version()
+    got = l.brats_abi_version()
+    if want is not None and got != want:
+        raise BratsHipError(f"{LIB_PATH} reports ABI version {got}, include/brats_hip.h declares {want}: rebuild the library "
+                            "(an A/B library must come from a tree with the same entry-point signatures)")
     _lib = l
     return l
+
+
+def _header_abi_version():
+    """The version the header's comment on brats_abi_version() states for this round ("N in round ..." / "N since ...")."""
+    m = re.search(r"int brats_abi_version\(void\);\s*/\*(.*?)\*/", open(HEADER_PATH).read(), flags=re.S)
+    if not m:
+        return None
+    nums = re.findall(r"(\d+) (?:since|in) round", m.group(1))
+    return max(int(n) for n in nums) if nums else None
 
 
 def check(rc, what):

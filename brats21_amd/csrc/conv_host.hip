@@ -5,11 +5,9 @@
 
 // ---- chunk selection ---------------------------------------------------------------------------
 int g_conv_vs8_mode = -1;
-int g_conv_ld_variant = -1;  // tuning only (scripts/time_ld.py): bits 4.. of the mode pick a template variant of conv_igemm_ld
 extern "C" int BRATS_API(brats_conv3d_set_vs8)(int mode) {
   const int old = g_conv_vs8_mode;
-  g_conv_vs8_mode = mode < 0 ? -1 : ((mode & 15) > 2 ? 2 : (mode & 15));  // 0 one-tile kernels, 1 conv_igemm_vs8, 2 conv_igemm_ld
-  g_conv_ld_variant = mode < 0 ? -1 : (mode >> 4);
+  g_conv_vs8_mode = mode < 0 ? -1 : (mode ? 1 : 0);  // 0 the 4x4x16-tile kernels, 1 conv_igemm_vs8 (4x8x16 tile)
   return old;
 }
 static int conv_vs8_enabled() {
@@ -31,8 +29,6 @@ extern "C" int BRATS_API(brats_conv3d_chunk)(int dtype, int ksize, int dil, int 
   // Cout = 48 (mod 96), bf16, 3x3x3 dilation 1: 24-channel chunks for the 4x8x16-tile kernel (conv_igemm_vs8.hpp)
   if (dtype == BRATS_BF16 && ksize == 3 && dil == 1 && cout > 0 && conv_vs8_enabled() && conv_vsplit_enabled()) {
     const int rows16 = ceil_div(cout, 16);
-    // mode 2: 16-channel chunks for the loader-wave kernel (conv_igemm_ld.hpp) where the sources allow them
-    if (rows16 % 3 == 0 && rows16 % 6 != 0 && conv_vs8_enabled() == 2 && c1 % 16 == 0 && (c2 <= 0 || c2 % 16 == 0) && c1 + (c2 > 0 ? c2 : 0) >= 32) return 16;
     if (rows16 % 3 == 0 && rows16 % 6 != 0 && c1 % 24 == 0 && (c2 <= 0 || c2 % 24 == 0)) return 24;
   }
   static int pref16 = -1;  // experiment switch: smaller K chunks -> smaller LDS tile -> more workgroups per CU

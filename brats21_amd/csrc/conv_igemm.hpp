@@ -14,7 +14,8 @@
 // Per Cin chunk (CK channels) the halo tile is staged once and all taps read it (27x reuse from
 // LDS; HBM/L2 sees only the ~2x halo amplification).  2 workgroups/CU overlap staging with MFMA.
 // Relatives: conv_igemm_vs8.hpp (y-split roles on a 4x8x16 tile, the default for bf16 layers with 48 mod 96 couts),
-// conv_igemm_f8.hpp (e4m3 operands).  (Two persistent experiments that did not pay live in scripts/probes/experiments/.)
+// conv_igemm_f8.hpp (e4m3 operands), conv_igemm_x3.hpp (f32 tensors, three 16-bit MFMA products).  (Experiments that did not
+// pay -- two persistent forms, the loader-wave kernel, three workgroups per CU -- live in scripts/probes/experiments/.)
 #pragma once
 #include <stdlib.h>
 #include "common.hpp"
@@ -114,15 +115,7 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       constexpr int k = k_;
       constexpr int ms = PARITY < 0 ? k : 2 * k + PARITY;
 #pragma unroll
-#ifdef BRATS_ABL_NOWLOAD  // ablation (diagnostic build only, WRONG results): no weight loads inside the MMA loop -- the first WD + 1
-      // macro-steps' fragments are reused; prices what the MFMA waves' own vector-memory stream costs them
-      for (int f = 0; f < NF; ++f) {
-        if constexpr (k <= WD) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
-        else OPAQUE_V(a[k % (WD + 1)][f]);
-      }
-#else
       for (int f = 0; f < NF; ++f) a[k % (WD + 1)][f] = wp0[((size_t)ms * rows16 + f) * 64];
-#endif
     };
     auto read_b = [&](auto k_, auto half_) {
       constexpr int k = k_, half = half_;
@@ -187,51 +180,6 @@ DEVI void conv_mma_chunk(const char* ldsb, int lane_b, int q, const void* wpk_ch
       });
     });
   }
-}
-
-// One chunk of MFMA work with a ring of RB activation fragments: fragment j = (macro-step k = j / 8, x-row i = j % 8) is
-// read RB - 1 fragments (3 (RB - 1) MFMAs) ahead of its use; the weight fragments of step k + WD are requested at the start
-// of step k.  Registers: NF * 8 * 4 accumulators + (WD + 1) * NF * 4 weights + RB * 4 activations.
-template <int NF, int WD, int RB, typename G>
-DEVI void conv_mma_ring(const char* ldsb, int lane_b, int q, const void* wpk_chunk, int rows16, int f0, int lane,
-                        f32x4 (&acc)[NF][8]) {
-  constexpr int NB = 8, YB = 4, MS = G::MS, NJ = MS * NB;
-  constexpr int FOZ = G::HY * G::HX * G::S;
-  const bf16x8* wp0 = (const bf16x8*)wpk_chunk + (size_t)f0 * 64 + lane;
-  bf16x8 a[WD + 1][NF];
-  bf16x8 b[RB];
-  auto load_a = [&](auto k_) {
-    constexpr int k = k_;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-#ifdef BRATS_ABL_NOWLOAD  // (ablation, see conv_mma_chunk)
-      if constexpr (k <= WD) a[k % (WD + 1)][f] = wp0[((size_t)k * rows16 + f) * 64];
-      else OPAQUE_V(a[k % (WD + 1)][f]);
-#else
-      a[k % (WD + 1)][f] = wp0[((size_t)k * rows16 + f) * 64];
-#endif
-    }
-  };
-  auto read_b = [&](auto j_) {
-    constexpr int j = j_, k = j / NB, i = j % NB;
-    constexpr int o0 = G::unitoff(4 * k), o1 = G::unitoff(4 * k + 1), o2 = G::unitoff(4 * k + 2), o3 = G::unitoff(4 * k + 3);
-    int lb;
-    if constexpr (o1 - o0 == G::UB && o2 - o0 == 2 * G::UB && o3 - o0 == 3 * G::UB) lb = lane_b + o0;
-    else lb = lane_b + (q == 0 ? o0 : q == 1 ? o1 - G::UB : q == 2 ? o2 - 2 * G::UB : o3 - 3 * G::UB);
-    b[j % RB] = *(const bf16x8*)(ldsb + lb + ((i / YB) * FOZ + (i % YB) * G::HX * G::S));
-  };
-  static_for<0, (WD < MS ? WD : MS)>([&](auto k_) { load_a(k_); });
-  static_for<0, RB - 1>([&](auto j_) { read_b(j_); });
-  static_for<0, NJ>([&](auto j_) {
-    constexpr int j = j_, k = j / NB, i = j % NB;
-    if constexpr (i == 0 && k + WD < MS) load_a(std::integral_constant<int, k + WD>{});
-    if constexpr (j + RB - 1 < NJ) read_b(std::integral_constant<int, j + RB - 1>{});
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-      acc[f][i] = MFMA16_16x16x32(a[k % (WD + 1)][f], b[j % RB], acc[f][i]);
-    __builtin_amdgcn_sched_barrier(0);
-  });
 }
 
 // 16-lane (one MFMA row group) all-reduce with DPP row rotations: 4 VALU ops, no LDS crossbar.

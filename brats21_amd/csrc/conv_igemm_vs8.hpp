@@ -90,11 +90,7 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
         }
         const u32x2 lo = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
         const u32x2 hi = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-#ifdef BRATS_ABL_NOSTORE  // ablation (diagnostic build only, WRONG results): the epilogue without its global stores
-        { u32x4 keep_ = u32x4{lo[0], hi[0], lo[1], hi[1]}; asm volatile("" :: "v"(keep_)); }
-#else
         *(u32x4*)(rowp + lane_w + (f0 + f) * 16) = u32x4{lo[0], hi[0], lo[1], hi[1]};
-#endif
       }
     }
   } else {
@@ -157,10 +153,10 @@ DEVI void vs8_epilogue_stats(const ConvParams& p, int ty4, const float* sred, in
   }
 }
 
-// W3 (round 3 experiment, BRATS_CONV_VS8_W3=1): the same kernel compiled for THREE workgroups per CU -- 168 VGPRs, made
-// possible by the ring form of the MMA loop (conv_mma_ring: 20 instead of 32 activation-fragment registers); 3 x 53.4 KB of LDS.
-template <int CK, int DIL, int NF, bool W3 = false>
-__global__ __launch_bounds__(256, W3 ? 3 : 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
+// (Three workgroups per CU -- a 168-register build on a ring form of the MMA loop -- measured 0.39 -> 0.57 ms in round 3:
+// scripts/probes/experiments/conv_igemm_ld.hpp keeps that loop.)
+template <int CK, int DIL, int NF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
   using T = bf16_t;
   using G = ConvGeom<T, 3, CK, DIL, VS8_TY>;
   constexpr int NB = 8, YB = 4;
@@ -230,12 +226,7 @@ __global__ __launch_bounds__(256, W3 ? 3 : 2) void conv_igemm_vs8_kernel(const C
       const int rb = ((gz * p.H + gy) * p.W + (x0 - G::R)) * pb;
 #pragma unroll
       for (int j = 0; j < IPR; ++j) {
-#ifdef BRATS_ABL_NOHALO  // ablation (diagnostic build only, WRONG results): halo loads without their memory traffic
-        // (loads kept, but all from one 16 KB window: L1 hits with non-zero data -- zeros would raise the MFMA clock)
-        const int vo = (row_ok && hx_part[j] >= 0) ? (rb + goff[j]) & 0x3ff0 : -1;
-#else
         const int vo = (row_ok && hx_part[j] >= 0) ? rb + goff[j] : -1;
-#endif
         r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
       }
     }
@@ -257,8 +248,7 @@ __global__ __launch_bounds__(256, W3 ? 3 : 2) void conv_igemm_vs8_kernel(const C
     __syncthreads();
     VS8_STAMP(3);  // LDS writes + barrier
     const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
-    if constexpr (W3) conv_mma_ring<NF, 2, 5, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
-    else conv_mma_chunk<T, 3, CK, DIL, NF, -1, NB, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    conv_mma_chunk<T, 3, CK, DIL, NF, -1, NB, G>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     VS8_STAMP(4);  // MFMA loop
   }
 
@@ -287,10 +277,10 @@ static inline int conv_vs8_mode() {
   return v;
 }
 
-template <int CK, int DIL, int NF, bool W3 = false>
+template <int CK, int DIL, int NF>
 int conv_launch_vs8(const ConvParams& p0, hipStream_t st) {
   constexpr int lds = conv_vs8_lds_bytes<CK, DIL, NF>();
-  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF, W3>;
+  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   ConvParams p = p0;

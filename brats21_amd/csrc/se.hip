@@ -179,7 +179,8 @@ __global__ __launch_bounds__(SE_NT) void se_bwd_kernel(const float* __restrict__
                                                        float inv_vox, const float* __restrict__ hidden, const float* __restrict__ gate1p,
                                                        const float* __restrict__ w1, const float* __restrict__ w2,
                                                        float* __restrict__ gadd, float* __restrict__ dw1, float* __restrict__ db1,
-                                                       float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int Ch) {
+                                                       float* __restrict__ dw2, float* __restrict__ db2, int N, int C, int Ch,
+                                                       int accum /* add to the parameter gradients of the samples before */) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   float* ds = (float*)lds_raw;          // [N][C]   d loss / d (pre-sigmoid)
   float* gap = ds + (size_t)N * C;      // [N][C]
@@ -228,23 +229,23 @@ __global__ __launch_bounds__(SE_NT) void se_bwd_kernel(const float* __restrict__
   // parameter gradients: samples added in order
   for (int i = tid; i < (c_hi - c_lo) * Ch; i += nt) {
     const int c = c_lo + i / Ch, j = i % Ch;   // dW2[c][j] = sum_n ds[n][c] hid[n][j]
-    float s = 0.f;
+    float s = accum ? dw2[(size_t)c * Ch + j] : 0.f;
     for (int n = 0; n < N; ++n) s += ds[n * C + c] * hid[n * Ch + j];
     dw2[(size_t)c * Ch + j] = s;
   }
   for (int i = tid; i < (j_hi - j_lo) * C; i += nt) {
     const int j = j_lo + i / C, c = i % C;     // dW1[j][c] = sum_n dh[n][j] gap[n][c]
-    float s = 0.f;
+    float s = accum ? dw1[(size_t)j * C + c] : 0.f;
     for (int n = 0; n < N; ++n) s += dh[n * Ch + j] * gap[n * C + c];
     dw1[(size_t)j * C + c] = s;
   }
   for (int c = c_lo + tid; c < c_hi; c += nt) {
-    float s = 0.f;
+    float s = accum ? db2[c] : 0.f;
     for (int n = 0; n < N; ++n) s += ds[n * C + c];
     db2[c] = s;
   }
   for (int j = j_lo + tid; j < j_hi; j += nt) {
-    float s = 0.f;
+    float s = accum ? db1[j] : 0.f;
     for (int n = 0; n < N; ++n) s += dh[n * Ch + j];
     db1[j] = s;
   }
@@ -285,20 +286,34 @@ int brats_se_bwd_launch(const float* dgate, const SeFold& fold, const float* cha
   if (fold.raw5 && (!fold.mean_rstd || !fold.gamma || !fold.beta || !fold.red3 || fold.groups <= 0 || C % fold.groups))
     BRATS_FAIL(BRATS_E_ARG, "se_bwd: incomplete EvoNorm fold arguments");
   const bool v4 = C % 4 == 0 && Ch % 4 == 0 && ((uintptr_t)w1 % 16 == 0) && ((uintptr_t)w2 % 16 == 0);
-  const size_t lds = ((size_t)N * (2 * C + 2 * Ch) + SE_PART_FLOATS) * 4;
-  if (N > SE_MAXN || C > SE_NT || lds > 160 * 1024)
-    BRATS_FAIL(BRATS_E_UNSUPPORTED, "se_bwd: N = %d (max %d) x (C = %d, C/r = %d) exceeds the workgroup's budget", N, SE_MAXN, C, Ch);
+  // samples in groups of at most SE_MAXN (the per-sample state lives in one workgroup's LDS); the parameter gradients of
+  // later groups are added to the earlier ones in order (launches on one stream: bitwise reproducible).  A per-GPU batch
+  // above 8 (small patches) used to fail here AFTER a whole forward pass.
   const int G = se_workgroups(C, Ch);
-  if (v4) {
-    static std::atomic<uint64_t> done{0};
-    BRATS_ENSURE_LDS_ATTR(se_bwd_kernel<4>, 160 * 1024, done);
-    hipLaunchKernelGGL(se_bwd_kernel<4>, dim3(G), dim3(SE_NT), lds, st, dgate, fold, chansum, inv_vox, hidden, gate1p, w1, w2, gadd, dw1,
-                       db1, dw2, db2, N, C, Ch);
-  } else {
-    static std::atomic<uint64_t> done{0};
-    BRATS_ENSURE_LDS_ATTR(se_bwd_kernel<1>, 160 * 1024, done);
-    hipLaunchKernelGGL(se_bwd_kernel<1>, dim3(G), dim3(SE_NT), lds, st, dgate, fold, chansum, inv_vox, hidden, gate1p, w1, w2, gadd, dw1,
-                       db1, dw2, db2, N, C, Ch);
+  for (int n0 = 0; n0 < N; n0 += SE_MAXN) {
+    const int nb = N - n0 < SE_MAXN ? N - n0 : SE_MAXN;
+    const size_t lds = ((size_t)nb * (2 * C + 2 * Ch) + SE_PART_FLOATS) * 4;
+    if (C > SE_NT || lds > 160 * 1024)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "se_bwd: C = %d, C/r = %d exceed the workgroup's budget", C, Ch);
+    SeFold f = fold;
+    if (f.raw5) {
+      f.raw5 += (size_t)n0 * C * 5;
+      f.red3 += (size_t)n0 * C * 3;
+      f.mean_rstd += (size_t)n0 * f.groups * 2;
+    }
+    const float* dg = dgate ? dgate + (size_t)n0 * C : nullptr;
+    const size_t oc = (size_t)n0 * C, oh = (size_t)n0 * Ch;
+    if (v4) {
+      static std::atomic<uint64_t> done{0};
+      BRATS_ENSURE_LDS_ATTR(se_bwd_kernel<4>, 160 * 1024, done);
+      hipLaunchKernelGGL(se_bwd_kernel<4>, dim3(G), dim3(SE_NT), lds, st, dg, f, chansum + oc, inv_vox, hidden + oh, gate1p + oc, w1, w2,
+                         gadd + oc, dw1, db1, dw2, db2, nb, C, Ch, n0 > 0 ? 1 : 0);
+    } else {
+      static std::atomic<uint64_t> done{0};
+      BRATS_ENSURE_LDS_ATTR(se_bwd_kernel<1>, 160 * 1024, done);
+      hipLaunchKernelGGL(se_bwd_kernel<1>, dim3(G), dim3(SE_NT), lds, st, dg, f, chansum + oc, inv_vox, hidden + oh, gate1p + oc, w1, w2,
+                         gadd + oc, dw1, db1, dw2, db2, nb, C, Ch, n0 > 0 ? 1 : 0);
+    }
   }
   BRATS_CHECK_LAUNCH();
   return 0;

@@ -85,6 +85,11 @@ class GraphedTrainStep:
     explicitly: ``multi_rank_capture=True`` (or BRATS_GRAPH_DDP=1); otherwise use the eager TrainStep with buckets."""
 
     def __init__(self, step, warmup=2, multi_rank_capture=None):
+        if getattr(step, "scaler", None) is not None and step.amp:
+            # torch.amp.GradScaler.step() / update() read found_inf on the HOST: a capture would either fail obscurely or bake
+            # one step's decision into the graph (ADVICE r3).  fp16 training runs eagerly (TrainStep), bf16 / x3 / fp32 graph.
+            raise NotImplementedError("GraphedTrainStep: a TrainStep with a GradScaler (amp_dtype=torch.float16) cannot be captured; "
+                                      "use the eager TrainStep for fp16, or bf16 / model.precision='x3' for graph replay")
         if step.buckets is not None:
             import os
             import torch.distributed as dist

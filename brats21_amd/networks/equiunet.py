@@ -240,6 +240,10 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     return dx[..., :c1], dx[..., c1:]
 
 
+def douts_device(douts):
+    return next(d.device for d in douts if d is not None)
+
+
 class _EquiUnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, dtype, *params):
@@ -308,6 +312,7 @@ class _EquiUnetFn(torch.autograd.Function):
             up1 = cgr(m.decoder1.ConvBnRelu2, u1)
             outs = [ops.head(up1, m.outconv.weight, m.outconv.bias, 1)]
         ctx.top_fused = fuse_top
+        ctx.out_shape = tuple(outs[0].shape)
         heads = [(m.outconv, up1, 1)]
         if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
             for hd, src, sc in ((m.deep_bottom[0], bottom, 8), (m.deep_bottom2[0], bottom_2, 8), (m.deep3[0], up3, 4),
@@ -350,6 +355,9 @@ class _EquiUnetFn(torch.autograd.Function):
         dsrc = {}
         top = None  # the output head on up1: folded into the GroupNorm backward of the last layer where that is built
         for (hd, src, sc), dout in zip(ctx.heads, douts):
+            if dout is None and hd is m.outconv and ctx.top_fused:
+                # a loss built from the deep heads only: the fused top has no stored up1 to fall back on -- zero logit gradients
+                dout = torch.zeros((ctx.out_shape), dtype=torch.float32, device=douts_device(douts))
             if dout is None:
                 continue
             if hd is m.outconv and (ctx.top_fused or (m.fold_head_bwd
@@ -371,7 +379,7 @@ class _EquiUnetFn(torch.autograd.Function):
         def plus(a, b):
             return a if b is None else a + b
 
-        d_c1 = cbw(m.decoder1.ConvBnRelu2, None, head=top) if top is not None else cbw(m.decoder1.ConvBnRelu2, extra(up1))
+        d_c1 = cbw(m.decoder1.ConvBnRelu2, None, head=top) if top is not None else cbw(m.decoder1.ConvBnRelu2, extra(up1) if extra(up1) is not None else torch.zeros_like(up1))
         d_skip1, d_u1 = cbw(m.decoder1.ConvBnRelu1, d_c1)
         d_up2 = plus(ops.upsample_bwd(d_u1, 2), extra(up2))
         d_skip2, d_u2 = cbw(m.decoder2.ConvBnRelu1, cbw(m.decoder2.ConvBnRelu2, d_up2))

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .._lib import PACK_DGRAD, PACK_FWD, BratsHipError
-from .equiunet import _AmaxSlots, _ConvParams, _PackedWeightsModule, _inherit_amax
+from .equiunet import douts_device, _AmaxSlots, _ConvParams, _PackedWeightsModule, _inherit_amax
 
 
 # ------------------------------------------------------------------------------------------ parameter holders
@@ -337,6 +337,7 @@ class _AsspFn(torch.autograd.Function):
             up1, rd1 = _block_fwd(cx, m.decoder1, cat1)
             outs = [ops.head(up1, m.out_conv.weight, m.out_conv.bias, 1)]
         ctx.top_fused = fuse_top
+        ctx.out_shape = tuple(outs[0].shape)
         heads = [(m.out_conv, up1, 1)]
         if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
             for hd, src, sc in ((m.deep3[0], up3, 4), (m.deep2[0], up2, 2)):
@@ -359,6 +360,9 @@ class _AsspFn(torch.autograd.Function):
         dsrc = {}
         top = None  # the output head on up1: folded into the backward of the decoder1 block (three logit planes)
         for (hd, src, sc), dout in zip(ctx.heads, douts):
+            if dout is None and hd is m.out_conv and ctx.top_fused:
+                # a loss built from the deep heads only: the fused top has no stored up1 to fall back on -- zero logit gradients
+                dout = torch.zeros((ctx.out_shape), dtype=torch.float32, device=douts_device(douts))
             if dout is None:
                 continue
             if hd is m.out_conv and (ctx.top_fused or (m.fold_head_bwd and hd.weight.shape[0] == 3)):
@@ -373,7 +377,7 @@ class _AsspFn(torch.autograd.Function):
             b = dsrc.get(t.data_ptr())
             return a if b is None else a + b
 
-        dcat1 = _block_bwd(cx, R["rd1"], None, head=top) if top is not None else _block_bwd(cx, R["rd1"], dsrc[up1.data_ptr()])
+        dcat1 = _block_bwd(cx, R["rd1"], None, head=top) if top is not None else _block_bwd(cx, R["rd1"], dsrc[up1.data_ptr()] if up1.data_ptr() in dsrc else torch.zeros_like(up1))
         d_up2 = plus(_conv_evo_bwd(cx, R["ru1"], ops.upsample_bwd(dcat1[..., h0:], 2)), up2)
         dcat2 = _block_bwd(cx, R["rd2"], d_up2)
         d_up3 = plus(_conv_evo_bwd(cx, R["ru2"], ops.upsample_bwd(dcat2[..., h1:], 2)), up3)

@@ -1127,3 +1127,61 @@ def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False, out=None):
                                                        db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
                                                        cout, _stream()), "conv3d_wgrad_shift")
     return dw, db
+
+
+# ------------------------------------------------------------------------------------------ box calibration
+def probe_box(device=None, mfma_ms=12.0, stream_bytes=403 << 20, modes=(0, 1)):
+    """What THIS box delivers right now on the two resources the rooflines are quoted against (csrc/probe.hip): 16-bit
+    MFMA TFLOP/s with every SIMD issuing back to back (two waves per SIMD, like the convolution kernels), and TB/s of a bf16
+    read + write stream over `stream_bytes` (the size of a 2 x 128^3 x 48 activation).  ~40 ms of GPU time, HIP-event timed
+    on the current stream.
+      mfma_TFLOPs       : dense pseudo-random operands -- the matrix rate the chip SUSTAINS (it holds 1.8-2.0 GHz of its
+                          nominal 2.4 GHz under this load: sclk_MHz = 16 cycles per MFMA and SIMD); roofline.frac_of_box
+                          is quoted against this number;
+      mfma_zeros_TFLOPs : every second operand value zero (post-ReLU activations): less switching power, higher clock --
+                          the ceiling for kernels fed with such data.
+    (modes 2 / 3 of the probe add vector instructions between the matrix groups: scripts/box_calib.py.)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    l = _lib.lib()
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks = 2 * ncu  # 8 waves per CU = two per SIMD, like the convolution kernels
+    out = torch.empty(blocks, dtype=torch.float32, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def mfma(iters, mode):
+        ev[0].record()
+        _lib.check(l.brats_probe_mfma(out.data_ptr(), blocks, iters, mode, _stream()), "probe_mfma")
+        ev[1].record()
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
+
+    res = {}
+    for mode in modes:
+        mfma(2000, mode)  # warm-up (code object load, clocks)
+        t0 = mfma(20000, mode)
+        iters = max(20000, int(20000 * mfma_ms / max(t0, 1e-3)))
+        ms = mfma(iters, mode)
+        tf = blocks * 4.0 * iters * 8 * 16384 / (ms * 1e-3) / 1e12
+        res[mode] = (tf, ms, iters)
+    src = torch.empty(stream_bytes, dtype=torch.uint8, device=dev)
+    src.view(torch.int16).fill_(0x3c00)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        _lib.check(l.brats_probe_stream(src.data_ptr(), dst.data_ptr(), stream_bytes, _stream()), "probe_stream")
+    reps = 8
+    ev[2].record()
+    for _ in range(reps):
+        _lib.check(l.brats_probe_stream(src.data_ptr(), dst.data_ptr(), stream_bytes, _stream()), "probe_stream")
+    ev[3].record()
+    ev[3].synchronize()
+    sms = ev[2].elapsed_time(ev[3]) / reps
+    rec = {"stream_TBps": round(2.0 * stream_bytes / (sms * 1e-3) / 1e12, 3)}
+    names = {0: "mfma", 1: "mfma_zeros", 2: "mfma_duty_dense", 3: "mfma_duty"}
+    for mode, (tf, ms, iters) in res.items():
+        rec[names[mode] + "_TFLOPs"] = round(tf, 1)
+    if 0 in res:  # two waves per SIMD x iters x 8 MFMAs x 16 cycles
+        rec["sclk_MHz"] = round(2.0 * res[0][2] * 8 * 16 / (res[0][1] * 1e-3) / 1e6, 0)
+    rec["probe"] = (f"csrc/probe.hip: {blocks} x 4 waves issuing v_mfma_f32_16x16x32_bf16 back to back, ~{mfma_ms:.0f} ms per mode (mfma = dense "
+                    f"random operands: the sustained matrix rate, sclk = the clock behind it at 16 cycles per MFMA and SIMD; mfma_zeros = "
+                    f"every second value zero); bf16 read + write stream over {stream_bytes >> 20} MiB, {sms * 1e3:.0f} us per pass")
+    return rec

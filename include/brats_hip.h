@@ -95,12 +95,11 @@ int brats_conv3d_pack_weights_multi_f16(const brats_pack_job* jobs, const int* b
 int brats_conv3d_tiles_per_sample(int D, int H, int W);
 /* ysplit of brats_conv3d_fwd must be a multiple of this (channels one wave owns for `cout` outputs) */
 int brats_conv3d_split_granule(int cout);
-/* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 2 = 16-channel chunks + the loader-wave kernel on the
- * 4x8x16 tile (conv_igemm_ld.hpp: next chunk prefetched by LDS-DMA), 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
- * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (BRATS_CONV_VS8).  Bits 4.. of a
- * non-negative mode select a tuning variant of the mode-2 kernel (scripts/time_ld.py; 0 = the default).  The setting
+/* bf16 3x3x3 dilation-1 layers with 48 (mod 96) output channels: 1 = 24-channel chunks + the 4x8x16-tile y-split kernel
+ * (conv_igemm_vs8.hpp), 0 = 48-channel chunks + the 4x4x16-tile kernels, -1 = default (BRATS_CONV_VS8, on).  The setting
  * changes brats_conv3d_chunk(), i.e. the packed-weight layout: weights must be packed under the same setting they are
- * used with (the Python side offers ops.set_vs8(), which also drops its packed-weight caches).  Returns the previous setting. */
+ * used with (the Python side offers ops.set_vs8(), which also drops its packed-weight caches).  Returns the previous setting.
+ * (Round 3's mode 2, the loader-wave kernel, measured slower and left the library: scripts/probes/experiments/.) */
 int brats_conv3d_set_vs8(int mode);
 /* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
  * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2
@@ -515,6 +514,19 @@ int brats_zscore_normalize(const float* x, float* y, double* stats, int planes, 
                            float clip, brats_stream_t s);
 int brats_gamma_noise(const float* x, float* y, size_t total, float vmin, float vrange, float gamma,
                       const float* noise, brats_stream_t s);
+
+/* ---- box calibration probes (bench.py's "box" record; no counterpart in the reference) -------------------------------
+ * The boxes of one MI355X pool differ by several per cent on identical code, and the clock the chip holds under MFMA load
+ * depends on power management: a roofline fraction against the nominal peak cannot tell a slower box from slower code.
+ * The caller times these launches with HIP events on the launch stream.
+ *   brats_probe_mfma: `blocks` workgroups of 4 waves, each wave issues `iters` x 8 independent v_mfma_f32_16x16x32_bf16 on
+ *     pseudo-random operands -> FLOP = blocks * 4 * iters * 8 * 16384; `out` = blocks floats of scratch.  mode bit 0: every
+ *     second operand value is zero (post-ReLU data); bit 1: 24 dependent VALU instructions between two groups of 8 MFMAs
+ *     (~60 % matrix duty, the regime of the implicit-GEMM kernels) instead of the pure matrix loop (a power virus).
+ *   brats_probe_stream: bf16 read + scale-shift-relu + write over `bytes` (16-byte aligned, multiple of 16) with the
+ *     library's own streaming policy (non-temporal, 4 vectors in flight) -> 2 * bytes of HBM traffic. */
+int brats_probe_mfma(float* out, int blocks, int iters, int mode, brats_stream_t s);
+int brats_probe_stream(const void* src, void* dst, size_t bytes, brats_stream_t s);
 
 #ifdef __cplusplus
 }

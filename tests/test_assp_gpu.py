@@ -374,7 +374,7 @@ def test_evonorm_se_bwd_with_folded_output_head(n, c, size):
         assert all(torch.equal(a, b) for a, b in zip(again, got) if a is not None)  # bitwise reproducible
 
 
-@pytest.mark.parametrize("n,c", [(2, 48), (1, 16), (4, 384), (3, 96)])
+@pytest.mark.parametrize("n,c", [(2, 48), (1, 16), (4, 384), (3, 96), (19, 48), (9, 192)])  # (> 8 samples: groups of 8)
 def test_se_gate_kernels_vs_torch_autograd(n, c):
     """csrc/se.hip (one launch forward, one backward) against the MONAI ResidualSELayer arithmetic in torch f64:
     gate = sigmoid(W2 relu(W1 gap + b1) + b2) with gap = chansum / V, and the gradients of gap, W1, b1, W2, b2

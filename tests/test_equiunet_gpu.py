@@ -438,3 +438,35 @@ def test_equiunet_other_widths_f32_vs_oracle(width):
     g16 = torch.cat([p.grad.flatten().cpu() for p in m.parameters()])
     gref = torch.cat([sd_ref[k].grad.flatten() for k, _ in m.named_parameters()])
     assert float(torch.nn.functional.cosine_similarity(g16, gref, dim=0)) > 0.98
+
+
+@pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
+def test_loss_from_deep_heads_only_with_fused_top(name):
+    """A loss that does not touch the main logits: autograd hands the network program None for them.  With the output head
+    folded into the last layer's passes (top_fused: up1 is never stored) the backward used to fall through to code that
+    needs up1; it now runs the fold with zero logit gradients -- same result as the unfused program."""
+    import warnings
+    from brats21_amd import get_model
+    grads = {}
+    for fold in ("1", "0"):
+        os.environ["BRATS_FOLD_HEAD"] = fold
+        os.environ["BRATS_FOLD_HEAD_FWD"] = fold
+        try:
+            torch.manual_seed(0)
+            with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = get_model(argparse.Namespace(model=name, width=8 if name == "equiunet" else 16, norm="group", act="relu", num_classes=3,
+                                                 dropout=0)).cuda().train()
+        finally:
+            os.environ.pop("BRATS_FOLD_HEAD", None)
+            os.environ.pop("BRATS_FOLD_HEAD_FWD", None)
+        m.precision = "fp32"
+        x = synth.random_image(1, 4, (16, 16, 16), seed=3).cuda()
+        out, deeps = m(x)
+        (deeps[0].square().mean() + deeps[-1].square().mean()).backward()
+        grads[fold] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    main = "outconv.weight" if name == "equiunet" else "out_conv.weight"
+    assert main in grads["1"] and float(grads["1"][main].abs().max()) == 0.0
+    for k, g in grads["0"].items():
+        if k in grads["1"]:
+            torch.testing.assert_close(grads["1"][k], g, atol=1e-6, rtol=1e-4)

@@ -27,10 +27,10 @@ LOGIT_ATOL = 1e-3   # north_star: "logits must match the reference PyTorch CPU p
 DICE_ATOL = 1e-3    # north_star: "Dice within 1e-3 of the CPU reference on identical synthetic volumes"
 
 
-def _get(model, width, seed=0):
+def _get(model, width, seed=0, act="relu"):
     from brats21_amd import get_model
     torch.manual_seed(seed)
-    ns = argparse.Namespace(model=model, width=width, norm="group", act="relu", num_classes=3, dropout=0)
+    ns = argparse.Namespace(model=model, width=width, norm="group", act=act, num_classes=3, dropout=0)
     with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
         warnings.simplefilter("ignore")
         return get_model(ns)
@@ -287,16 +287,19 @@ def test_assp48_full_size_patch_vs_oracle():
     m.precision = "auto"
 
 
-@pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
-def test_width48_fp16_gradients_vs_f64_oracle(name):
+@pytest.mark.parametrize("name,act", [("equiunet", "relu"), ("equiunet_assp_evo", "relu"), ("equiunet", "swish"), ("equiunet", "elu")])
+def test_width48_fp16_gradients_vs_f64_oracle(name, act):
     """Per-parameter gradients of both width-48 networks in the fp16 storage mode (loss scaled by 2^14 before backward and
     unscaled afterwards, as the GradScaler does) against the oracle evaluated in float64, 1x4x32^3.  ABSOLUTE bars where the
     bf16 tests can only bound the error relative to torch's own CPU bf16 autocast (bf16: median 1-11 %, worst 17-21 %):
     EquiUnetASSPEvo (smooth EvoNorm / swish units) median < 1 %, worst < 10 % (measured 0.16 % / 4.8 %); EquiUnet
     (GroupNorm + ReLU: a pre-activation that changes sign under the 16-bit rounding flips its gradient mask, so the error
-    is set by the mask flips, not by the arithmetic) median < 8 %, worst < 20 % (measured 5.5 % / 12 %)."""
+    is set by the mask flips, not by the arithmetic) median < 8 %, worst < 20 % (measured 5.5 % / 12 %).
+    The CONTROL for that explanation (round 3 moved EquiUnet's bar from 1.5 % to 8 % on the strength of it): the same
+    network, the same GroupNorm forward / backward kernels and fp16 storage, with a SMOOTH activation (--act swish / elu:
+    no mask to flip) must reach the ASSP level -- median < 1 %, worst < 10 % -- or the GroupNorm path has an fp16 defect."""
     _cpu_threads()
-    m = _get(name, 48)
+    m = _get(name, 48, act=act)
     g = torch.Generator().manual_seed(11)
     sd = {k: (v.detach().clone() + (0.02 * torch.randn(v.shape, generator=g) if v.dtype.is_floating_point and k.endswith(("gamma", "beta", "bn.weight", "bn.bias")) else 0))
           for k, v in m.state_dict().items()}
@@ -306,7 +309,7 @@ def test_width48_fp16_gradients_vs_f64_oracle(name):
     x = synth.random_image(1, 4, size, seed=5)
     t = synth.nested_spheres(1, size)
     sd_ref = {k: (v.clone().double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
-    fwd = unet.equiunet_forward if name == "equiunet" else unet.assp_evo_forward
+    fwd = (lambda sd_, x_: unet.equiunet_forward(sd_, x_, act=act)) if name == "equiunet" else unet.assp_evo_forward
     unet.deep_supervision_loss(fwd(sd_ref, x.double()), t.double()).backward()
     scale = 2.0 ** 14
     m.precision = "fp16"
@@ -322,7 +325,7 @@ def test_width48_fp16_gradients_vs_f64_oracle(name):
         rel.append((float((gr - ref).norm() / (ref.norm() + 1e-30)), k))
     rel.sort()
     med, worst = rel[len(rel) // 2][0], rel[-1]
-    print(f"\n{name}-48 @32^3 fp16 gradients vs f64 oracle: median rel err {med:.3e}, worst {worst[0]:.3e} ({worst[1]})")
-    bars = (0.08, 0.20) if name == "equiunet" else (0.01, 0.10)
+    print(f"\n{name}-48 ({act}) @32^3 fp16 gradients vs f64 oracle: median rel err {med:.3e}, worst {worst[0]:.3e} ({worst[1]})")
+    bars = (0.08, 0.20) if (name, act) == ("equiunet", "relu") else (0.01, 0.10)
     assert med < bars[0] and worst[0] < bars[1], (med, worst)
     m.precision = "auto"
