@@ -6,7 +6,7 @@ import bench
 from brats21_amd import get_model
 
 dev = torch.device("cuda:0")
-args = argparse.Namespace(width=48, model="equiunet", sw_batch=4, precision="bf16", fp8=None)
+args = argparse.Namespace(width=48, model="equiunet", sw_batch=4, precision="bf16", fp8=None, infer_headline_only="--all" not in sys.argv)
 ns = argparse.Namespace(model="equiunet", width=48, norm="group", act="relu", num_classes=3, dropout=0)
 torch.manual_seed(0)
 with contextlib.redirect_stdout(io.StringIO()):

@@ -129,3 +129,46 @@ def test_config3_stitched_logits_vs_oracle_and_bf16_flip8_dice():
     sure = (ref[..., p_b[2]:160 - p_a[2]].abs() > 2e-3).expand_as(seg_ref) | ~seg_ref
     assert torch.equal(seg1[sure], seg_ref[sure])
     m.precision = "auto"
+
+
+def test_whole_volume_path_vs_oracle_f32_and_x3():
+    """The reference's PUBLISHED evaluation path (learning/engine.py:305-309, README.md:134-170): no sliding window, the whole
+    padded 240 x 240 x 160 volume through the network.  bench.py times it (inference_whole_volume); here the network's logits
+    at that size -- non-cubic, 4.4x the voxels of a training patch, every level's tile count different from the 128^3 case --
+    are checked against the CPU oracle on the bench's own volume and weights: exact-f32 mode AND the split-precision mode
+    within the north-star bar (identity TTA; the 16 transformers are pinned bit for bit above), then the Evaluator's
+    whole-volume chain (16 TTA transforms, bf16) against the same chain in f32: hard Dice within 1e-3."""
+    from brats21_amd import tta
+    from brats21_amd.evaluate import Evaluator, hard_dice_metric, shape_to_divisible
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    m = _model()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    m.skip_deep_heads_in_eval = True
+    x = _volume()
+    xd = x.to(DEV)
+    padded, p_b, p_a = shape_to_divisible(xd, k=8)
+    assert tuple(padded.shape[2:]) == (240, 240, 160)
+    with torch.no_grad():
+        ref = unet.equiunet_forward(sd, padded.cpu(), deep_supervision=False)
+        ref = ref[0] if isinstance(ref, (tuple, list)) else ref
+        errs = {}
+        for prec in ("fp32", "x3"):
+            m.precision = prec
+            out = m(padded)
+            out = out[0] if isinstance(out, (tuple, list)) else out
+            errs[prec] = float((out.cpu() - ref).abs().max())
+    print(f"\nwhole padded volume 240x240x160 through the network, max abs logit err vs the CPU oracle over {ref.numel()} values: {errs} "
+          f"(|logits| max {float(ref.abs().max()):.2f})")
+    assert errs["fp32"] < 1e-3 and errs["x3"] < 1e-3, errs
+    # the Evaluator's whole-volume chain with the reference's 16 transforms: bf16 against f32
+    td = synth.nested_spheres(1, VOL).to(DEV)
+    dice = {}
+    for prec, amp in (("fp32", False), ("bf16", True)):
+        m.precision = "auto" if amp else "fp32"
+        ev = Evaluator(m, tta_transforms=list(tta.get_tta_transforms()), sliding_window_size=None, k_divisible=8, amp=amp)
+        dice[prec] = hard_dice_metric(ev(xd, target=td)["seg"], td).cpu()
+        del ev
+    print(f"whole-volume chain, 16 TTA transforms: hard Dice vs target f32 {dice['fp32'].flatten().tolist()} bf16 {dice['bf16'].flatten().tolist()}")
+    assert float((dice["fp32"] - dice["bf16"]).abs().max()) <= 1e-3, dice
+    m.precision = "auto"
