@@ -209,10 +209,15 @@ extern "C" int BRATS_API(brats_conv3d_tiles_per_sample)(int D, int H, int W) {
   return ceil_div(D, CONV_TZ) * ceil_div(H, CONV_TY) * ceil_div(W, CONV_TX);
 }
 
+bool conv_pre_supported(int ck, int dil, int rows16);                            // conv_bf16_k3_pre.hip
+int conv_pre_launch(const ConvParams& p, int ck, int dil, hipStream_t st);
+
+struct ConvPre { const float* ss1 = nullptr; const float* ss2 = nullptr; int act = 0; float slope = 0.f; bool on = false; };
+
 static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const float* xamax,
                          const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
                          int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
-                         int cout, brats_stream_t s) {
+                         int cout, brats_stream_t s, const ConvPre& pre = ConvPre{}) {
   if (!x1 || !packed_w || !y || c1 <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0)
     BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: null pointer or non-positive size");
   if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: c2 > 0 but x2 is NULL");
@@ -234,6 +239,7 @@ static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int
   p.x1 = x1; p.x2 = x2; p.c1 = c1; p.c2 = c2; p.p1 = pitch1; p.p2 = pitch2;
   p.wpk = packed_w; p.bias = bias; p.y = y; p.ypitch = ypitch; p.stats = stats;
   p.y2 = y2; p.y2pitch = y2pitch; p.ysplit = ysplit; p.xamax = xamax;
+  p.ss1 = pre.ss1; p.ss2 = pre.ss2; p.pre_act = pre.act; p.pre_slope = pre.slope;
   if (y2) {
     const ConvTileChoice tc = conv_choose_tile(ceil_div(cout, 16));
     if (ysplit <= 0 || ysplit >= cout || ysplit % (tc.nf * 16) || y2pitch % 4)
@@ -247,6 +253,7 @@ static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int
 #endif
   hipStream_t st = (hipStream_t)s;
   if (ksize == 1) dil = 1;
+  if (pre.on) return conv_pre_launch(p, ck, dil, st);
 #define GO(T) \
   if (ksize == 3 && dil == 1) return conv_launch<T, 3, 1>(p, ck, st); \
   if (ksize == 3 && dil == 2) return conv_launch<T, 3, 2>(p, ck, st); \
@@ -269,6 +276,27 @@ extern "C" int BRATS_API(brats_conv3d_fwd)(const void* x1, int c1, int pitch1, c
                                 int cout, brats_stream_t s) {
   return conv_fwd_impl(x1, c1, pitch1, x2, c2, pitch2, nullptr, packed_w, bias, y, ypitch, y2, y2pitch, ysplit, stats, dtype, ksize,
                        dil, N, D, H, W, cout, s);
+}
+
+extern "C" int BRATS_API(brats_conv3d_pre_ok)(int dtype, int ksize, int dil, int c1, int c2, int cout) {
+  if (dtype != BRATS_BF16 || ksize != 3 || cout <= 0) return 0;
+  const int ck = BRATS_API(brats_conv3d_chunk)(dtype, ksize, dil, c1, c2, cout);
+  return ck > 0 && conv_pre_supported(ck, dil, ceil_div(cout, 16)) ? 1 : 0;
+}
+
+extern "C" int BRATS_API(brats_conv3d_fwd_pre)(const void* x1, int c1, int pitch1, const float* ss1, const void* x2, int c2, int pitch2,
+                                    const float* ss2, int act, float slope, const void* packed_w, const float* bias, void* y,
+                                    int ypitch, float* stats, int dtype, int dil, int N, int D, int H, int W, int cout,
+                                    brats_stream_t s) {
+  if (dtype != BRATS_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd_pre: 16-bit activations only");
+  if (act != BRATS_ACT_RELU && act != BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd_pre: relu / leakyrelu only (act %d)", act);
+  if (!ss1 && !ss2) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd_pre: neither source has a scale / shift table (use brats_conv3d_fwd)");
+  if (((size_t)ss1 | (size_t)ss2) & 15) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd_pre: scale / shift tables must be 16-byte aligned");
+  if (c1 % 8 || (c2 > 0 && c2 % 8)) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd_pre: channel counts must be multiples of 8");
+  ConvPre pre;
+  pre.ss1 = ss1; pre.ss2 = ss2; pre.act = act; pre.slope = slope; pre.on = true;
+  return conv_fwd_impl(x1, c1, pitch1, x2, c2, pitch2, nullptr, packed_w, bias, y, ypitch, nullptr, 0, 0, stats, dtype, 3, dil, N, D, H,
+                       W, cout, s, pre);
 }
 
 extern "C" int BRATS_API(brats_conv3d_x3_fwd)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,

@@ -27,6 +27,9 @@ struct ConvParams {
   int N, D, H, W, cout, rows16, nchunks;
   int tz, ty, tx;
   const float* xamax;  // split-precision kernels only (conv_igemm_x3.hpp): device scalar max|x| -> input scale; NULL = 1
+  // PRE kernels only ("normalise + activate on load", inference): per-(sample, channel) {scale, shift} of source 1 / 2 (NULL =
+  // that source is read as it is), applied to every staged value as act(x * scale + shift) before it enters LDS
+  const float* ss1; const float* ss2; int pre_act; float pre_slope;
 #ifdef BRATS_VS8_STAMPS
   long long* stamps;  // diagnostic build only
 #endif
@@ -191,8 +194,46 @@ DEVI float row16_sum(float x) {
   return x;
 }
 
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false>
+// ---- normalise + activate on load (PRE kernels) ------------------------------------------------------------------------
+// Under no_grad nobody but the next convolution reads z = act(GroupNorm(y)) of a layer inside a block: the consumer then
+// stages the RAW convolution output y and applies the producer's per-(sample, channel) affine map and activation between the
+// global load and the LDS write -- z is never stored, the affine_act pass (a read + a write of the whole tensor) is gone.
+// Voxels outside the volume must enter LDS as ZERO (the padding of z, not act(shift)): `ok`.  The arithmetic is
+// affine_act_kernel's (norm.hip: multiply, add, max / select in f32, one rounding to the 16-bit type), so the staged values
+// are bit-identical to the stored z.  relu / leakyrelu only (the published configurations).
+DEVI u32x4 conv_pre_apply(u32x4 v, const float (&sc)[8], const float (&sh)[8], bool leaky, float slope, bool ok) {
+  const uint32_t w[4] = {v[0], v[1], v[2], v[3]};  // (through scalars: see f8_quant8)
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a, b;
+    unpack2(w[i], a, b);
+    a = a * sc[2 * i] + sh[2 * i];
+    b = b * sc[2 * i + 1] + sh[2 * i + 1];
+    if (leaky) {
+      a = a > 0.f ? a : a * slope;
+      b = b > 0.f ? b : b * slope;
+    } else {
+      a = __builtin_fmaxf(a, 0.f);
+      b = __builtin_fmaxf(b, 0.f);
+    }
+    o[i] = ok ? pack2(a, b) : 0u;
+  }
+  return u32x4{o[0], o[1], o[2], o[3]};
+}
+// the 8 {scale, shift} pairs of the piece a lane stages: channels cb + 8 part .. + 7 of sample n (ss = [N][C][2] f32)
+DEVI void conv_pre_load(const float* ss, int n, int csrc, int cb, int part, float (&sc)[8], float (&sh)[8]) {
+  const f32x4* q = (const f32x4*)(ss + ((size_t)n * csrc + cb + part * 8) * 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 t = q[i];
+    sc[2 * i] = t[0]; sh[2 * i] = t[1]; sc[2 * i + 1] = t[2]; sh[2 * i + 1] = t[3];
+  }
+}
+
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+  static_assert(!PRE || std::is_same<T, bf16_t>::value, "normalise-on-load exists for the 16-bit kernels");
   using G = ConvGeom<T, KS, CK, DIL>;
   using TL = ConvTile<NF, KSPLIT, VS>;
   constexpr int NB = TL::NB, YB = NB / 2;
@@ -276,13 +317,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         r[k][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
       }
     }
+    // PRE (normalise + activate on load): this chunk's {scale, shift} of the lane's channels, requested behind the halo loads
+    float psc[PRE ? IPR : 1][8], psh[PRE ? IPR : 1][8];
+    const float* pre_ss = nullptr;
+    if constexpr (PRE) {
+      pre_ss = c0 < p.c1 ? p.ss1 : p.ss2;  // scalar: NULL = this source is read as it is
+      if (pre_ss) {
+        const int csrc = c0 < p.c1 ? p.c1 : p.c2, cb = c0 < p.c1 ? c0 : c0 - p.c1;
+#pragma unroll
+        for (int j = 0; j < IPR; ++j) conv_pre_load(pre_ss, n, csrc, cb, hx_part[j] >= 0 ? hx_part[j] & 0xffff : 0, psc[j], psh[j]);
+      }
+    }
     if (chunk > 0) __syncthreads();  // all waves finished reading the previous chunk's tile
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
       if (wave + 4 * k < NROWS) {
 #pragma unroll
         for (int j = 0; j < IPR; ++j)
-          if (lds_off[j] >= 0) *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = r[k][j];
+          if (lds_off[j] >= 0) {
+            u32x4 val = r[k][j];
+            if constexpr (PRE) {
+              if (pre_ss) {  // piece by piece, right in front of its LDS write: the staged registers die as they are consumed
+                const int row = wave + 4 * k;
+                const int gz = z0 - G::R + row / G::HY, gy = y0 - G::R + row % G::HY;
+                const bool row_ok = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
+                val = conv_pre_apply(val, psc[j], psh[j], p.pre_act == BRATS_ACT_LEAKY, p.pre_slope, row_ok && hx_part[j] >= 0);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = val;
+          }
       }
     }
     __syncthreads();
@@ -452,10 +516,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------------
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false>
 int conv_launch_one(const ConvParams& p, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT, VS>();
-  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS>;
+  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS, PRE>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT, VS>::NFW));
@@ -483,7 +547,7 @@ static inline ConvTileChoice conv_choose_tile(int rows16) {
   return {1, true, 1};
 }
 
-template <typename T, int KS, int CK, int DIL>
+template <typename T, int KS, int CK, int DIL, bool PRE = false>
 int conv_launch_ck(const ConvParams& p, hipStream_t st) {
   const ConvTileChoice t = conv_choose_tile(p.rows16);
   if (t.nf == 3 && !t.ksplit) {
@@ -491,17 +555,17 @@ int conv_launch_ck(const ConvParams& p, hipStream_t st) {
     // workgroup) double the grid at the price of staging each halo tile twice
     if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled() &&
         (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 6) < conv_small_grid_threshold())
-      return conv_launch_one<T, KS, CK, DIL, 3, false, true>(p, st);
-    return conv_launch_one<T, KS, CK, DIL, 3, false>(p, st);
+      return conv_launch_one<T, KS, CK, DIL, 3, false, true, PRE>(p, st);
+    return conv_launch_one<T, KS, CK, DIL, 3, false, false, PRE>(p, st);
   }
   if (t.nf == 3 && t.ksplit) {
     // Cout = 48 (mod 96): the y-split roles (no K reduction, shared epilogue) for bf16; K-split stays for f32 / opt-out
-    if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled()) return conv_launch_one<T, KS, CK, DIL, 3, false, true>(p, st);
-    return conv_launch_one<T, KS, CK, DIL, 3, true>(p, st);
+    if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled()) return conv_launch_one<T, KS, CK, DIL, 3, false, true, PRE>(p, st);
+    return conv_launch_one<T, KS, CK, DIL, 3, true, false, PRE>(p, st);
   }
-  if (t.nf == 2 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, false>(p, st);
-  if (t.nf == 2 && t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, true>(p, st);
-  return conv_launch_one<T, KS, CK, DIL, 1, true>(p, st);
+  if (t.nf == 2 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, false, false, PRE>(p, st);
+  if (t.nf == 2 && t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, true, false, PRE>(p, st);
+  return conv_launch_one<T, KS, CK, DIL, 1, true, false, PRE>(p, st);
 }
 
 // implemented in conv_<dtype>_k<KS>_d<DIL>.hip (one translation unit each, for parallel builds)

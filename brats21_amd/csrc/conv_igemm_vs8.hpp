@@ -155,7 +155,8 @@ DEVI void vs8_epilogue_stats(const ConvParams& p, int ty4, const float* sred, in
 
 // (Three workgroups per CU -- a 168-register build on a ring form of the MMA loop -- measured 0.39 -> 0.57 ms in round 3:
 // scripts/probes/experiments/conv_igemm_ld.hpp keeps that loop.)
-template <int CK, int DIL, int NF>
+// PRE: normalise + activate on load (inference; conv_igemm.hpp: conv_pre_apply)
+template <int CK, int DIL, int NF, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
   using T = bf16_t;
   using G = ConvGeom<T, 3, CK, DIL, VS8_TY>;
@@ -231,6 +232,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
       }
     }
     VS8_STAMP(0);  // prologue / issue of the halo loads
+    // PRE (normalise + activate on load): this chunk's {scale, shift} of the lane's channels, requested behind the halo loads
+    float psc[PRE ? IPR : 1][8], psh[PRE ? IPR : 1][8];
+    const float* pre_ss = nullptr;
+    if constexpr (PRE) {
+      pre_ss = c0 < p.c1 ? p.ss1 : p.ss2;  // scalar: NULL = this source is read as it is
+      if (pre_ss) {
+        const int csrc = c0 < p.c1 ? p.c1 : p.c2, cb = c0 < p.c1 ? c0 : c0 - p.c1;
+#pragma unroll
+        for (int j = 0; j < IPR; ++j) conv_pre_load(pre_ss, n, csrc, cb, hx_part[j] >= 0 ? hx_part[j] & 0xffff : 0, psc[j], psh[j]);
+      }
+    }
     if (chunk > 0) __syncthreads();
     VS8_STAMP(1);  // barrier: everybody done with the previous chunk
 #ifdef BRATS_VS8_STAMPS
@@ -242,7 +254,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
       if (wave + 4 * k < NROWS) {
 #pragma unroll
         for (int j = 0; j < IPR; ++j)
-          if (lds_off[j] >= 0) *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = r[k][j];
+          if (lds_off[j] >= 0) {
+            u32x4 val = r[k][j];
+            if constexpr (PRE) {
+              if (pre_ss) {  // piece by piece, right in front of its LDS write: the staged registers die as they are consumed
+                const int row = wave + 4 * k;
+                const int gz = z0 - G::R + row / G::HY, gy = y0 - G::R + row % G::HY;
+                const bool row_ok = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
+                val = conv_pre_apply(val, psc[j], psh[j], p.pre_act == BRATS_ACT_LEAKY, p.pre_slope, row_ok && hx_part[j] >= 0);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = val;
+          }
       }
     }
     __syncthreads();
@@ -277,10 +301,10 @@ static inline int conv_vs8_mode() {
   return v;
 }
 
-template <int CK, int DIL, int NF>
+template <int CK, int DIL, int NF, bool PRE = false>
 int conv_launch_vs8(const ConvParams& p0, hipStream_t st) {
   constexpr int lds = conv_vs8_lds_bytes<CK, DIL, NF>();
-  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF>;
+  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF, PRE>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   ConvParams p = p0;

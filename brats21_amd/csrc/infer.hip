@@ -58,6 +58,34 @@ __global__ void sw_accumulate_kernel(const float* __restrict__ prob, const float
   }
 }
 
+// The same for ALL windows of a predictor batch in ONE launch (the per-window form needs one launch per window because
+// overlapping windows would race): output-centric -- a thread owns one voxel of the padded image and adds the windows that
+// cover it in window order, i.e. in exactly the order (and with exactly the operations) of B per-window launches.
+__global__ void sw_accumulate_multi_kernel(const float* __restrict__ prob, const float* __restrict__ imp, float* __restrict__ out,
+                                           float* __restrict__ cnt, const int* __restrict__ win, int B, int NB, int K, int Dp, int Hp,
+                                           int Wp, int rd, int rh, int rw) {
+  const size_t total = (size_t)NB * K * Dp * Hp * Wp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    size_t t = i;
+    const int x = t % Wp; t /= Wp;
+    const int y = t % Hp; t /= Hp;
+    const int z = t % Dp; t /= Dp;
+    const int k = t % K;
+    const int n = (int)(t / K);
+    float o = 0.f, c = 0.f;
+    bool hit = false;
+    for (int b = 0; b < B; ++b) {
+      const int wz = z - win[b * 4 + 1], wy = y - win[b * 4 + 2], wx = x - win[b * 4 + 3];
+      if (win[b * 4] != n || (unsigned)wz >= (unsigned)rd || (unsigned)wy >= (unsigned)rh || (unsigned)wx >= (unsigned)rw) continue;
+      if (!hit) { o = out[i]; c = cnt[i]; hit = true; }
+      const float w = imp[((size_t)wz * rh + wy) * rw + wx];
+      o += w * prob[((((size_t)b * K + k) * rd + wz) * rh + wy) * rw + wx];
+      c += w;
+    }
+    if (hit) { out[i] = o; cnt[i] = c; }
+  }
+}
+
 // dst[n][k][z][y][x] = out[n][k][z+pz][y+py][x+px] / cnt[...]   (inferers.py:154-162)
 __global__ void sw_finalize_kernel(const float* __restrict__ out, const float* __restrict__ cnt, float* __restrict__ dst,
                                    size_t NK, int Dp, int Hp, int Wp, int D, int H, int W, int pz, int py, int px) {
@@ -113,6 +141,16 @@ extern "C" int brats_sw_accumulate(const float* prob, const float* importance, f
     BRATS_FAIL(BRATS_E_ARG, "sw_accumulate: window outside the (padded) image");
   hipLaunchKernelGGL(sw_accumulate_kernel, dim3(igrid((size_t)K * rd * rh * rw)), dim3(256), 0, (hipStream_t)s, prob, importance,
                      out, count, K, Dp, Hp, Wp, rd, rh, rw, n, z0, y0, x0);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int brats_sw_accumulate_multi(const float* prob, const float* importance, float* out, float* count, const int* windows,
+                                         int B, int NB, int K, int Dp, int Hp, int Wp, int rd, int rh, int rw, brats_stream_t s) {
+  if (!prob || !importance || !out || !count || !windows || B <= 0 || NB <= 0 || K <= 0 || rd > Dp || rh > Hp || rw > Wp)
+    BRATS_FAIL(BRATS_E_ARG, "sw_accumulate_multi: bad argument");
+  hipLaunchKernelGGL(sw_accumulate_multi_kernel, dim3(igrid((size_t)NB * K * Dp * Hp * Wp)), dim3(256), 0, (hipStream_t)s, prob,
+                     importance, out, count, windows, B, NB, K, Dp, Hp, Wp, rd, rh, rw);
   BRATS_CHECK_LAUNCH();
   return 0;
 }

@@ -199,10 +199,9 @@ def sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, overlap
             k = prob.shape[1]
             out = torch.zeros((nb, k) + image_size, dtype=torch.float32, device=x.device)
             cnt = torch.zeros_like(out)
-        for j in range(b):
-            n, z0, y0, x0 = (idx for idx in ([(g0 + j) // num_win] + list(starts[(g0 + j) % num_win])))
-            _lib.check(lib.brats_sw_accumulate(prob[j].data_ptr(), imp.data_ptr(), out.data_ptr(), cnt.data_ptr(), k,
-                                               *image_size, *roi, n, z0, y0, x0, stream), "sw_accumulate")
+        # all windows of the batch in one launch (output-centric, windows added in order: bit-identical to one launch per window)
+        _lib.check(lib.brats_sw_accumulate_multi(prob.data_ptr(), imp.data_ptr(), out.data_ptr(), cnt.data_ptr(),
+                                                 win_tbl[g0:g0 + b].data_ptr(), b, nb, k, *image_size, *roi, stream), "sw_accumulate_multi")
     res = torch.empty((nb, k) + image_size_, dtype=torch.float32, device=x.device)
     _lib.check(lib.brats_sw_finalize(out.data_ptr(), cnt.data_ptr(), res.data_ptr(), nb * k, *image_size, *image_size_, *pad,
                                      stream), "sw_finalize")

@@ -121,7 +121,7 @@ def _unit_act(unit, act):
     return act, None
 
 
-def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False):
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False, lazy=False):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
     -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
     x recorded); the normalise+act pass records the |max| of its own output for the next layer."""
@@ -129,6 +129,12 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
     cout = w.shape[0]
     cin_pad = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
     c1 = x.shape[-1] if x2 is not None else None
+    if isinstance(x, ops.Pending) or isinstance(x2, ops.Pending):
+        # inference: an input whose normalised activation was never stored -- applied on load where that form of the
+        # convolution is built for this layer, materialised (the affine_act pass) otherwise
+        if fp8 or not ops.conv_pre_ok(dtype, 3, unit.dilation, x.shape[-1], x2.shape[-1] if x2 is not None else 0, cout):
+            x = x.materialize() if isinstance(x, ops.Pending) else x
+            x2 = x2.materialize() if isinstance(x2, ops.Pending) else x2
     if _f8_ok(fp8, dtype, x, x2):
         wpk = ops.pack_weights_f8(w, PACK_FWD, cin_pad=cin_pad, c1=c1)
         y, stats = ops.conv3d_f8(x, wpk, cout, unit.dilation, want_stats=True, x2=x2, amax=getattr(x, "_amax", None),
@@ -142,6 +148,8 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
         return y, (unit, x, x2, y, mean_rstd, scale_shift)
     amax = slots.take() if slots is not None else None
     kact, slope_t = _unit_act(unit, act)
+    if lazy and slope_t is None and kact in ("relu", "leakyrelu") and amax is None and not pool:
+        return ops.Pending(y, scale_shift, kact), None  # (no_grad only: nothing is taped)
     if pool and kact in ("relu", "leakyrelu") and y.numel() * y.element_size() >= (256 << 20):
         # the layer ends an encoder level: normalise + act and the 2x2x2 max pool of the result in one pass -- for tensors
         # beyond the Infinity Cache (the 128^3 level: 188 us against 148 + 85); smaller ones are re-read from the cache by
@@ -270,11 +278,16 @@ class _EquiUnetFn(torch.autograd.Function):
         fp8 = m.conv_fp8 if ops.is16(dtype) else None
         slots = _AmaxSlots(32, dev) if fp8 else None
 
-        will_bwd = any(ctx.needs_input_grad)
+        will_bwd = any(ctx.needs_input_grad) and model._fwd_grad  # (needs_input_grad ignores no_grad)
 
-        def cgr(unit, xin, x2=None, pool=False):
+        # inference (no_grad): the activation between the two units of a block has ONE reader, the block's second
+        # convolution -- it is never stored (ops.Pending: normalise + act applied on load, model.norm_on_load)
+        lazy_ok = (not will_bwd) and (not torch.is_grad_enabled()) and m.norm_on_load and ops.is16(dtype)
+
+        def cgr(unit, xin, x2=None, pool=False, lazy=False):
             # (training: the fused pooling pass also records the arg-max bytes its backward reads)
-            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=("argmax" if will_bwd else True) if pool else False)
+            z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=("argmax" if will_bwd else True) if pool else False,
+                              lazy=lazy and lazy_ok)
             tape.append(rec)
             return z
 
@@ -285,17 +298,18 @@ class _EquiUnetFn(torch.autograd.Function):
         # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
         # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
         # (the last layer of a level writes its activation -- the skip connection -- and the max-pooled tensor in one pass)
-        down1, p1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0), pool=True)
-        down2, p2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, p1), pool=True)
-        down3, p3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, p2), pool=True)
-        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, p3))
+        down1, p1 = cgr(m.encoder1.ConvBnRelu2, cgr(m.encoder1.ConvBnRelu1, x0, lazy=True), pool=True)
+        down2, p2 = cgr(m.encoder2.ConvBnRelu2, cgr(m.encoder2.ConvBnRelu1, p1, lazy=True), pool=True)
+        down3, p3 = cgr(m.encoder3.ConvBnRelu2, cgr(m.encoder3.ConvBnRelu1, p2, lazy=True), pool=True)
+        down4 = cgr(m.encoder4.ConvBnRelu2, cgr(m.encoder4.ConvBnRelu1, p3, lazy=True))
         # bottom (:477-478): dilated block, then conv over cat[down4, bottom]
-        bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4))
+        deep_heads = m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training)
+        bottom = cgr(m.bottom.ConvBnRelu2, cgr(m.bottom.ConvBnRelu1, down4, lazy=True), lazy=not deep_heads)
         bottom_2 = cgr(m.bottom_2, down4, x2=bottom)
         # decoder (:481-486)
-        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, down3, x2=up(bottom_2)))
-        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, down2, x2=up(up3)))
-        u1 = cgr(m.decoder1.ConvBnRelu1, down1, x2=up(up2))
+        up3 = cgr(m.decoder3.ConvBnRelu2, cgr(m.decoder3.ConvBnRelu1, down3, x2=up(bottom_2), lazy=True))
+        up2 = cgr(m.decoder2.ConvBnRelu2, cgr(m.decoder2.ConvBnRelu1, down2, x2=up(up3), lazy=True))
+        u1 = cgr(m.decoder1.ConvBnRelu1, down1, x2=up(up2), lazy=True)
         # the last layer's activation up1 feeds only the output head: where the kernels for it are built, the head reads
         # the raw convolution output and applies GroupNorm + act on load (ops.gn_head), the backward recomputes what it
         # needs (ops.gn_act_bwd_head) -- up1 (2 x 403 MB written + read at 2 x 48 x 128^3) is never stored
@@ -314,7 +328,7 @@ class _EquiUnetFn(torch.autograd.Function):
         ctx.top_fused = fuse_top
         ctx.out_shape = tuple(outs[0].shape)
         heads = [(m.outconv, up1, 1)]
-        if m.deep_supervision and not (m.skip_deep_heads_in_eval and not m.training):
+        if deep_heads:
             for hd, src, sc in ((m.deep_bottom[0], bottom, 8), (m.deep_bottom2[0], bottom_2, 8), (m.deep3[0], up3, 4),
                                 (m.deep2[0], up2, 2)):
                 outs.append(ops.head(src, hd.weight, hd.bias, sc))
@@ -426,6 +440,9 @@ class EquiUnet(_PackedWeightsModule):
         # when the activations are bf16 (BASELINE.json configs[4]); the weight gradients stay bf16
         self.conv_fp8 = None
         self.skip_deep_heads_in_eval = False
+        # inference (no_grad, 16-bit): the activation between the two convolutions of a block is applied on load by the second
+        # one and never stored (ops.Pending / brats_conv3d_fwd_pre); BRATS_NORM_ON_LOAD=0: the two-pass path, for A/B runs
+        self.norm_on_load = os.environ.get("BRATS_NORM_ON_LOAD", "1") != "0"
         # weight gradients on a second HIP stream (they depend only on dy and the saved input).  Off: measured 16.40 ->
         # 16.63 ms / step same-box -- the all-taps kernel owns a CU's whole LDS, so the two streams only take CUs from
         # each other, and the tails they could fill are shorter than the interference they add
@@ -497,6 +514,7 @@ class EquiUnet(_PackedWeightsModule):
         if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
             raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
         params = tuple(self.parameters())
+        self._fwd_grad = torch.is_grad_enabled()  # (inside autograd.Function.forward grad mode is always off)
         self._weights_may_have_changed()
         if self.training and self.pack_plan and torch.is_grad_enabled():
             ops.plan_for(self, x.device)  # all layers' weights (forward + dgrad layouts) packed by one launch

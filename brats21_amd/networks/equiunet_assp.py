@@ -288,7 +288,7 @@ class _AsspFn(torch.autograd.Function):
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if (ops.is16(dtype) or ops.x3_active()) else 4)
-        will_bwd = any(ctx.needs_input_grad)
+        will_bwd = any(ctx.needs_input_grad) and model._fwd_grad  # (needs_input_grad ignores no_grad)
 
         def pool(t):  # max and average of a 2x2x2 cell never exceed the |max| of the input
             # (training: the arg-max bytes go along, the pooling backward reads them instead of the window)
@@ -482,6 +482,7 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
             raise BratsHipError("brats21_amd.EquiUnetASSPEvo runs on the GPU only (no CPU fallback)")
         if x.dim() != 5 or x.shape[1] != 4 or any(s % 8 for s in x.shape[2:]):
             raise ValueError("expected input [N, 4, D, H, W] with D, H, W divisible by 8")
+        self._fwd_grad = torch.is_grad_enabled()  # (inside autograd.Function.forward grad mode is always off)
         self._weights_may_have_changed()
         if self.training and self.pack_plan and torch.is_grad_enabled():
             ops.plan_for(self, x.device)  # all layers' weights (forward + dgrad layouts) packed by one launch

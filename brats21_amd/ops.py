@@ -451,7 +451,60 @@ def tiles_per_sample(d, h, w):
     return _lib.lib().brats_conv3d_tiles_per_sample(d, h, w)
 
 
+class Pending:
+    """z = act(y * scale + shift) that has NOT been stored: the raw convolution output `y` of a ConvBnRelu unit plus what
+    its consumer needs to apply the normalisation + activation on load (conv3d(pre=...), include/brats_hip.h:
+    brats_conv3d_fwd_pre), or to materialise it after all (``materialize()`` = the affine_act pass)."""
+
+    def __init__(self, y, scale_shift, act, slope=0.01):
+        self.y, self.scale_shift, self.act, self.slope = y, scale_shift, act, slope
+        self.shape, self.dtype, self.device = y.shape, y.dtype, y.device
+
+    def materialize(self):
+        return affine_act(self.y, self.scale_shift, self.act, slope=self.slope)
+
+
+def conv_pre_ok(dtype, ksize, dil, c1, c2, cout):
+    """Is the normalise-on-load form of the convolution built for this layer?  (16-bit, 3x3x3, dilation 1, Cout % 48 == 0)"""
+    return is16(dtype) and bool(_lib.lib().brats_conv3d_pre_ok(_code(dtype), ksize, dil, c1, c2, cout))
+
+
 def conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False, x2=None, split=None, amax=None):
+    if isinstance(x, Pending) or isinstance(x2, Pending):
+        return _conv3d_pre(x, packed_w, cout, ksize, dil, bias, out, want_stats, x2)
+    return _conv3d(x, packed_w, cout, ksize, dil, bias, out, want_stats, x2, split, amax)
+
+
+def _conv3d_pre(x, packed_w, cout, ksize, dil, bias, out, want_stats, x2):
+    """conv3d whose input(s) are Pending activations: normalise + act applied while the halo tile is staged."""
+    p1 = x if isinstance(x, Pending) else None
+    p2 = x2 if isinstance(x2, Pending) else None
+    xa = p1.y if p1 is not None else x
+    xb = p2.y if p2 is not None else x2
+    if p1 is not None and p2 is not None and (p1.act != p2.act or p1.slope != p2.slope):
+        raise _lib.BratsHipError("conv3d: the two pending inputs carry different activations")
+    act, slope = (p1 or p2).act, (p1 or p2).slope
+    ptr, c, p = _desc(xa)
+    n, d, h, w, _ = xa.shape
+    ptr2, c2, pp2 = (None, 0, 0)
+    if xb is not None:
+        ptr2, c2, pp2 = _desc(xb)
+    if out is None:
+        out = new_act(n, d, h, w, cout, xa.dtype, xa.device)
+    optr, oc, op = _desc(out)
+    if oc != cout or out.dtype != xa.dtype:
+        raise _lib.BratsHipError("conv3d: bad output tensor")
+    stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=xa.device) if want_stats else None
+    with _span("conv_igemm", c + c2, cout, ksize, dil, n, d, h, w, str(xa.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_fwd_pre(ptr, c, p, p1.scale_shift.data_ptr() if p1 is not None else None, ptr2, c2, pp2,
+                                                   p2.scale_shift.data_ptr() if p2 is not None else None, ACTS[act], float(slope),
+                                                   packed_w.data_ptr(), _f32(bias), optr, op,
+                                                   stats.data_ptr() if stats is not None else None, _code(xa.dtype), dil, n, d, h, w,
+                                                   cout, _stream()), "conv3d_fwd_pre")
+    return out, stats
+
+
+def _conv3d(x, packed_w, cout, ksize=3, dil=1, bias=None, out=None, want_stats=False, x2=None, split=None, amax=None):
     """y[N,D,H,W,cout] = conv([x | x2]) with weights from pack_weights().  Returns (y, stats|None) where
     stats = [N, tiles, cout, 2] per-tile per-channel (sum, sum of squares) of the f32 result.
     x2: optional second input (virtual concat, no torch.cat).  split: write output channels

@@ -109,6 +109,17 @@ int brats_conv3d_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2,
                      void* y2, int y2pitch, int ysplit, float* stats,
                      int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                      brats_stream_t s);
+/* "Normalise + activate on load" form of the 16-bit 3x3x3 convolution (inference): the inputs are RAW convolution outputs
+ * of the producing layers; ss1 / ss2 ([N][c1][2] / [N][c2][2] f32 {scale, shift} per sample and channel, as written by
+ * brats_gn_finalize; NULL = that source is read as it is) are applied as z = act(x * scale + shift) -- act BRATS_ACT_RELU or
+ * BRATS_ACT_LEAKY(slope) -- while the halo tile is staged, bit-identical to brats_affine_act_fwd followed by
+ * brats_conv3d_fwd; out-of-volume voxels enter as zeros.  The normalised activation is never stored: for a ConvBnRelu pair
+ * inside a UBlock (networks/equiunet2020.py:105-123) under no_grad that removes one read + one write of the tensor.
+ * brats_conv3d_pre_ok() = 1 where the form is built (Cout a multiple of 48, 48- or 24-channel chunks, dilation 1). */
+int brats_conv3d_pre_ok(int dtype, int ksize, int dil, int c1, int c2, int cout);
+int brats_conv3d_fwd_pre(const void* x1, int c1, int pitch1, const float* ss1, const void* x2, int c2, int pitch2,
+                         const float* ss2, int act, float slope, const void* packed_w, const float* bias, void* y, int ypitch,
+                         float* stats, int dtype, int dil, int N, int D, int H, int W, int cout, brats_stream_t s);
 /* Split-precision form with an input scale (dtype BRATS_X3_F16 / BRATS_X3_BF16 only; 3x3x3): `xamax` (may be NULL = no
  * scaling) is a device scalar holding max|x| of the input -- written by the kernel that produced the tensor
  * (brats_gn_bwd_apply & co., brats_absmax).  The input is multiplied by the power of two that puts |max| into [2^14, 2^15)
@@ -397,6 +408,11 @@ int brats_sw_gather(const float* src, float* dst, const int* windows, int B, int
 int brats_sw_accumulate(const float* prob, const float* importance, float* out, float* count, int K,
                         int Dp, int Hp, int Wp, int rd, int rh, int rw, int n, int z0, int y0, int x0,
                         brats_stream_t s);
+/* the same for all B windows of one predictor batch (`windows` as in brats_sw_gather, prob = [B][K][rd][rh][rw]) in ONE launch:
+ * a thread owns a voxel of the padded image [NB][K][Dp][Hp][Wp] and adds the windows covering it in window order --
+ * bit-identical to B calls of brats_sw_accumulate in that order (overlapping windows cannot share a per-window launch) */
+int brats_sw_accumulate_multi(const float* prob, const float* importance, float* out, float* count, const int* windows,
+                              int B, int NB, int K, int Dp, int Hp, int Wp, int rd, int rh, int rw, brats_stream_t s);
 /* dst = crop(out / count) (inferers.py:154-162) */
 int brats_sw_finalize(const float* out, const float* count, float* dst, int NK, int Dp, int Hp, int Wp,
                       int D, int H, int W, int pad_z, int pad_y, int pad_x, brats_stream_t s);

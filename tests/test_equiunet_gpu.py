@@ -470,3 +470,58 @@ def test_loss_from_deep_heads_only_with_fused_top(name):
     for k, g in grads["0"].items():
         if k in grads["1"]:
             torch.testing.assert_close(grads["1"][k], g, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("act", ["relu", "leakyrelu"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("size,n", [((32, 32, 32), 2), ((40, 24, 16), 1)])
+def test_normalise_on_load_inference_is_bit_identical(act, prec, size, n):
+    """no_grad inference with the activation between the two convolutions of every block applied ON LOAD by the second one
+    (ops.Pending / brats_conv3d_fwd_pre: z is never stored) against the two-pass path (affine_act, then the plain kernel):
+    the staged values are computed by the same f32 operations and rounded once, so the logits must be IDENTICAL -- on a
+    ragged volume too (out-of-volume voxels must enter as zeros, not as act(shift)), with and without the deep heads."""
+    import warnings
+    from brats21_amd import get_model, ops
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = get_model(argparse.Namespace(model="equiunet", width=48, norm="group", act=act, num_classes=3, dropout=0)).cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in m.parameters():  # (negative GroupNorm weights too: the affine map is not monotone)
+            if p.dim() == 1:
+                p.add_(0.5 * torch.randn(p.shape, generator=g).cuda())
+    m.precision = prec
+    x = synth.random_image(n, 4, size, seed=9).cuda()
+    outs = {}
+    with torch.no_grad():
+        for skip in (False, True):
+            m.skip_deep_heads_in_eval = skip
+            for on in (True, False):
+                m.norm_on_load = on
+                o = m(x)
+                outs[(skip, on)] = [t.clone() for t in ([o[0]] + list(o[1]) if isinstance(o, tuple) else [o])]
+    for skip in (False, True):
+        for a, b in zip(outs[(skip, True)], outs[(skip, False)]):
+            assert torch.equal(a, b)
+    assert torch.equal(outs[(True, True)][0], outs[(False, True)][0])
+    # and the fused kernels really ran: one affine_act launch less per block
+    calls = {"n": 0}
+    orig = ops.affine_act
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    ops.affine_act = counting
+    try:
+        with torch.no_grad():
+            m.norm_on_load = True
+            m(x)
+            n_on = calls["n"]
+            m.norm_on_load = False
+            m(x)
+            n_off = calls["n"] - n_on
+    finally:
+        ops.affine_act = orig
+        m.norm_on_load = True
+    assert n_off - n_on >= 8, (n_on, n_off)

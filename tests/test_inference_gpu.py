@@ -139,3 +139,30 @@ def test_sliding_window_batch_size_does_not_change_results():
         y1 = sliding_window_inference(x, (16, 16, 16), 1, m, overlap=0.5)
         y3 = sliding_window_inference(x, (16, 16, 16), 3, m, overlap=0.5)
     assert torch.equal(y1, y3)
+
+
+def test_batched_window_accumulate_is_bit_identical_to_one_launch_per_window():
+    """brats_sw_accumulate_multi (all windows of a predictor batch in one output-centric launch) against the per-window
+    launches it replaces, on overlapping windows over two samples: same additions in the same order -> torch.equal."""
+    from brats21_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    nb, k, img, roi = 2, 3, (20, 24, 28), (12, 16, 16)
+    wins = [(0, 0, 0, 0), (0, 4, 8, 12), (0, 8, 8, 6), (1, 8, 0, 12), (0, 2, 3, 5), (1, 0, 8, 0), (1, 3, 3, 3)]
+    prob = torch.randn((len(wins), k) + roi, generator=g).to(dev)
+    imp = (torch.rand(roi, generator=g) + 0.1).to(dev)
+    base_o = torch.randn((nb, k) + img, generator=g).to(dev)
+    base_c = torch.rand((nb, k) + img, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    o1, c1 = base_o.clone(), base_c.clone()
+    for j, (n, z0, y0, x0) in enumerate(wins):
+        _lib.check(lib.brats_sw_accumulate(prob[j].data_ptr(), imp.data_ptr(), o1.data_ptr(), c1.data_ptr(), k, *img, *roi, n, z0, y0, x0, st),
+                   "sw_accumulate")
+    o2, c2 = base_o.clone(), base_c.clone()
+    tbl = torch.tensor(wins, dtype=torch.int32, device=dev)
+    _lib.check(lib.brats_sw_accumulate_multi(prob.data_ptr(), imp.data_ptr(), o2.data_ptr(), c2.data_ptr(), tbl.data_ptr(), len(wins), nb, k,
+                                             *img, *roi, st), "sw_accumulate_multi")
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(c1, c2)
+    assert not torch.equal(o1, base_o)
