@@ -208,6 +208,10 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
                                            slope_t=slope_t)
     # data-parallel: the weight gradient is written straight into its slice of the all-reduce bucket
     wdst = dest(names[unit.conv.weight]) if dest is not None else None
+    # (model.wgrad_stream = "small": only the 16^3 / 32^3 levels, whose weight-gradient grids are <= 1 workgroup per CU and leave
+    #  most of the chip idle beside the next layer's equally small input-gradient launch)
+    if side is not None and getattr(unit, "_side_small_only", False) and x.shape[1] > 32:
+        side = None
     with ops.side_stream(side, dy, x, x2) as on_side:
         # (the weight gradient depends only on dy and the saved input and nobody but the optimizer waits for it: on the
         # side stream it fills the CUs that the tail of the input-gradient kernel and the small GroupNorm launches leave idle)
@@ -353,6 +357,8 @@ class _EquiUnetFn(torch.autograd.Function):
         # weight gradients on a side stream (model.wgrad_stream); with gradient buckets they stay on the main stream: the
         # buckets' copies and collectives are ordered against it
         side = ops.get_side_stream(douts[0].device) if (m.wgrad_stream and m._grad_sink is None) else None
+        for u in rec:
+            u._side_small_only = m.wgrad_stream == "small"
 
         def cbw(unit, dz, need_dx=True, head=None, pool=None):
             return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head, pool)
@@ -446,7 +452,8 @@ class EquiUnet(_PackedWeightsModule):
         # weight gradients on a second HIP stream (they depend only on dy and the saved input).  Off: measured 16.40 ->
         # 16.63 ms / step same-box -- the all-taps kernel owns a CU's whole LDS, so the two streams only take CUs from
         # each other, and the tails they could fill are shorter than the interference they add
-        self.wgrad_stream = os.environ.get("BRATS_WGRAD_STREAM", "0") != "0"
+        ws = os.environ.get("BRATS_WGRAD_STREAM", "0")
+        self.wgrad_stream = "small" if ws == "small" else ws != "0"
         self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
         self._grad_dest = None  # (ditto: parameter index -> its slice of an all-reduce bucket, or None)
         # training: one multi-tensor weight-packing launch per step (ops.PackPlan).  Off by default here: this network's

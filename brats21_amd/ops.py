@@ -1183,10 +1183,11 @@ def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False, out=None):
 
 
 # ------------------------------------------------------------------------------------------ box calibration
-def probe_box(device=None, mfma_ms=12.0, stream_bytes=403 << 20, modes=(0, 1)):
+def probe_box(device=None, mfma_ms=50.0, stream_bytes=403 << 20, modes=(0, 1)):
     """What THIS box delivers right now on the two resources the rooflines are quoted against (csrc/probe.hip): 16-bit
     MFMA TFLOP/s with every SIMD issuing back to back (two waves per SIMD, like the convolution kernels), and TB/s of a bf16
-    read + write stream over `stream_bytes` (the size of a 2 x 128^3 x 48 activation).  ~40 ms of GPU time, HIP-event timed
+    read + write stream over `stream_bytes` (the size of a 2 x 128^3 x 48 activation).  ~120 ms of GPU time (shorter bursts read +-3 % with the chip's power control; 50 ms per
+    mode repeats to +-0.1 %: scripts/probe_noise.py), HIP-event timed
     on the current stream.
       mfma_TFLOPs       : dense pseudo-random operands -- the matrix rate the chip SUSTAINS (it holds 1.8-2.0 GHz of its
                           nominal 2.4 GHz under this load: sclk_MHz = 16 cycles per MFMA and SIMD); roofline.frac_of_box
