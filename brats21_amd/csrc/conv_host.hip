@@ -22,6 +22,11 @@ extern "C" int BRATS_API(brats_conv3d_chunk)(int dtype, int ksize, int dil, int 
     // split precision (conv_igemm_x3.hpp): hi + lo LDS tiles = the f32 tile's bytes; 24 channels keep two workgroups per CU
     if (ksize != 3) return 0;
     static const int x3[] = {24, 16, 8};
+    // Cout = 48 (mod 96): the y-split roles need 145 VGPRs with 16-channel chunks -- three workgroups per CU (3 x 43 KB of
+    // LDS): 48 -> 48 @2x128^3 1.417 -> 1.372 ms, 96 -> 48 2.376 -> 2.335 (same box, scripts/time_x3_conv.py); the cout-half
+    // roles (Cout >= 96) are faster with 24 (48 -> 96: 2.15 vs 2.19 ms)
+    const int rows16 = ceil_div(cout, 16);
+    if (cout > 0 && rows16 % 3 == 0 && rows16 % 6 != 0 && c1 % 16 == 0 && (c2 <= 0 || c2 % 16 == 0)) return 16;
     for (int i = 0; i < 3; ++i)
       if (c1 % x3[i] == 0 && (c2 <= 0 || c2 % x3[i] == 0)) return x3[i];
     return 0;

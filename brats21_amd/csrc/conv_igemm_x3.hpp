@@ -111,7 +111,7 @@ constexpr int conv_x3_lds_bytes() {
 // wave roles: VS = all four waves compute the same NF*16 couts for a quarter of the tile's voxels (4 x-rows each);
 // !VS = wave (wm, wn) computes cout half wn (NF*16 of the workgroup's 2*NF*16) for z half wm (8 x-rows)
 template <int KS, int CK, int DIL, int NF, bool VS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_kernel(const ConvParams p) {
   using G = ConvGeom<bf16_t, KS, CK, DIL>;
   using TL = ConvTile<NF, false, VS>;
   constexpr int NB = TL::NB, YB = NB / 2;
