@@ -157,17 +157,17 @@ def inference_bench(model, dev, args):
     from brats21_amd.evaluate import Evaluator
     model.eval()
     model.skip_deep_heads_in_eval = True
-    amp = args.precision != "fp32"
+    amp = args.precision not in ("fp32", "x3")
     amp_dtype = torch.float16 if args.precision == "fp16" else torch.bfloat16
     vol = synth.random_image(1, 4, (240, 240, 155), seed=99, device=dev)
     vol = vol * (synth.nested_spheres(1, (240, 240, 155), device=dev)[:, 0:1] > 0)  # zero background outside the "brain"
     fwd_flop = 1995.7e9 if args.model == "equiunet" else 1689.8e9  # per 4x128^3 patch forward
     legs = {}
 
-    def leg(name, transforms, roi, overlap, forwards, flop, what):
+    def leg(name, transforms, roi, overlap, forwards, flop, what, leg_amp=None):
         transforms = list(transforms)
         ev = Evaluator(model, tta_transforms=transforms, sliding_window_size=roi, sw_batch_size=args.sw_batch, overlap=overlap,
-                       k_divisible=8, amp=amp, use_graph=True, amp_dtype=amp_dtype)
+                       k_divisible=8, amp=amp if leg_amp is None else leg_amp, use_graph=True, amp_dtype=amp_dtype)
         with torch.no_grad():
             ev(vol)  # warm-up: lazy init, allocator, graph capture of every patch / volume shape
             torch.cuda.synchronize()
@@ -189,6 +189,15 @@ def inference_bench(model, dev, args):
         f"4x240x240x155 padded to 160 (learning/engine.py:217), window 128^3, overlap 0.5, 18 windows x 8-flip TTA = 144 patch "
         f"forwards ({args.sw_batch} windows per launch), {args.precision}, hipGraph patch step, on-GPU mean + threshold + "
         "background removal + BraTS labels + crop")
+    if amp and not args.fp8:
+        # configs[3] in the 1e-3-logit parity mode: f32 tensors, 3x3x3 convolutions on three fp16-pair MFMA products
+        old_prec, model.precision = model.precision, "x3"
+        try:
+            leg("inference_x3", tta.flip8(), roi, 0.5, 144, 144 * fwd_flop,
+                "the same volume / windows / 8-flip TTA as `inference`, model.precision='x3' (f32 storage, split-precision "
+                "convolutions: stitched logits within 1e-3 of the CPU oracle, tests/test_config3_gpu.py)", leg_amp=False)
+        finally:
+            model.precision = old_prec
     if not args.infer_headline_only:
         leg("inference_ref16", tta.get_tta_transforms(), roi, 0.25, 288, 288 * fwd_flop,
             "same volume, window 128^3, overlap 0.25 (18 windows), the reference's 16 TTA transforms (src/definer.py:647-658) "
@@ -257,8 +266,9 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="patches per GPU")
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--model", default="equiunet")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="fp16 = the reference's own autocast dtype (IEEE half storage) under its GradScaler loop; bf16 is the headline")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "x3"],
+                    help="fp16 = the reference's own autocast dtype (IEEE half storage) under its GradScaler loop; bf16 is the headline; "
+                         "fp32 = exact-f32 MFMA kernels; x3 = f32 storage with split-precision (3 x fp16-pair MFMA) convolutions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 logit parity) timing leg")
     ap.add_argument("--no-infer", action="store_true", help="skip the sliding-window + TTA inference measurement")
@@ -320,7 +330,9 @@ def main():
     size = (args.patch,) * 3
     x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
     t = synth.nested_spheres(args.batch, size, device=dev)
-    use_amp = args.precision != "fp32"
+    use_amp = args.precision not in ("fp32", "x3")
+    if args.precision == "x3":
+        model.precision = "x3"
     amp_dtype = torch.float16 if args.precision == "fp16" else torch.bfloat16
     assert not (args.graph and args.precision == "fp16"), "--graph: the GradScaler's inf check reads the device every step; use bf16"
     train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets, amp_dtype=amp_dtype)
@@ -408,12 +420,14 @@ def main():
       cnt, avg_ms, tot_ms = table[dom_key]
       kind, cin, cout, k, dil, n, d, h, w, dt = dom_key
       fl = conv_flops(cin, cout, k, n, d, h, w)
-      peak = PEAK_FP8_TFLOPS if dt == "e4m3" else (PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS)
+      # (x3: three 16-bit MFMAs per algorithmic product -- the kernel's ceiling is a third of the 16-bit peak)
+      x3 = dt.startswith("x3")
+      peak = PEAK_FP8_TFLOPS if dt == "e4m3" else (PEAK_BF16_TFLOPS / 3 if x3 else (PEAK_BF16_TFLOPS if use_amp else PEAK_F32_TFLOPS))
       achieved = fl / (avg_ms * 1e-3) / 1e12
       # frac_of_box: against the matrix rate this chip SUSTAINED in the probe right before the timed region (dense operands, every
       # SIMD issuing; e4m3 runs at twice, exact f32 at 1/16 of the 16-bit pipe rate) -- comparable across the boxes of a pool,
       # which frac (against the nominal peak at 2.4 GHz) is not
-      box_peak = box["mfma_TFLOPs"] * (2.0 if dt == "e4m3" else (1.0 if use_amp else PEAK_F32_TFLOPS / PEAK_BF16_TFLOPS))
+      box_peak = box["mfma_TFLOPs"] * (2.0 if dt == "e4m3" else (1.0 / 3 if x3 else (1.0 if use_amp else PEAK_F32_TFLOPS / PEAK_BF16_TFLOPS)))
       roofline = {"bound": "mfma", "kernel": f"{kind} cin={cin} cout={cout} k={k} dil={dil} @{n}x{d}x{h}x{w}",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                   "frac_of_box": round(achieved / box_peak, 4),

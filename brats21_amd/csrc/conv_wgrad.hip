@@ -1214,27 +1214,47 @@ static int wgrad_mfma(const void* x1, int c1, int pitch1, const void* x2, int c2
 // hi / lo tensors (dense, 16-bit) into the workspace, the UNCHANGED 16-bit kernels run three times into three groups of
 // split-K slabs, and the one fixed-order reduction sums all of them (bitwise reproducible).  Price: 12 extra bytes of HBM
 // traffic per operand element and three tile stagings instead of one.
+// a thread owns 8 consecutive channels of one voxel (32 B of f32 in, 16 B + 16 B out); two voxels in flight, short-lived
+// blocks, non-temporal loads and stores (the tensors are streamed once; csrc/probe.hip's policy: 6.2 TB/s against 5.5)
 template <int V>
 __global__ void __launch_bounds__(256) x3_split_kernel(const float* __restrict__ src, int pitch, bf16_t* __restrict__ hi,
                                                        bf16_t* __restrict__ lo, size_t voxels, int C, const float* __restrict__ amax) {
-  // a thread owns 8 consecutive channels of one voxel (C % 8 == 0)
   const float sc = amax ? x3_scale_from_amax(*amax) : 1.f;
   const int cv = C / 8;
   const size_t total = voxels * cv;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t vox = i / cv;
-    const int c = (int)(i % cv) * 8;
-    float x[8], h[8], l[8];
-    Vec<float, 4>::load(src + vox * pitch + c, x);
-    Vec<float, 4>::load(src + vox * pitch + c + 4, x + 4);
+  const size_t stride = (size_t)gridDim.x * 256;
+  auto load = [&](size_t i, u32x4& a, u32x4& b) {
+    const float* p = src + (i / cv) * pitch + (i % cv) * 8;
+    a = __builtin_nontemporal_load((const u32x4*)p);
+    b = __builtin_nontemporal_load((const u32x4*)(p + 4));
+  };
+  auto emit = [&](size_t i, const u32x4& a, const u32x4& b) {
+    const uint32_t w[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      x[e] *= sc;
-      h[e] = bf2f(f2bf(x[e]));
-      l[e] = x[e] - h[e];
+    for (int e = 0; e < 4; ++e) {
+      const float x0 = __uint_as_float(w[2 * e]) * sc, x1 = __uint_as_float(w[2 * e + 1]) * sc;
+      h[e] = pack2(x0, x1);
+      float h0, h1;
+      unpack2(h[e], h0, h1);
+      l[e] = pack2(x0 - h0, x1 - h1);
     }
-    Vec<bf16_t, 8>::store(hi + vox * C + c, h);
-    Vec<bf16_t, 8>::store(lo + vox * C + c, l);
+    const size_t o = (i / cv) * C + (i % cv) * 8;
+    __builtin_nontemporal_store(u32x4{h[0], h[1], h[2], h[3]}, (u32x4*)(hi + o));
+    __builtin_nontemporal_store(u32x4{l[0], l[1], l[2], l[3]}, (u32x4*)(lo + o));
+  };
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < total; i += 2 * stride) {
+    u32x4 a0, b0, a1, b1;
+    load(i, a0, b0);
+    load(i + stride, a1, b1);
+    emit(i, a0, b0);
+    emit(i + stride, a1, b1);
+  }
+  if (i < total) {
+    u32x4 a0, b0;
+    load(i, a0, b0);
+    emit(i, a0, b0);
   }
 }
 static size_t x3_align(size_t b) { return (b + 255) / 256 * 256; }
@@ -1253,7 +1273,8 @@ static int wgrad_x3(const void* x1, int c1, int pitch1, const void* x2, int c2, 
   bf16_t* ly = (bf16_t*)b;
   auto split = [&](const void* src, int pitch, bf16_t* hi, bf16_t* lo, int c, const float* amax) {
     const size_t total = vox * (c / 8);
-    const unsigned blocks = (unsigned)(total / 256 < 16384 ? (total + 255) / 256 : 16384);
+    size_t nb = (total + 511) / 512;  // two pieces per thread
+    const unsigned blocks = (unsigned)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
     hipLaunchKernelGGL(x3_split_kernel<0>, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const float*)src, pitch, hi, lo, vox, c, amax);
   };
   split(x1, pitch1, h1, l1, c1, nullptr);

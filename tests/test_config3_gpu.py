@@ -2,9 +2,9 @@
 4x240x240x155 volume, padded to a multiple of 8 like Engine.evaluate (learning/engine.py:217 -> 160), EquiUnet width 48,
 128^3 window, overlap 0.5 (18 windows), with the bench's own volume and the model's own kaiming initialisation:
 
-  (i)   f32 mode, identity TTA: the stitched LOGITS of the HIP path (window gather -> exact-f32 MFMA network -> weighted
-        accumulate -> divide -> crop) against oracle/inference.py + oracle/unet.py on the GPU box's host cores, over the
-        whole volume, within the north-star bar of 1e-3 abs;
+  (i)   f32 mode AND the split-precision mode ("x3"), identity TTA: the stitched LOGITS of the HIP path (window gather ->
+        exact-f32 MFMA / three-fp16-product network -> weighted accumulate -> divide -> crop) against oracle/inference.py +
+        oracle/unet.py on the GPU box's host cores, over the whole volume, within the north-star bar of 1e-3 abs;
   (ii)  the benchmarked configuration (bf16, 8-flip TTA, the Evaluator's full chain down to the thresholded, background-
         removed segmentation): hard Dice against the synthetic target within 1e-3 of the same chain in f32 mode (whose
         network arithmetic (i) has just pinned to the oracle and whose flips (iii) pins to torch.flip);
@@ -92,6 +92,9 @@ def test_config3_stitched_logits_vs_oracle_and_bf16_flip8_dice():
     m.precision = "fp32"
     with torch.no_grad():
         logits = sliding_window_inference(padded, ROI, 3, lambda w: m(w), overlap=0.5)
+        m.precision = "x3"  # the split-precision parity mode (csrc/conv_igemm_x3.hpp) through the same chain
+        logits_x3 = sliding_window_inference(padded, ROI, 3, lambda w: m(w), overlap=0.5)
+        m.precision = "fp32"
         torch.cuda.synchronize()
         calls = []
 
@@ -103,8 +106,10 @@ def test_config3_stitched_logits_vs_oracle_and_bf16_flip8_dice():
     assert sum(calls) == 18  # 3 x 3 x 2 windows
     assert tuple(logits.shape) == tuple(ref.shape) == (1, 3, 240, 240, 160)
     err = float((logits.cpu() - ref).abs().max())
-    print(f"\nconfigs[3] f32 stitched logits vs oracle over {ref.numel()} values: max abs err {err:.3e} (|logits| max {float(ref.abs().max()):.2f})")
-    assert err < 1e-3, err
+    err_x3 = float((logits_x3.cpu() - ref).abs().max())
+    print(f"\nconfigs[3] stitched logits vs oracle over {ref.numel()} values: max abs err f32 {err:.3e}, x3 {err_x3:.3e} "
+          f"(|logits| max {float(ref.abs().max()):.2f})")
+    assert err < 1e-3 and err_x3 < 1e-3, (err, err_x3)
 
     # ---- (ii) the benchmarked chain: bf16 + 8-flip TTA against the same chain in f32 ----
     td = target.to(DEV)
