@@ -216,7 +216,7 @@ def launch_ranks(n, argv, dry_run=False):
     0's one JSON line) and stderr are relayed, its exit code returned.  Called before any HIP call of this process."""
     import socket
     import subprocess
-    if not dry_run:
+    if not dry_run and os.environ.get("BRATS_DIST_BACKEND") != "gloo":  # (gloo: the debugging set-up with ranks sharing a GPU)
         have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
         if have < n:
             print(f"bench.py: --gpus {n} but this node has {have} GPU(s)", file=sys.stderr)
@@ -356,8 +356,14 @@ def main():
     # they are recorded in two of the timed steps only (at 1/3 and 2/3 of the run), inside the timed region
     sample_at = sorted({args.steps // 3, (2 * args.steps) // 3})
     sampled = len(sample_at)
+    def barrier():  # (RCCL: name the device, or ProcessGroupNCCL guesses it from the rank and warns)
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[local])
+        else:
+            dist.barrier()
+
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -367,7 +373,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
     ddp_info = None

@@ -12,6 +12,13 @@ python3 scripts/pmc_report.py final/pmc > $out/pmc_conv.txt
 bash scripts/pmc.sh final/pmc_dom scripts/prof_conv.py dom > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc_dom > $out/pmc_dominant.txt
 python3 scripts/pmc_report.py final/pmc_dom --json "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128" "conv_igemm_vs8_kernel<24, 1, 3, false>" > $out/pmc_dominant.json
+# round 4: the split-precision parity mode as the timed configuration (per-layer table), and the inference leg's kernel statistics
+python3 bench.py --precision x3 --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --kernel-table > $out/bench_x3.json 2> $out/conv_table_x3.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x3 -- python3 bench.py --precision x3 --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > /dev/null 2>&1
+cp $out/stats_x3/*/*kernel_stats.csv $out/bench_x3_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_infer -- python3 scripts/prof_infer.py > /dev/null 2>&1
+cp $out/stats_infer/*/*kernel_stats.csv $out/infer_kernel_stats.csv
+python3 bench.py --model equiunet_assp_evo --precision x3 --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp_x3.json
 python3 bench.py --steps 10 --warmup 3 --fp8 all --no-cpu-baseline 2> /dev/null | tail -1 > $out/bench_fp8.json
 python3 bench.py --steps 10 --warmup 3 --fp8 all --graph --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_fp8_graph.json
 python3 bench.py --model equiunet_assp_evo --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp.json
@@ -25,4 +32,5 @@ PYTHONPATH=. python3 scripts/time_wgrad_f8.py > $out/wgrad_f8_table.txt 2>/dev/n
 python3 bench.py --precision fp16 --steps 10 --warmup 3 --infer-headline-only --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_fp16.json
 python3 bench.py --model equiunet_assp_evo --width 64 --precision fp16 --batch 4 --fp8 all --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_assp64_fp16_fp8_b4.json
 BRATS_FORCE_DDP=1 python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg 2> /dev/null | tail -1 > $out/bench_ddp1_forced.json
+rm -rf $out/stats $out/stats_assp $out/stats_assp64 $out/stats_x3 $out/stats_infer
 tail -c 600 $out/bench.json; echo; cat $out/pmc_conv.txt | cut -c1-250
