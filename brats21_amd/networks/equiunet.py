@@ -38,22 +38,33 @@ class _ConvParams(nn.Module):
 
 
 class _NormParams(nn.Module):
-    def __init__(self, c):
+    """weight / bias of the unit's norm layer; with ``batch`` also nn.BatchNorm3d's buffers (same state-dict names)."""
+
+    def __init__(self, c, batch=False):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(c))
         self.bias = nn.Parameter(torch.zeros(c))
+        if batch:
+            self.register_buffer("running_mean", torch.zeros(c))
+            self.register_buffer("running_var", torch.ones(c))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
 
 class ConvBnRelu(nn.Module):
     """conv3x3x3 (no bias) -> norm -> act -> Dropout(p)   (networks/equiunet2020.py:51-75).  The norm is GroupNorm(8)
     (``--norm group``) or InstanceNorm3d(affine=True) (``--norm instance``, the CLI default; networks/factory.py:
-    179-188): the same kernels with 8 or ``planes`` statistics groups.  ``--act prelu``: MONAI's Act["prelu"] = nn.PReLU()
+    179-188): the same kernels with 8 or ``planes`` statistics groups.  ``--norm batch`` (nn.BatchNorm3d(affine=True),
+    round 4) is the same kernels again: NDHWC is contiguous, so the batch [N, D, H, W, C] viewed as ONE sample
+    [1, N*D, H, W, C] with ``planes`` groups gives exactly the batch statistics (biased variance) in training mode, forward
+    and backward; the running buffers are updated from the finalised mean / rstd, and eval mode builds the per-channel
+    scale / shift from them (_bn_forward_tables).  ``--act prelu``: MONAI's Act["prelu"] = nn.PReLU()
     -- one learnable slope per unit, state-dict key ``<unit>.prelu.weight`` like the reference's nn.Sequential entry."""
 
     def __init__(self, inplanes, planes, dilation=1, norm="group", act="relu"):
         super().__init__()
         self.conv = _ConvParams(inplanes, planes, 3, bias=False)
-        self.bn = _NormParams(planes)
+        self.batch_norm = norm == "batch"
+        self.bn = _NormParams(planes, batch=self.batch_norm)
         if act == "prelu":
             self.prelu = nn.PReLU()
         self.dilation = dilation
@@ -121,7 +132,40 @@ def _unit_act(unit, act):
     return act, None
 
 
-def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False, lazy=False):
+def _one_sample(t):
+    """[N, D, H, W, C] (dense) as one sample [1, N*D, H, W, C]: what turns per-sample statistics into batch statistics."""
+    n, d, h, w, c = t.shape
+    if not t.is_contiguous():
+        raise BratsHipError("--norm batch needs dense activations")
+    return t.view(1, n * d, h, w, c)
+
+
+def _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training):
+    """BatchNorm3d + activation behind the convolution (see ConvBnRelu)."""
+    n, d, h, wd, c = y.shape
+    bn = unit.bn
+    if training:
+        mean_rstd, scale_shift = ops.gn_finalize(stats.view(1, -1, c, 2), 1, c, c, n * d * h * wd, bn.weight.detach(), bn.bias.detach())
+        with torch.no_grad():  # running buffers: momentum 0.1, UNBIASED variance (torch.nn.functional.batch_norm)
+            cnt = float(n * d * h * wd)
+            mean = mean_rstd[0, :, 0]
+            var = (1.0 / mean_rstd[0, :, 1].double() ** 2 - 1e-5).clamp_min(0).float()
+            bn.running_mean.mul_(0.9).add_(mean, alpha=0.1)
+            bn.running_var.mul_(0.9).add_(var, alpha=0.1 * cnt / max(cnt - 1.0, 1.0))
+            bn.num_batches_tracked += 1
+    else:
+        mean_rstd = None
+        scale = bn.weight.detach() * torch.rsqrt(bn.running_var + 1e-5)
+        scale_shift = torch.stack([scale, bn.bias.detach() - bn.running_mean * scale], -1).reshape(1, c, 2).contiguous().float()
+    kact, slope_t = _unit_act(unit, act)
+    z = ops.affine_act(_one_sample(y), scale_shift, kact, slope_t=slope_t).view(n, d, h, wd, c)
+    rec = (unit, x, x2, y, mean_rstd, scale_shift)
+    if pool:
+        return (z, ops.maxpool2(z, want_argmax=pool == "argmax")), rec
+    return z, rec
+
+
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False, lazy=False, training=True):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
     -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
     x recorded); the normalise+act pass records the |max| of its own output for the next layer."""
@@ -143,6 +187,8 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
         wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=c1)
         y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
     n, d, h, wd, _ = y.shape
+    if unit.batch_norm:
+        return _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training)
     mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
     if no_act:  # the last layer under the fused output head (ops.gn_head): the activation is applied on load there
         return y, (unit, x, x2, y, mean_rstd, scale_shift)
@@ -188,7 +234,16 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         grads[names[unit.prelu.weight]] = ops.prelu_slope_grad(dz, y, scale_shift)
         if sink is not None:
             sink(names[unit.prelu.weight], grads[names[unit.prelu.weight]])
-    if head is not None:
+    if unit.batch_norm:
+        if mean_rstd is None:
+            raise NotImplementedError("--norm batch: backward through an eval-mode forward (running statistics) is not implemented")
+        n_, d_, h_, w_, c_ = y.shape
+        dy, dgamma, dbeta = ops.gn_act_bwd(_one_sample(dz), _one_sample(y), scale_shift, mean_rstd, unit.bn.weight.detach(), c_, kact,
+                                           amax=amax, slope_t=slope_t)
+        dy = dy.view(n_, d_, h_, w_, c_)
+        if amax is not None:
+            dy._amax = amax
+    elif head is not None:
         # the last layer: its output feeds only the 1x1x1 head, whose backward is folded into the GroupNorm backward --
         # d(up1) is never written, the head's weight / bias gradients come out of the same passes (ops.gn_act_bwd_head)
         hd, dout = head
@@ -291,7 +346,7 @@ class _EquiUnetFn(torch.autograd.Function):
         def cgr(unit, xin, x2=None, pool=False, lazy=False):
             # (training: the fused pooling pass also records the arg-max bytes its backward reads)
             z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=("argmax" if will_bwd else True) if pool else False,
-                              lazy=lazy and lazy_ok)
+                              lazy=lazy and lazy_ok, training=m.training)
             tape.append(rec)
             return z
 
@@ -319,7 +374,7 @@ class _EquiUnetFn(torch.autograd.Function):
         # needs (ops.gn_act_bwd_head) -- up1 (2 x 403 MB written + read at 2 x 48 x 128^3) is never stored
         kact, slope_t = _unit_act(m.decoder1.ConvBnRelu2, act)
         nk = m.outconv.weight.shape[0]
-        fuse_top = (m.fold_head_fwd and slope_t is None and kact in ("relu", "leakyrelu") and nk <= 4
+        fuse_top = (m.fold_head_fwd and not m.decoder1.ConvBnRelu2.batch_norm and slope_t is None and kact in ("relu", "leakyrelu") and nk <= 4
                     and (not will_bwd or (m.fold_head_bwd and ops.head_fold_ok(m.outconv.weight, kact, slope_t))))
         if fuse_top:
             y1, rec1 = _cgr_fwd(m.decoder1.ConvBnRelu2, u1, dtype, act, None, None, fp8, slots, no_act=True)
@@ -367,7 +422,7 @@ class _EquiUnetFn(torch.autograd.Function):
             """Backward of the last layer of an encoder level: its output gradient = d_skip + max-pool backward(d_pooled)."""
             idx = getattr(down, "_pool_argmax", None)
             kact, slope_t = _unit_act(unit, act)
-            if idx is not None and m.fold_pool_bwd and slope_t is None and kact in ("relu", "leakyrelu"):
+            if idx is not None and m.fold_pool_bwd and not unit.batch_norm and slope_t is None and kact in ("relu", "leakyrelu"):
                 return cbw(unit, None, need_dx, pool=(d_skip, d_pooled, idx))
             return cbw(unit, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip), need_dx)
 
@@ -380,7 +435,7 @@ class _EquiUnetFn(torch.autograd.Function):
                 dout = torch.zeros((ctx.out_shape), dtype=torch.float32, device=douts_device(douts))
             if dout is None:
                 continue
-            if hd is m.outconv and (ctx.top_fused or (m.fold_head_bwd
+            if hd is m.outconv and (ctx.top_fused or (m.fold_head_bwd and not m.decoder1.ConvBnRelu2.batch_norm
                                                        and ops.head_fold_ok(hd.weight, *_unit_act(m.decoder1.ConvBnRelu2, act)))):
                 top = (hd, dout)
                 continue
@@ -427,8 +482,11 @@ class EquiUnet(_PackedWeightsModule):
     def __init__(self, inplanes, num_classes, features, norm_layer=None, act="relu", deep_supervision=False, dropout=0,
                  refinement=False):
         super().__init__()
-        if norm_layer not in ("group", "instance"):
-            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance (got {norm_layer!r})")
+        if norm_layer not in ("group", "instance", "batch"):
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance|batch (got {norm_layer!r}; 'bcn' = the "
+                                      "reference's BCNorm with EstBN is outside the accelerated path)")
+        if norm_layer == "batch" and act == "prelu":
+            raise NotImplementedError("--norm batch with --act prelu is not implemented")
         if act not in ("relu", "leakyrelu", "elu", "prelu", "swish", "mish"):
             raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu|elu|prelu|swish|mish (got {act!r})")
         if dropout:
@@ -489,6 +547,9 @@ class EquiUnet(_PackedWeightsModule):
         for mod in self.modules():
             if isinstance(mod, _ConvParams):
                 nn.init.kaiming_normal_(mod.weight.data, a=0.0, mode="fan_out")
+            elif isinstance(mod, _NormParams) and norm_layer == "batch":  # factory.py:219-221: BatchNorm3d weights ~ N(1, 0.02)
+                nn.init.normal_(mod.weight.data, 1.0, 0.02)
+                nn.init.constant_(mod.bias.data, 0.0)
 
     def _dtype(self):
         if self.precision == "bf16":

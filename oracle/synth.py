@@ -25,7 +25,13 @@ def fill_state_dict(shapes):
     sd = {}
     for k, shp in shapes.items():
         leaf = k.rsplit(".", 1)[-1]
-        if leaf in ("v", "running_var"):
+        if k.endswith("bn.running_var"):      # nn.BatchNorm3d buffers (--norm batch): positive, not all ones
+            sd[k] = closed_form(k, shp, 0.2, 1.0)
+        elif k.endswith("bn.running_mean"):
+            sd[k] = closed_form(k, shp, 0.05, 0.0)
+        elif leaf == "num_batches_tracked":
+            sd[k] = torch.tensor(0, dtype=torch.long)
+        elif leaf in ("v", "running_var"):
             sd[k] = torch.ones(shp)
         elif leaf == "gamma" or k.endswith("bn.weight"):
             sd[k] = closed_form(k, shp, 0.15, 1.0)

@@ -38,25 +38,32 @@ def _act(x, act, slope=None):
     raise ValueError(act)
 
 
-def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group"):
+def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group", training=True, new_stats=None):
     """ConvBnRelu, networks/equiunet2020.py:51-75: conv3x3x3 (no bias, pad=dil) -> norm -> act -> Dropout(p=0)
     (identity).  norm "group" = GroupNorm(8, C, affine), "instance" = InstanceNorm3d(C, affine=True) (the CLI
-    default, src/arguments_train.py:48) = per-(sample, channel) statistics, biased variance, eps 1e-5
-    (networks/factory.py:179-188)."""
+    default, src/arguments_train.py:48) = per-(sample, channel) statistics, biased variance, eps 1e-5, "batch" =
+    BatchNorm3d(C, affine=True) (networks/factory.py:179-188): batch statistics in training mode (momentum 0.1 update of the
+    running buffers, unbiased variance there), the running buffers in eval mode.  The oracle is pure: the updated buffers
+    of a training-mode call are returned through ``new_stats`` ({key: tensor}) instead of being written into ``sd``."""
     y = F.conv3d(x, sd[pre + ".conv.weight"], None, 1, dilation, dilation)
     if norm == "group":
         y = F.group_norm(y, 8, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], 1e-5)
     elif norm == "instance":
         y = F.instance_norm(y, None, None, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], True, 0.1, 1e-5)
+    elif norm == "batch":
+        rm, rv = sd[pre + ".bn.running_mean"].detach().clone().to(y.dtype), sd[pre + ".bn.running_var"].detach().clone().to(y.dtype)
+        y = F.batch_norm(y, rm, rv, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], training, 0.1, 1e-5)
+        if training and new_stats is not None:
+            new_stats[pre + ".bn.running_mean"], new_stats[pre + ".bn.running_var"] = rm, rv
     else:
         raise ValueError(norm)
     return _act(y, act, sd.get(pre + ".prelu.weight"))
 
 
-def ublock(sd, pre, x, dilation=(1, 1), act="relu", norm="group"):
+def ublock(sd, pre, x, dilation=(1, 1), act="relu", norm="group", training=True, new_stats=None):
     """UBlock, networks/equiunet2020.py:105-123."""
-    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act, norm)
-    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act, norm)
+    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act, norm, training, new_stats)
+    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act, norm, training, new_stats)
 
 
 def _up(x, s):
@@ -69,17 +76,19 @@ def _c1(sd, pre, x):
     return F.conv3d(x, sd[pre + ".weight"], sd[pre + ".bias"])
 
 
-def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group"):
-    """EquiUnet.forward, networks/equiunet2020.py:467-500. Returns (logits, [4 deep heads])."""
-    down1 = ublock(sd, "encoder1", x, act=act, norm=norm)
-    down2 = ublock(sd, "encoder2", F.max_pool3d(down1, 2, 2), act=act, norm=norm)
-    down3 = ublock(sd, "encoder3", F.max_pool3d(down2, 2, 2), act=act, norm=norm)
-    down4 = ublock(sd, "encoder4", F.max_pool3d(down3, 2, 2), act=act, norm=norm)
-    bottom = ublock(sd, "bottom", down4, (2, 2), act, norm)
-    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act, norm)
-    up3 = ublock(sd, "decoder3", torch.cat([down3, _up(bottom_2, 2)], 1), act=act, norm=norm)
-    up2 = ublock(sd, "decoder2", torch.cat([down2, _up(up3, 2)], 1), act=act, norm=norm)
-    up1 = ublock(sd, "decoder1", torch.cat([down1, _up(up2, 2)], 1), act=act, norm=norm)
+def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group", training=True, new_stats=None):
+    """EquiUnet.forward, networks/equiunet2020.py:467-500. Returns (logits, [4 deep heads]).  training / new_stats: only
+    --norm batch distinguishes the two modes (conv_gn_act)."""
+    kw = dict(act=act, norm=norm, training=training, new_stats=new_stats)
+    down1 = ublock(sd, "encoder1", x, **kw)
+    down2 = ublock(sd, "encoder2", F.max_pool3d(down1, 2, 2), **kw)
+    down3 = ublock(sd, "encoder3", F.max_pool3d(down2, 2, 2), **kw)
+    down4 = ublock(sd, "encoder4", F.max_pool3d(down3, 2, 2), **kw)
+    bottom = ublock(sd, "bottom", down4, (2, 2), **kw)
+    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act, norm, training, new_stats)
+    up3 = ublock(sd, "decoder3", torch.cat([down3, _up(bottom_2, 2)], 1), **kw)
+    up2 = ublock(sd, "decoder2", torch.cat([down2, _up(up3, 2)], 1), **kw)
+    up1 = ublock(sd, "decoder1", torch.cat([down1, _up(up2, 2)], 1), **kw)
     out = _c1(sd, "outconv", up1)
     if not deep_supervision:
         return out
@@ -92,7 +101,7 @@ def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group"):
     return out, deeps
 
 
-def equiunet_state_shapes(width, inplanes=4, num_classes=3, act="relu"):
+def equiunet_state_shapes(width, inplanes=4, num_classes=3, act="relu", norm="group"):
     """Ordered {key: shape} of EquiUnet(features=[width*2**i]) with GroupNorm, deep supervision
     (networks/equiunet2020.py:424-458). Checked against the reference in tests/golden.  act "prelu" adds the unit's
     nn.PReLU weight (the activation is a named entry of the reference's nn.Sequential, :51-65)."""
@@ -103,6 +112,10 @@ def equiunet_state_shapes(width, inplanes=4, num_classes=3, act="relu"):
         shapes[pre + ".conv.weight"] = (cout, cin, 3, 3, 3)
         shapes[pre + ".bn.weight"] = (cout,)
         shapes[pre + ".bn.bias"] = (cout,)
+        if norm == "batch":  # nn.BatchNorm3d's buffers, in its state-dict order
+            shapes[pre + ".bn.running_mean"] = (cout,)
+            shapes[pre + ".bn.running_var"] = (cout,)
+            shapes[pre + ".bn.num_batches_tracked"] = ()
         if act == "prelu":
             shapes[pre + ".prelu.weight"] = (1,)
 

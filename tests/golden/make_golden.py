@@ -102,6 +102,47 @@ def equiunet_instance_fixture():
     _model_fixture(m, unet.equiunet_state_shapes, 8, (32, 32, 32), "equiunet_w8_32_instance.npz", 2)
 
 
+def equiunet_batch_fixture():
+    """--norm batch (nn.BatchNorm3d(affine=True), networks/factory.py:185-186): a training-mode step on a batch of TWO
+    patches (batch statistics, running buffers updated), then the eval-mode forward on the updated buffers."""
+    import functools
+    width, size, fname = 8, (16, 16, 16), "equiunet_w8_16_batchnorm.npz"
+    m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="batch", act="relu", deep_supervision=True, dropout=0)
+    shapes = unet.equiunet_state_shapes(width, norm="batch")
+    sd = synth.fill_state_dict(shapes)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), "state-dict key order/name mismatch vs reference"
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    x = synth.closed_form_image(2, 4, size)
+    t = synth.nested_spheres(2, size)
+    out = m(x)
+    loss = _ds_loss(out, t, _criterion())
+    loss.backward()
+    res = {"meta": json.dumps({"width": width, "size": list(size), "batch": 2, "keys": list(sd.keys())}),
+           "logits": out[0].detach().numpy(), "loss": np.float64(loss.item())}
+    for i, d in enumerate(out[1]):
+        res[f"deep{i}"] = d.detach().numpy()[:, :, ::2, ::2, ::2]
+    names, gn = [], []
+    for k, p in m.named_parameters():
+        names.append(k)
+        gn.append(float(p.grad.double().norm()))
+        if p.grad.numel() <= 4096:
+            res["grad:" + k] = p.grad.numpy().copy()
+    res["grad_names"] = json.dumps(names)
+    res["grad_norms"] = np.array(gn)
+    for k, v in m.state_dict().items():  # the running buffers after one training forward
+        if "running_" in k or "num_batches" in k:
+            res["buf:" + k] = v.numpy().copy()
+    m.eval()
+    with torch.no_grad():
+        res["eval_logits"] = m(x)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, fname), **res)
+    print(fname, "loss", loss.item(), "logits absmax", float(out[0].abs().max()), "eval absmax", float(np.abs(res["eval_logits"]).max()))
+
+
 def assp_fixture():
     m = EquiUnetASSPEvo(4, 3, [16, 32, 64, 128], norm_layer="group", act="relu", deep_supervision=True, dropout=0)
     _model_fixture(m, unet.assp_evo_state_shapes, 16, (32, 32, 32), "assp_w16_32.npz", 1)
@@ -312,7 +353,7 @@ if __name__ == "__main__":
     m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
                                      t.Rotate90(angles=[0, 90, 180, 270])])
     sys.modules["src_definer_tta"] = m
-    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance", "equiunet_elu", "equiunet_prelu"]
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance", "equiunet_elu", "equiunet_prelu", "equiunet_batch"]
     if "equiunet" in which:
         equiunet_fixtures()
     if "equiunet_instance" in which:
@@ -321,6 +362,8 @@ if __name__ == "__main__":
         equiunet_elu_fixture()
     if "equiunet_prelu" in which:
         equiunet_prelu_fixture()
+    if "equiunet_batch" in which:
+        equiunet_batch_fixture()
     if "assp" in which:
         assp_fixture()
     if "ops" in which:

@@ -247,3 +247,34 @@ def test_equiunet_prelu_oracle_matches_reference(golden_dir):
     for k in g.files:
         if k.startswith("grad:") and k.endswith(".prelu.weight"):
             np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=1e-6, rtol=1e-4)
+
+
+def test_equiunet_batch_norm_oracle_matches_reference(golden_dir):
+    """--norm batch (nn.BatchNorm3d, networks/factory.py:185-186): training-mode step on two patches (logits, loss, gradients,
+    updated running buffers) and the eval-mode forward on those buffers, against the reference's own outputs."""
+    g = _load(golden_dir, "equiunet_w8_16_batchnorm.npz")
+    meta = json.loads(str(g["meta"]))
+    shapes = unet.equiunet_state_shapes(meta["width"], norm="batch")
+    assert list(shapes.keys()) == meta["keys"]
+    sd = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+          for k, v in synth.fill_state_dict(shapes).items()}
+    size = tuple(meta["size"])
+    x, t = synth.closed_form_image(meta["batch"], 4, size), synth.nested_spheres(meta["batch"], size)
+    new_stats = {}
+    out = unet.equiunet_forward(sd, x, norm="batch", training=True, new_stats=new_stats)
+    loss = unet.deep_supervision_loss(out, t)
+    loss.backward()
+    np.testing.assert_allclose(out[0].detach().numpy(), g["logits"], atol=TOL, rtol=0)
+    for i, d in enumerate(out[1]):
+        np.testing.assert_allclose(d.detach().numpy()[:, :, ::2, ::2, ::2], g[f"deep{i}"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-9)
+    for k, v in new_stats.items():
+        np.testing.assert_allclose(v.numpy(), g["buf:" + k], atol=1e-6, rtol=1e-5)
+    sd_eval = {k: v.detach() for k, v in sd.items()}
+    sd_eval.update(new_stats)
+    with torch.no_grad():
+        ev = unet.equiunet_forward(sd_eval, x, norm="batch", training=False)[0]
+    np.testing.assert_allclose(ev.numpy(), g["eval_logits"], atol=TOL, rtol=0)
