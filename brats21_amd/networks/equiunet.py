@@ -499,7 +499,9 @@ class EquiUnet(_PackedWeightsModule):
         self.deep_supervision = deep_supervision
         self.act = act
         self.features = list(features)
-        self.precision = "auto"
+        # "auto" = follow torch.autocast; BRATS_PRECISION=x3 makes the split-precision parity mode the default of an unmodified
+        # training script run with --no_amp
+        self.precision = os.environ.get("BRATS_PRECISION", "auto")
         # None | "fwd" | "all": run the 3x3x3 convolutions (forward / forward + input gradients) on the e4m3 MFMA kernel
         # when the activations are bf16 (BASELINE.json configs[4]); the weight gradients stay bf16
         self.conv_fp8 = None

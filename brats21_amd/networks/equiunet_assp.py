@@ -421,7 +421,9 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
         self.deep_supervision = deep_supervision
         self.act = act.upper()
         self.features = list(features)
-        self.precision = "auto"
+        # "auto" = follow torch.autocast; BRATS_PRECISION=x3 makes the split-precision parity mode the default of an unmodified
+        # training script run with --no_amp
+        self.precision = os.environ.get("BRATS_PRECISION", "auto")
         self.conv_fp8 = None  # None | "fwd" | "all": e4m3 kernel for the 3x3x3 convolutions (see EquiUnet.conv_fp8)
         self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "1") != "0"  # training: one multi-tensor weight-packing launch per step (ops.PackPlan)
         # the output head's backward inside the backward of the decoder1 block (brats_evonorm_se_bwd with dlogits); 0: the
