@@ -1259,6 +1259,12 @@ __global__ void __launch_bounds__(256) x3_split_kernel(const float* __restrict__
 }
 static size_t x3_align(size_t b) { return (b + 255) / 256 * 256; }
 static size_t wgrad_x3_split_bytes(size_t voxels, int c) { return c > 0 ? x3_align(voxels * c * 2) : 0; }  // one of hi / lo
+static void x3_split_launch(const float* src, int pitch, bf16_t* hi, bf16_t* lo, size_t vox, int c, const float* amax, hipStream_t st) {
+  const size_t total = vox * (c / 8);
+  size_t nb = (total + 511) / 512;  // two pieces per thread
+  const unsigned blocks = (unsigned)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
+  hipLaunchKernelGGL(x3_split_kernel<0>, dim3(blocks), dim3(256), 0, st, src, pitch, hi, lo, vox, c, amax);
+}
 
 static int wgrad_x3(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch,
                     const float* amax_dy, float* ws, float* dw, size_t slab_bytes, int dil, int N, int D, int H, int W, int cout,
@@ -1272,10 +1278,7 @@ static int wgrad_x3(const void* x1, int c1, int pitch1, const void* x2, int c2, 
   bf16_t* hy = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, cout);
   bf16_t* ly = (bf16_t*)b;
   auto split = [&](const void* src, int pitch, bf16_t* hi, bf16_t* lo, int c, const float* amax) {
-    const size_t total = vox * (c / 8);
-    size_t nb = (total + 511) / 512;  // two pieces per thread
-    const unsigned blocks = (unsigned)(nb < 1 ? 1 : (nb > 262144 ? 262144 : nb));
-    hipLaunchKernelGGL(x3_split_kernel<0>, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const float*)src, pitch, hi, lo, vox, c, amax);
+    x3_split_launch((const float*)src, pitch, hi, lo, vox, c, amax, st);
   };
   split(x1, pitch1, h1, l1, c1, nullptr);
   if (c2 > 0) split(x2, pitch2, h2, l2, c2, nullptr);
@@ -1367,33 +1370,25 @@ static int wgrad_shift_geometry(int dtype, int ksize, int N, int D, int H, int W
 
 extern "C" size_t BRATS_API(brats_conv3d_wgrad_shift_ws_bytes)(int dtype, int ksize, int N, int D, int H, int W, int cin, int cout) {
   if (ksize != 1 && ksize != 3) return 0;
+  if (dtype == BRATS_X3_BF16) {  // split precision: three groups of 16-bit slabs + the hi / lo tensors of x and dy (wgrad_shift_x3)
+    const size_t vox = (size_t)N * D * H * W;
+    const size_t slab = BRATS_API(brats_conv3d_wgrad_shift_ws_bytes)(BRATS_BF16, ksize, N, D, H, W, cin, cout) * 3;
+    return x3_align(slab) + 2 * wgrad_x3_split_bytes(vox, cin) + 2 * wgrad_x3_split_bytes(vox, cout);
+  }
   WgradParams p;
   int cof, cif, cot, cit;
   wgrad_shift_geometry(dtype, ksize, N, D, H, W, cin, cout, &p, &cof, &cif, &cot, &cit);
   return (size_t)p.nsplit * p.ntaps * cout * cin * sizeof(float);
 }
 
-extern "C" int BRATS_API(brats_conv3d_wgrad_shift)(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
-                                        float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
-                                        brats_stream_t s) {
-  if (!x || !dy || !ws || !dw || cin <= 0 || cout <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0)
-    BRATS_FAIL(BRATS_E_ARG, "wgrad_shift: null pointer / bad size");
-  if ((ksize != 1 && ksize != 3) || dil < 1) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: ksize=%d dil=%d unsupported", ksize, dil);
-  if (dtype != BRATS_BF16 && dtype != BRATS_F32) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: dtype %d", dtype);
-  const int epl = dtype == BRATS_BF16 ? 8 : 4;
-  if (xpitch % epl || dypitch % epl || cin % epl || cout % epl)
-    BRATS_FAIL(BRATS_E_ARG, "wgrad_shift: channel counts / pitches must be multiples of %d", epl);
-  {
-    const int mp = xpitch > dypitch ? xpitch : dypitch;
-    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
-      BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
-  }
+// launches the shifted-tap MFMA kernel of one problem into the slabs at ws; *nsplit_out = slabs written ([split][taps][cout][cin])
+static int wgrad_shift_mfma(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, int dtype, int ksize, int dil,
+                            int N, int D, int H, int W, int cout, hipStream_t st, int* nsplit_out, int* ntaps_out) {
   WgradParams p;
   int cof, cif, cot, cit;
   wgrad_shift_geometry(dtype, ksize, N, D, H, W, cin, cout, &p, &cof, &cif, &cot, &cit);
   p.x1 = x; p.x2 = nullptr; p.c1 = cin; p.c2 = 0; p.p1 = xpitch; p.p2 = 0;
   p.dy = dy; p.dyp = dypitch; p.ws = ws; p.dil = dil;
-  hipStream_t st = (hipStream_t)s;
   if (cin % 16 || cout % 16) {  // slab entries of padded ci / co lanes are never written
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)p.nsplit * p.ntaps * cout * cin * sizeof(float), st);
     if (e != hipSuccess) BRATS_FAIL(BRATS_E_HIP, "wgrad_shift: memset: %s", hipGetErrorString(e));
@@ -1401,7 +1396,56 @@ extern "C" int BRATS_API(brats_conv3d_wgrad_shift)(const void* x, int cin, int x
   dim3 grid(p.ntaps * p.nsplit, cot, cit);
   const int rc = dtype == BRATS_BF16 ? wgrad_dispatch<bf16_t, 1, 1>(p, cof, cif, grid, st) : wgrad_dispatch<float, 1, 1>(p, cof, cif, grid, st);
   if (rc) return rc;
-  wgrad_reduce_launch((const float*)ws, dw, p.nsplit, cout, cin, p.ntaps, st);
+  *nsplit_out = p.nsplit;
+  *ntaps_out = p.ntaps;
+  return 0;
+}
+
+static int wgrad_shift_impl(const void* x, int cin, int xpitch, const void* dy, int dypitch, const float* amax_dy, float* ws, float* dw,
+                            float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout, brats_stream_t s) {
+  if (!x || !dy || !ws || !dw || cin <= 0 || cout <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0)
+    BRATS_FAIL(BRATS_E_ARG, "wgrad_shift: null pointer / bad size");
+  if ((ksize != 1 && ksize != 3) || dil < 1) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: ksize=%d dil=%d unsupported", ksize, dil);
+  if (dtype != BRATS_BF16 && dtype != BRATS_F32 && dtype != BRATS_X3_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: dtype %d", dtype);
+  const bool x3 = dtype == BRATS_X3_BF16;
+  const int epl = dtype == BRATS_BF16 ? 8 : 4;
+  if (xpitch % epl || dypitch % epl || cin % epl || cout % epl)
+    BRATS_FAIL(BRATS_E_ARG, "wgrad_shift: channel counts / pitches must be multiples of %d", epl);
+  if (x3 && (cin % 8 || cout % 8)) BRATS_FAIL(BRATS_E_ARG, "wgrad_shift (split precision): channel counts must be multiples of 8");
+  {
+    const int mp = xpitch > dypitch ? xpitch : dypitch;
+    if ((double)D * H * W * mp * (dtype == BRATS_BF16 ? 2 : 4) >= 2147483648.0)
+      BRATS_FAIL(BRATS_E_UNSUPPORTED, "wgrad_shift: one sample of %dx%dx%d x pitch %d exceeds the 2 GiB buffer-offset range", D, H, W, mp);
+  }
+  hipStream_t st = (hipStream_t)s;
+  int ns = 0, ntaps = 0;
+  if (x3) {
+    // split precision (see wgrad_x3): hi / lo tensors of x and of dy * 2^k, three runs of the 16-bit kernel, one reduction
+    const size_t vox = (size_t)N * D * H * W;
+    const size_t slab = BRATS_API(brats_conv3d_wgrad_shift_ws_bytes)(BRATS_BF16, ksize, N, D, H, W, cin, cout) * 3;
+    char* b = (char*)ws + x3_align(slab);
+    bf16_t* hx = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, cin);
+    bf16_t* lx = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, cin);
+    bf16_t* hy = (bf16_t*)b; b += wgrad_x3_split_bytes(vox, cout);
+    bf16_t* ly = (bf16_t*)b;
+    x3_split_launch((const float*)x, xpitch, hx, lx, vox, cin, nullptr, st);
+    x3_split_launch((const float*)dy, dypitch, hy, ly, vox, cout, amax_dy, st);
+    BRATS_CHECK_LAUNCH();
+    int total = 0;
+    const size_t per = (size_t)(ksize == 3 ? 27 : 1) * cout * cin;
+    const bf16_t* xs[3] = {lx, hx, hx};
+    const bf16_t* ys[3] = {hy, ly, hy};
+    for (int t = 0; t < 3; ++t) {  // (small terms first: the reduction adds the slabs in this order)
+      const int rc = wgrad_shift_mfma(xs[t], cin, cin, ys[t], cout, ws + (size_t)total * per, BRATS_BF16, ksize, dil, N, D, H, W, cout, st, &ns, &ntaps);
+      if (rc) return rc;
+      total += ns;
+    }
+    wgrad_reduce_launch((const float*)ws, dw, total, cout, cin, ntaps, st, amax_dy);
+  } else {
+    const int rc = wgrad_shift_mfma(x, cin, xpitch, dy, dypitch, ws, dtype, ksize, dil, N, D, H, W, cout, st, &ns, &ntaps);
+    if (rc) return rc;
+    wgrad_reduce_launch((const float*)ws, dw, ns, cout, cin, ntaps, st);
+  }
   if (dbias) {
     const size_t vox = (size_t)N * D * H * W;
     if (dtype == BRATS_BF16) hipLaunchKernelGGL(dbias_kernel<bf16_t>, dim3(cout), dim3(256), 0, st, (const bf16_t*)dy, dypitch, dbias, vox, cout);
@@ -1409,6 +1453,18 @@ extern "C" int BRATS_API(brats_conv3d_wgrad_shift)(const void* x, int cin, int x
   }
   BRATS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int BRATS_API(brats_conv3d_wgrad_shift)(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
+                                        float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
+                                        brats_stream_t s) {
+  return wgrad_shift_impl(x, cin, xpitch, dy, dypitch, nullptr, ws, dw, dbias, dtype, ksize, dil, N, D, H, W, cout, s);
+}
+extern "C" int BRATS_API(brats_conv3d_x3_wgrad_shift)(const void* x, int cin, int xpitch, const void* dy, int dypitch, const float* amax_dy,
+                                           float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N, int D, int H,
+                                           int W, int cout, brats_stream_t s) {
+  if (dtype != BRATS_X3_BF16) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_wgrad_shift: dtype must be BRATS_X3_F16 or BRATS_X3_BF16");
+  return wgrad_shift_impl(x, cin, xpitch, dy, dypitch, amax_dy, ws, dw, dbias, dtype, ksize, dil, N, D, H, W, cout, s);
 }
 
 // ---- e4m3 weight gradient (all-taps blocks only; everything else stays on the bf16 kernels) --------------------------

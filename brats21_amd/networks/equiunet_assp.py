@@ -127,10 +127,11 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
     if db is None:
         db = ops.channel_dot(dy).sum(0)
-    if cx.x3s and k == 3 and getattr(dy, "_amax", None) is None:
+    if cx.x3s and getattr(dy, "_amax", None) is None:
         dy._amax = ops.absmax(dy)  # (a producer that records no |max|: one extra pass)
     if k == 1:
-        dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1, out=cx.dest(conv.weight))  # a GEMM over the voxels: shifted-tap kernel, 1 tap
+        # a GEMM over the voxels: shifted-tap kernel, 1 tap
+        dw, _ = ops.conv3d_wgrad_shift(xin, dy, 1, out=cx.dest(conv.weight), amax_dy=dy._amax if cx.x3s else None)
         cx.put(conv.weight, dw)
     else:
         ax, ady = getattr(xin, "_amax", None), getattr(dy, "_amax", None)
@@ -175,7 +176,7 @@ def _aspp_bwd(cx, aspp, x, d_acat):
     for i, (k, dl) in enumerate(zip(aspp.kernel_sizes, aspp.dilations)):
         conv = aspp.convs[i]
         dyi = d_acat[..., i * q:(i + 1) * q]
-        dw, _ = ops.conv3d_wgrad_shift(x, dyi, k, dl)
+        dw, _ = ops.conv3d_wgrad_shift(x, dyi, k, dl, amax_dy=ops.absmax(dyi) if cx.x3s else None)  # (16^3: the extra pass is 3 MB)
         cx.put(conv.weight, dw)
         cx.put(conv.bias, db_all[i * q:(i + 1) * q])
         terms.append((dyi, ops.pack_weights_direct(conv.weight, cx.dtype, PACK_DGRAD), k, dl))

@@ -1164,18 +1164,32 @@ def dconv_run(jobs, n, d, h, w, dtype):
     _lib.check(_lib.lib().brats_dconv_run(buf, len(jobs), _code(dtype), n, d, h, w, _stream()), "dconv_run")
 
 
-def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False, out=None):
+def conv3d_wgrad_shift(x, dy, ksize=1, dil=1, want_dbias=False, out=None, amax_dy=None):
     """dW [cout, cin, k, k, k] f32 (and dbias) of a 1x1x1 convolution, or of a 3x3x3 convolution at any dilation
-    (shifted-tap form of the weight-gradient kernel: the ASPP branches with dilation 4 / 6)."""
+    (shifted-tap form of the weight-gradient kernel: the ASPP branches with dilation 4 / 6).  Inside a split_precision()
+    block f32 tensors run the three-product form (amax_dy: the scale source of dy, see conv3d_wgrad)."""
     ptr, c, p = _desc(x)
     dptr, cout, dp = _desc(dy)
     n, d, h, w, _ = x.shape
-    code = _code(x.dtype)
+    kd = x.dtype
+    if _X3 is not None and x.dtype == torch.float32 and c % 8 == 0 and cout % 8 == 0:
+        kd = _X3  # (1x1x1 too: the voxel GEMM is MFMA-bound in exact f32 -- 3.0 of EquiUnetASSPEvo-48's 44 ms x3 step)
+    code = _code(kd)
+    if amax_dy is not None and kd in (X3F, X3B):
+        nbytes = _lib.lib().brats_conv3d_wgrad_shift_ws_bytes(code, ksize, n, d, h, w, c, cout)
+        ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+        dw = _grad_out(out, (cout, c, ksize, ksize, ksize), x.device)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
+        with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(kd)):
+            _lib.check(_lib.lib().brats_conv3d_x3_wgrad_shift(ptr, c, p, dptr, dp, _f32(amax_dy), ws.data_ptr(), dw.data_ptr(),
+                                                              db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
+                                                              cout, _stream()), "conv3d_x3_wgrad_shift")
+        return dw, db
     nbytes = _lib.lib().brats_conv3d_wgrad_shift_ws_bytes(code, ksize, n, d, h, w, c, cout)
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
     dw = _grad_out(out, (cout, c, ksize, ksize, ksize), x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_dbias else None
-    with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(x.dtype)):
+    with _span("conv_wgrad", c, cout, ksize, dil, n, d, h, w, str(kd)):
         _lib.check(_lib.lib().brats_conv3d_wgrad_shift(ptr, c, p, dptr, dp, ws.data_ptr(), dw.data_ptr(),
                                                        db.data_ptr() if db is not None else None, code, ksize, dil, n, d, h, w,
                                                        cout, _stream()), "conv3d_wgrad_shift")

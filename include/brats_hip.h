@@ -190,6 +190,11 @@ size_t brats_conv3d_wgrad_shift_ws_bytes(int dtype, int ksize, int N, int D, int
 int brats_conv3d_wgrad_shift(const void* x, int cin, int xpitch, const void* dy, int dypitch, float* ws, float* dw,
                              float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,
                              brats_stream_t s);
+/* the same in split precision (dtype BRATS_X3_F16 / BRATS_X3_BF16: f32 x and dy, three 16-bit MFMA products; amax_dy as in
+ * brats_conv3d_x3_wgrad); brats_conv3d_wgrad_shift(_ws_bytes) accept the two codes as well (no scale) */
+int brats_conv3d_x3_wgrad_shift(const void* x, int cin, int xpitch, const void* dy, int dypitch, const float* amax_dy,
+                                float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N, int D, int H, int W,
+                                int cout, brats_stream_t s);
 
 /* ---- GroupNorm(8) + activation (nn.GroupNorm networks/factory.py:179-182, get_act :195-200) ---
  * finalize: per-(n,channel) tile partials -> per-(n,group) mean / rstd (biased var, eps) and the

@@ -245,3 +245,27 @@ def test_x3_gradients_vs_f64_oracle(name, width, size):
     print(f"\n{name}-{width} @{size}^3 vs f64 (logit err, worst per-parameter gradient rel err, median): {res}")
     assert res["x3"][0] < LOGIT_ATOL, res
     assert res["x3"][2] < 2e-4 and res["x3"][1][0] < 2e-2, res
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,size", [(48, 24, 1, 1, (8, 16, 16)), (24, 48, 1, 1, (5, 6, 7)), (96, 96, 3, 4, (8, 8, 8)), (32, 64, 3, 6, (8, 8, 8))])
+def test_conv3d_wgrad_shift_x3_vs_f64(cin, cout, k, dil, size):
+    """The shifted-tap weight gradient (1x1x1 convolutions; 3x3x3 at dilation 4 / 6: the ASPP branches) in split precision
+    against float64, beside the exact-f32 kernel: f32-class on fp16 pairs with the dY scale."""
+    from brats21_amd import ops
+    n = 2
+    x = _rand((n, cin, *size), 21)
+    dy = _rand((n, cout, *size), 22) * 1e-5
+    w = torch.zeros(cout, cin, k, k, k, dtype=torch.double, requires_grad=True)
+    F.conv3d(x.double(), w, None, 1, dil * (k // 2), dil).backward(dy.double())
+    ref = w.grad
+    xd, dyd = _nd(x), _nd(dy)
+    exact, _ = ops.conv3d_wgrad_shift(xd, dyd, k, dil)
+    amax = ops.absmax(dyd)
+    with ops.split_precision(ops.X3F):
+        got, _ = ops.conv3d_wgrad_shift(xd, dyd, k, dil, amax_dy=amax)
+        again, _ = ops.conv3d_wgrad_shift(xd, dyd, k, dil, amax_dy=amax)
+    torch.cuda.synchronize()
+    e, e0 = _relmax(got.double().cpu(), ref), _relmax(exact.double().cpu(), ref)
+    print(f"wgrad_shift k={k} d={dil}: x3 rel-to-max err {e:.2e} (exact-f32 kernel {e0:.2e})")
+    assert e < 3e-6 and e < 4 * max(e0, 3e-7), (e, e0)
+    assert torch.equal(got, again)  # fixed-order reduction: bitwise reproducible
