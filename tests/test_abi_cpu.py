@@ -85,7 +85,12 @@ def test_state_dict_contract_and_factory_errors():
     with pytest.raises(NameError):
         get_model(argparse.Namespace(model="nnunet", **ns))
     with pytest.raises(NotImplementedError):
-        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "batch"}))
+        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "bcn"}))
+    # --norm batch (round 4): nn.BatchNorm3d's parameter / buffer names and order
+    mb = get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "batch"}))
+    shapes_b = unet.equiunet_state_shapes(8, norm="batch")
+    assert list(mb.state_dict().keys()) == list(shapes_b.keys())
+    assert all(tuple(mb.state_dict()[k].shape) == tuple(v) for k, v in shapes_b.items())
     # no CPU fallback: a CPU forward must fail loudly
     from brats21_amd import BratsHipError
     with pytest.raises(BratsHipError):
