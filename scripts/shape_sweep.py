@@ -9,8 +9,9 @@ from oracle import synth, unet
 
 dev = torch.device("cuda:0")
 bad = 0
-for name, width in (("equiunet", 48), ("equiunet", 64), ("equiunet_assp_evo", 48), ("equiunet_assp_evo", 64), ("equiunet", 16)):
-    ns = argparse.Namespace(model=name, width=width, norm="group", act="relu", num_classes=3, dropout=0)
+for name, width, norm in (("equiunet", 48, "group"), ("equiunet", 64, "group"), ("equiunet_assp_evo", 48, "group"), ("equiunet_assp_evo", 64, "group"),
+                          ("equiunet", 16, "group"), ("equiunet", 32, "instance"), ("equiunet", 48, "batch")):
+    ns = argparse.Namespace(model=name, width=width, norm=norm, act="relu", num_classes=3, dropout=0)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -18,30 +19,30 @@ for name, width in (("equiunet", 48), ("equiunet", 64), ("equiunet_assp_evo", 48
     for size, n in (((8, 8, 8), 1), ((16, 24, 40), 3), ((40, 56, 72), 1), ((72, 64, 48), 2), ((96, 96, 96), 1), ((128, 128, 128), 1)):
         x = synth.random_image(n, 4, size, seed=7).to(dev)
         t = synth.nested_spheres(n, size).to(dev)
-        for mode in ("fp32", "bf16", "fp8"):
+        for mode in ("fp32", "x3", "bf16", "fp8"):
             if mode == "fp32" and size[0] * size[1] * size[2] > 40 * 56 * 72:
                 continue
             m.zero_grad(set_to_none=True)
-            m.precision = "fp32" if mode == "fp32" else "auto"
+            m.precision = mode if mode in ("fp32", "x3") else "auto"
             m.conv_fp8 = "all" if mode == "fp8" else None
             try:
-                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode != "fp32"):
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=mode not in ("fp32", "x3")):
                     out, deeps = m(x)
                     loss = unet.deep_supervision_loss((out, deeps), t)
                 loss.backward()
                 ok = bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
                 extra = ""
-                if mode == "fp32" and size[0] * size[1] * size[2] <= 16 * 24 * 40 and width <= 48:
+                if mode in ("fp32", "x3") and size[0] * size[1] * size[2] <= 16 * 24 * 40 and width <= 48:
                     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
                     with torch.no_grad():
-                        ref = (unet.equiunet_forward if name == "equiunet" else unet.assp_evo_forward)(sd, x.cpu())[0]
+                        ref = (unet.equiunet_forward(sd, x.cpu(), norm=norm) if name == "equiunet" else unet.assp_evo_forward(sd, x.cpu()))[0]
                     err = float((out.detach().cpu() - ref).abs().max())
                     extra = f" err vs oracle {err:.2e}"
                     ok = ok and err < 1e-3
-                print(f"{name}-{width} {n}x{size} {mode}: loss {float(loss):.4f} {'ok' if ok else 'BAD'}{extra}", flush=True)
+                print(f"{name}-{width}-{norm} {n}x{size} {mode}: loss {float(loss):.4f} {'ok' if ok else 'BAD'}{extra}", flush=True)
                 bad += not ok
             except Exception as e:  # noqa: BLE001
-                print(f"{name}-{width} {n}x{size} {mode}: EXCEPTION {type(e).__name__}: {str(e)[:150]}", flush=True)
+                print(f"{name}-{width}-{norm} {n}x{size} {mode}: EXCEPTION {type(e).__name__}: {str(e)[:150]}", flush=True)
                 bad += 1
     del m
 print("bad:", bad)
