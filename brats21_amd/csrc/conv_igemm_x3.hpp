@@ -102,19 +102,41 @@ DEVI void conv_mma_chunk_x3(const char* ldsb, int lo_off, int lane_b, int q, con
   });
 }
 
-template <int KS, int CK, int DIL, int NF, bool VS>
+// statistics of a 4x8x16 tile: sred[wm + 2 wn][NF*16][2] -> one entry per 4x4x16 sub-tile (y-half wn), summed over wm
+template <int NF>
+DEVI void vs8_stats_write(const ConvParams& p, int ty4, const float* sred, int tid, int n, int tzi, int tyi, int txi, int ct) {
+  if (tid < 2 * NF * 16) {
+    const int half = tid / (NF * 16), cl = tid % (NF * 16);
+    const int c = ct * NF * 16 + cl;
+    const int ty_i = tyi * 2 + half;
+    if (c < p.cout && ty_i < ty4) {
+      const size_t tps = (size_t)p.tz * ty4 * p.tx;
+      const size_t tile = ((size_t)tzi * ty4 + ty_i) * p.tx + txi;
+      float* dst = p.stats + (((size_t)n * tps + tile) * p.cout + c) * 2;
+      dst[0] = sred[((2 * half) * NF * 16 + cl) * 2] + sred[((2 * half + 1) * NF * 16 + cl) * 2];
+      dst[1] = sred[((2 * half) * NF * 16 + cl) * 2 + 1] + sred[((2 * half + 1) * NF * 16 + cl) * 2 + 1];
+    }
+  }
+}
+
+template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY>
 constexpr int conv_x3_lds_bytes() {
-  using G = ConvGeom<bf16_t, KS, CK, DIL>;
+  using G = ConvGeom<bf16_t, KS, CK, DIL, TY>;
   return 2 * ((G::LDS_TILE + 15) / 16 * 16) + ConvTile<NF, false, VS>::SRED_BYTES;
 }
 
-// wave roles: VS = all four waves compute the same NF*16 couts for a quarter of the tile's voxels (4 x-rows each);
-// !VS = wave (wm, wn) computes cout half wn (NF*16 of the workgroup's 2*NF*16) for z half wm (8 x-rows)
-template <int KS, int CK, int DIL, int NF, bool VS>
-__global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_kernel(const ConvParams p) {
-  using G = ConvGeom<bf16_t, KS, CK, DIL>;
+// wave roles: VS = all four waves compute the same NF*16 couts for a quarter of the tile's voxels;
+// !VS = wave (wm, wn) computes cout half wn (NF*16 of the workgroup's 2*NF*16) for z half wm (8 x-rows).
+// TY = tile rows in y: 4, or -- VS only -- 8 (the 4x8x16 tile of conv_igemm_vs8.hpp: a wave owns 4 y-rows in each of its two
+// z-slices = 8 voxel fragments, so a weight fragment pair fetched from L2 feeds 24 x 3 MFMAs instead of 12 x 3, the halo
+// amplification drops 2.53x -> 2.11x, and the per-tile costs are paid half as often; statistics stay per 4x4x16 sub-tile)
+template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY>
+__global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY) ? 3 : 2) void conv_igemm_x3_kernel(const ConvParams p, int ty4) {
+  static_assert(TY == CONV_TY || (TY == 8 && VS), "the 8-row tile exists for the y-split roles");
+  using G = ConvGeom<bf16_t, KS, CK, DIL, TY>;
   using TL = ConvTile<NF, false, VS>;
-  constexpr int NB = TL::NB, YB = NB / 2;
+  constexpr int YB = VS ? TY / 2 : CONV_TY;         // y-rows per wave and z-slice: VS 2 (TY = 4) or 4 (TY = 8); cout-half roles 4
+  constexpr int NB = 2 * YB;
   constexpr int LDS_HALF = (G::LDS_TILE + 15) / 16 * 16;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_k
   const int tyi = bt % p.ty; bt /= p.ty;
   const int tzi = bt % p.tz;
   const int n = bt / p.tz;
-  const int z0 = tzi * CONV_TZ, y0 = tyi * CONV_TY, x0 = txi * CONV_TX;
+  const int z0 = tzi * CONV_TZ, y0 = tyi * TY, x0 = txi * CONV_TX;  // (TY = 8: p.ty counts 8-row tiles, ty4 the 4-row ones)
   const int ct = blockIdx.y;
   const int f0 = ct * TL::NFW + (VS ? 0 : wn * NF);
   const size_t sample_vox = (size_t)n * p.D * p.H * p.W;
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_k
     for (int i = 0; i < NB; ++i) acc[f][i] = b;
   }
 
-  const int lane_b = ((wm * 2) * G::HY * G::HX + (VS ? wn * 2 * G::HX : 0) + v) * G::S + q * G::UB;
+  const int lane_b = ((wm * 2) * G::HY * G::HX + (VS ? wn * YB * G::HX : 0) + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 128 * 16;  // bytes of packed hi + lo weights per chunk
 
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
@@ -230,11 +252,11 @@ __global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_k
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
-    const bool full = z0 + CONV_TZ <= p.D && y0 + CONV_TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * TL::NFW * 16 <= p.cout;
+    const bool full = z0 + CONV_TZ <= p.D && y0 + TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * TL::NFW * 16 <= p.cout;
     if (full) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
         float* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -251,7 +273,7 @@ __global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_k
     } else {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
         const bool ok = z < p.D && y < p.H && x_ok;
         const float mk = ok ? 1.f : 0.f;
         float* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
@@ -293,7 +315,10 @@ __global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_k
   }
   if (p.stats) {
     __syncthreads();
-    if (tid < TL::NFW * 16) {
+    if constexpr (TY == 8) {
+      // one 4x4x16 statistics entry per y-half (= wn): the layout every consumer reads (conv_igemm_vs8.hpp)
+      vs8_stats_write<NF>(p, ty4, sred, tid, n, tzi, tyi, txi, ct);
+    } else if (tid < TL::NFW * 16) {
       const int c = ct * TL::NFW * 16 + tid;
       if (c < p.cout) {
         const size_t tps = (size_t)p.tz * p.ty * p.tx;
@@ -312,15 +337,18 @@ __global__ __launch_bounds__(256, (CK == 16 && VS) ? 3 : 2) void conv_igemm_x3_k
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------------
-template <int KS, int CK, int DIL, int NF, bool VS>
-int conv_x3_launch_one(const ConvParams& p, hipStream_t st) {
-  constexpr int lds = conv_x3_lds_bytes<KS, CK, DIL, NF, VS>();
+template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY>
+int conv_x3_launch_one(const ConvParams& p0, hipStream_t st) {
+  constexpr int lds = conv_x3_lds_bytes<KS, CK, DIL, NF, VS, TY>();
   static_assert(lds <= 160 * 1024, "x3 LDS tile too large");
-  auto kern = conv_igemm_x3_kernel<KS, CK, DIL, NF, VS>;
+  auto kern = conv_igemm_x3_kernel<KS, CK, DIL, NF, VS, TY>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
+  ConvParams p = p0;
+  const int ty4 = p.ty;
+  p.ty = ceil_div(p.H, TY);
   dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, false, VS>::NFW));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, ty4);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
@@ -331,6 +359,12 @@ template <int KS, int CK, int DIL>
 int conv_x3_launch_ck(const ConvParams& p, hipStream_t st) {
   const ConvTileChoice t = conv_choose_tile(p.rows16);
   const bool small = (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / (2 * t.nf) > 0 ? p.rows16 / (2 * t.nf) : 1) < conv_small_grid_threshold();
+  if constexpr (CK == 16 && DIL == 1) {
+    // Cout = 48 (mod 96), big volumes: the y-split roles on the 4x8x16 tile (BRATS_X3_TY8=0: the 4x4x16 tile, for A/B runs)
+    static int ty8 = -1;
+    if (ty8 < 0) { const char* e = getenv("BRATS_X3_TY8"); ty8 = e ? atoi(e) : 1; }
+    if (ty8 && t.nf == 3 && t.ksplit && (long)p.N * p.tz * p.ty * p.tx >= 2048) return conv_x3_launch_one<KS, CK, DIL, 3, true, 8>(p, st);
+  }
   if (t.nf == 3) return (t.ksplit || small) ? conv_x3_launch_one<KS, CK, DIL, 3, true>(p, st) : conv_x3_launch_one<KS, CK, DIL, 3, false>(p, st);
   if (t.nf == 2) return (t.ksplit || small) ? conv_x3_launch_one<KS, CK, DIL, 2, true>(p, st) : conv_x3_launch_one<KS, CK, DIL, 2, false>(p, st);
   return conv_x3_launch_one<KS, CK, DIL, 1, true>(p, st);
