@@ -194,6 +194,23 @@ DEVI float row16_sum(float x) {
   return x;
 }
 
+// statistics of a 4x8x16 tile: sred[wm + 2 wn][NF*16][2] -> one entry per 4x4x16 sub-tile (y-half wn), summed over wm
+template <int NF>
+DEVI void vs8_stats_write(const ConvParams& p, int ty4, const float* sred, int tid, int n, int tzi, int tyi, int txi, int ct) {
+  if (tid < 2 * NF * 16) {
+    const int half = tid / (NF * 16), cl = tid % (NF * 16);
+    const int c = ct * NF * 16 + cl;
+    const int ty_i = tyi * 2 + half;
+    if (c < p.cout && ty_i < ty4) {
+      const size_t tps = (size_t)p.tz * ty4 * p.tx;
+      const size_t tile = ((size_t)tzi * ty4 + ty_i) * p.tx + txi;
+      float* dst = p.stats + (((size_t)n * tps + tile) * p.cout + c) * 2;
+      dst[0] = sred[((2 * half) * NF * 16 + cl) * 2] + sred[((2 * half + 1) * NF * 16 + cl) * 2];
+      dst[1] = sred[((2 * half) * NF * 16 + cl) * 2 + 1] + sred[((2 * half + 1) * NF * 16 + cl) * 2 + 1];
+    }
+  }
+}
+
 // ---- normalise + activate on load (PRE kernels) ------------------------------------------------------------------------
 // Under no_grad nobody but the next convolution reads z = act(GroupNorm(y)) of a layer inside a block: the consumer then
 // stages the RAW convolution output y and applies the producer's per-(sample, channel) affine map and activation between the
