@@ -1,0 +1,41 @@
+"""-m gpu: bench.py's output contract on a small configuration (a child process: the JSON line is what the driver parses)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout  # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_small_configuration():
+    r = _bench("--width", "8", "--patch", "32", "--steps", "4", "--warmup", "2", "--no-infer", "--no-cpu-baseline", "--no-parity-leg")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "box"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 4 and r["warmup"] == 2 and r["higher_is_better"] is True and r["scaling"] == "weak"
+    assert r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "bf16" and "workload" in r["config"]
+    assert abs(r["value"] - 2 / (r["ms_per_step"] * 1e-3)) < 0.02 * r["value"]  # patches/s = batch / step time
+    rf, box = r["roofline"], r["box"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_box", "traffic", "kernel", "avg_ms"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(rf["frac_of_box"] - rf["achieved"] / box["mfma_TFLOPs"]) < 1e-3
+    # the box probe: a sane MI355X (sustained 16-bit matrix rate between 1 and 2.6 PFLOP/s, stream between 3 and 8 TB/s)
+    assert 1000.0 < box["mfma_TFLOPs"] < 2600.0 and 3.0 < box["stream_TBps"] < 8.0 and 1000 < box["sclk_MHz"] < 2500
+
+
+def test_bench_x3_precision_runs_the_split_kernels():
+    r = _bench("--width", "8", "--patch", "32", "--steps", "3", "--warmup", "1", "--precision", "x3", "--no-infer", "--no-cpu-baseline",
+               "--no-parity-leg")
+    assert r["dtype"] == "x3" and r["roofline"]["peak"] < 1000.0  # a third of the 16-bit peak: three MFMAs per product
