@@ -11,4 +11,4 @@ void brats_set_error(const char* fmt, ...) {
 }
 extern "C" const char* brats_last_error(void) { return g_err; }
 // 2: round 3 (brats_maxpool2_fwd gained the arg-max output; fold entry points added)
-extern "C" int brats_abi_version(void) { return 3; }
+extern "C" int brats_abi_version(void) { return 4; }

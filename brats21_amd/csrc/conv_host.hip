@@ -64,142 +64,162 @@ extern "C" size_t BRATS_API(brats_conv3d_packed_bytes)(int dtype, int ksize, int
 // ---- weight packing ----------------------------------------------------------------------------
 // out[chunk][ms][row16][lane][16 B]; see conv_igemm.hpp for the unit -> (tap, channel) map.
 // X3 (split precision, conv_igemm_x3.hpp): out[chunk][ms][row16][hi | lo][lane][16 B], hi = rn16(w), lo = rn16(w - hi)
-template <typename T, bool X3 = false>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int mode, int taps,
-                                    int cin_w, int cin_off, int rows, int rows16, int kdim, int ck, int ms_n,
-                                    size_t total) {
-  constexpr bool BF = std::is_same<T, bf16_t>::value;
-  constexpr int EPL = BF ? 8 : 4;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int e = idx % EPL;
-  size_t t = idx / EPL;
-  const int lane = t % 64; t /= 64;
-  int hl = 0;
-  if (X3) { hl = t % 2; t /= 2; }
-  const int ft = t % rows16; t /= rows16;
-  const int ms = t % ms_n;
-  const int chunk = t / ms_n;
-  const int q = lane >> 4, row = ft * 16 + (lane & 15);
-  int tap, kc;
-  bool valid;
-  if (BF) {
-    const int upt = ck / 8, g = 4 * ms + q;
-    valid = g < taps * upt;
-    tap = g / upt;
-    kc = chunk * ck + (g % upt) * 8 + e;
+//
+// One workgroup packs the fragments of (K chunk, 16-row group, PACK_ROWS of its rows): the torch-layout weights it needs are
+// CONTIGUOUS runs (forward: ck * taps floats per output row; dgrad: PACK_ROWS * taps floats per K row), read coalesced into LDS,
+// and every thread then gathers the 16-byte piece of one (macro-step, lane) from LDS.  (The first packer gathered from
+// global memory with a stride of `taps` floats -- 33 launches x 9 us per EquiUnet-48 step.)
+static constexpr int PACK_ROWS = 4;                            // fragment rows per workgroup
+static constexpr int PACK_SUBS = 16 / PACK_ROWS;               // workgroups per 16-row fragment group
+static constexpr int PACK_LDS_FLOATS = PACK_ROWS * 48 * 27;    // rows x the largest chunk x 27 taps (20736 B)
+DEVI void pack_tile(const brats_pack_job& J, int blk, float* lds) {
+  constexpr int RB = PACK_ROWS;
+  const int sub = blk % PACK_SUBS, ft = (blk / PACK_SUBS) % J.rows16, chunk = (blk / PACK_SUBS) / J.rows16;
+  const int taps = J.taps, ck = J.ck, row0 = ft * 16 + sub * RB;
+  const bool fwd = J.mode == BRATS_PACK_FWD;
+  // 16-byte loads, all of a thread's loads issued before the first LDS write, when every run starts and ends on a 16-byte
+  // boundary (always, for input-channel counts that are multiples of 4); element-wise otherwise
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool al = ((size_t)J.w & 15) == 0 && (J.cin_real * taps) % 4 == 0 && (J.cin_off * taps) % 4 == 0 && blockDim.x == 256;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (fwd) {
+    // lds[r][kcl][tap] = w[row0 + r][cin_off + chunk * ck + kcl][tap]  (zero beyond the real input channels / rows)
+    const int seg = ck * taps;
+    int kvalid = J.cin_real - J.cin_off - chunk * ck;
+    kvalid = kvalid < 0 ? 0 : (kvalid > ck ? ck : kvalid);
+    const int jlim = kvalid * taps;
+    if (al && seg % 4 == 0 && jlim % 4 == 0) {
+      const int seg4 = seg / 4, jl4 = jlim / 4;
+      constexpr int IT = (48 * 27 / 4 + 63) / 64, RW = (RB + 3) / 4;  // 6 loads per row, RW rows per wave
+      float4 v[RW][IT];
+#pragma unroll
+      for (int h = 0; h < RW; ++h) {
+        const int r = wave + 4 * h;
+        const float4* src = reinterpret_cast<const float4*>(J.w + ((size_t)(row0 + r) * J.cin_real + J.cin_off + chunk * ck) * taps);
+        const bool rv = r < RB && row0 + r < J.rows;
+#pragma unroll
+        for (int u = 0; u < IT; ++u) v[h][u] = rv && lane + 64 * u < jl4 ? src[lane + 64 * u] : zero4;
+      }
+#pragma unroll
+      for (int h = 0; h < RW; ++h)
+#pragma unroll
+        for (int u = 0; u < IT; ++u)
+          if (wave + 4 * h < RB && lane + 64 * u < seg4) reinterpret_cast<float4*>(lds)[(wave + 4 * h) * seg4 + lane + 64 * u] = v[h][u];
+    } else {
+      for (int i = threadIdx.x; i < RB * seg; i += blockDim.x) {
+        const int r = i / seg, j = i - r * seg;
+        float v = 0.f;
+        if (row0 + r < J.rows && j < jlim) v = J.w[((size_t)(row0 + r) * J.cin_real + J.cin_off + chunk * ck) * taps + j];
+        lds[i] = v;
+      }
+    }
   } else {
-    const int g = 4 * (4 * ms + e) + q;
-    valid = g < taps * ck;
-    tap = g / ck;
-    kc = chunk * ck + g % ck;
+    // lds[kcl][r][tap] = w[chunk * ck + kcl][cin_off + row0 + r][tap]
+    const int seg = RB * taps;
+    int rvalid = J.rows - row0, rv2 = J.cin_real - J.cin_off - row0;
+    rvalid = rvalid < rv2 ? rvalid : rv2;
+    rvalid = rvalid < 0 ? 0 : (rvalid > RB ? RB : rvalid);
+    const int jlim = rvalid * taps;
+    constexpr int LPS = RB * 27 / 4 <= 32 ? 32 : 64;  // lanes per K row's run (RB * 27 / 4 sixteen-byte pieces)
+    constexpr int KPW = 64 / LPS;                     // K rows a wave loads per instruction
+    if (al && seg % 4 == 0 && jlim % 4 == 0 && seg <= 4 * LPS) {
+      const int seg4 = seg / 4, jl4 = jlim / 4, l = lane % LPS;
+      constexpr int IT = 48 / (4 * KPW);
+      float4 v[IT];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int kcl = (wave + 4 * u) * KPW + lane / LPS;
+        const float4* src = reinterpret_cast<const float4*>(J.w + ((size_t)(chunk * ck + kcl) * J.cin_real + J.cin_off + row0) * taps);
+        v[u] = kcl < ck && l < jl4 ? src[l] : zero4;
+      }
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        const int kcl = (wave + 4 * u) * KPW + lane / LPS;
+        if (kcl < ck && l < seg4) reinterpret_cast<float4*>(lds)[kcl * seg4 + l] = v[u];
+      }
+    } else {
+      for (int i = threadIdx.x; i < ck * seg; i += blockDim.x) {
+        const int kcl = i / seg, j = i - kcl * seg;
+        float v = 0.f;
+        if (j < jlim) v = J.w[((size_t)(chunk * ck + kcl) * J.cin_real + J.cin_off + row0) * taps + j];
+        lds[i] = v;
+      }
+    }
   }
-  float val = 0.f;
-  if (valid && row < rows && kc < kdim) {
-    if (mode == BRATS_PACK_FWD) val = w[((size_t)row * cin_w + cin_off + kc) * taps + tap];
-    else val = w[((size_t)kc * cin_w + cin_off + row) * taps + (taps - 1 - tap)];
+  __syncthreads();
+  const bool x3 = J.dtype == BRATS_X3_BF16;
+  const int nx = x3 ? 2 : 1;
+  const int pieces = J.ms_n * 4 * RB * nx;
+  if (J.dtype == BRATS_F32) {
+    // f32 fragments: 4 K units per lane, unit g = 4 * (4 * ms + e) + q -> (tap, channel) = (g / ck, g % ck)
+    for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
+      const int r = p % RB, q = (p / RB) & 3, ms = p / (4 * RB);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int g = 4 * (4 * ms + e) + q, tap = g / ck, kcl = g - tap * ck;
+        v[e] = g < taps * ck ? (fwd ? lds[(r * ck + kcl) * taps + tap] : lds[(kcl * RB + r) * taps + (taps - 1 - tap)]) : 0.f;
+      }
+      const size_t o = ((((size_t)chunk * J.ms_n + ms) * J.rows16 + ft) * 64 + q * 16 + sub * RB + r) * 4;
+      *reinterpret_cast<float4*>((float*)J.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return;
   }
-  if (X3 && hl) val -= to_f<T>(from_f<T>(val));
-  out[idx] = from_f<T>(val);
+  // 16-bit fragments: a lane's piece = 8 consecutive K channels of one tap; unit g = 4 * ms + q
+  const int upt = ck / 8;
+  for (int p = threadIdx.x; p < pieces; p += blockDim.x) {
+    const int r = p % RB, q = (p / RB) & 3;
+    int t = p / (4 * RB), hl = 0;
+    if (x3) { hl = t & 1; t >>= 1; }
+    const int ms = t, g = 4 * ms + q, tap = g / upt, kcl0 = (g - tap * upt) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float val = 0.f;
+      if (g < taps * upt) val = fwd ? lds[(r * ck + kcl0 + e) * taps + tap] : lds[((kcl0 + e) * RB + r) * taps + (taps - 1 - tap)];
+      v[e] = hl ? val - bf2f(f2bf(val)) : val;
+    }
+    const size_t o = (((((size_t)chunk * J.ms_n + ms) * J.rows16 + ft) * nx + hl) * 64 + q * 16 + sub * RB + r) * 8;
+    Vec<bf16_t, 8>::store((bf16_t*)J.out + o, v);
+  }
+}
+__global__ void __launch_bounds__(256) pack_weights_kernel(const brats_pack_job J) {
+  __shared__ __attribute__((aligned(16))) float lds[PACK_LDS_FLOATS];
+  pack_tile(J, blockIdx.x, lds);
+}
+
+static int pack_blocks(int kdim, int ck, int rows) { return (kdim / ck) * ceil_div(rows, 16) * PACK_SUBS; }
+extern "C" int BRATS_API(brats_conv3d_pack_blocks)(int kdim, int ck, int rows) {
+  return ck > 0 && kdim % ck == 0 && rows > 0 ? pack_blocks(kdim, ck, rows) : 0;
 }
 
 extern "C" int BRATS_API(brats_conv3d_pack_weights)(const float* w, void* packed, int dtype, int mode, int ksize,
                                          int cout_w, int cin_w, int cin_off, int cin_cnt, int ck,
                                          brats_stream_t s) {
   if (!w || !packed || (ksize != 1 && ksize != 3) || ck <= 0) BRATS_FAIL(BRATS_E_ARG, "pack_weights: bad argument");
-  const int taps = ksize * ksize * ksize;
-  const int rows = mode == BRATS_PACK_FWD ? cout_w : cin_cnt;
-  const int kdim = mode == BRATS_PACK_FWD ? cin_cnt : cout_w;
-  if (kdim % ck) BRATS_FAIL(BRATS_E_ARG, "pack_weights: K channels %d not a multiple of chunk %d", kdim, ck);
-  const int rows16 = ceil_div(rows, 16);
-  const int ms = macro_steps(dtype, ksize, ck);
-  const int epl = dtype == BRATS_F32 ? 4 : 8;
-  const size_t total = (size_t)(kdim / ck) * ms * rows16 * 64 * epl * (dtype == BRATS_X3_BF16 ? 2 : 1);
-  const int blocks = (int)((total + 255) / 256);
-  if (dtype == BRATS_BF16)
-    hipLaunchKernelGGL(pack_weights_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, mode,
-                       taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
-  else if (dtype == BRATS_X3_BF16)
-    hipLaunchKernelGGL((pack_weights_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)packed, mode,
-                       taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
-  else
-    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)packed, mode,
-                       taps, cin_w, cin_off, rows, rows16, kdim, ck, ms, total);
+  if (dtype != BRATS_BF16 && dtype != BRATS_X3_BF16 && dtype != BRATS_F32) BRATS_FAIL(BRATS_E_ARG, "pack_weights: dtype %d", dtype);
+  brats_pack_job J;
+  J.w = w; J.out = packed; J.dtype = dtype; J.mode = mode; J.taps = ksize * ksize * ksize;
+  J.cin_w = cin_w; J.cin_real = cin_w; J.cin_off = cin_off;
+  J.rows = mode == BRATS_PACK_FWD ? cout_w : cin_cnt;
+  J.kdim = mode == BRATS_PACK_FWD ? cin_cnt : cout_w;
+  if (J.kdim % ck) BRATS_FAIL(BRATS_E_ARG, "pack_weights: K channels %d not a multiple of chunk %d", J.kdim, ck);
+  if (PACK_ROWS * ck * J.taps > PACK_LDS_FLOATS) BRATS_FAIL(BRATS_E_UNSUPPORTED, "pack_weights: chunk %d x %d taps exceeds the staging tile", ck, J.taps);
+  J.rows16 = ceil_div(J.rows, 16); J.ck = ck; J.ms_n = macro_steps(dtype, ksize, ck); J.reserved = 0;
+  J.total = (unsigned long long)(J.kdim / ck) * J.ms_n * J.rows16 * 64 * (dtype == BRATS_F32 ? 4 : 8) * (dtype == BRATS_X3_BF16 ? 2 : 1);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(pack_blocks(J.kdim, ck, J.rows)), dim3(256), 0, (hipStream_t)s, J);
   BRATS_CHECK_LAUNCH();
   return 0;
 }
 
 // ---- multi-tensor packing: one launch for every layer of a network -----------------------------------------------
-static constexpr int PACK_BLOCK = 2048;  // output elements per block (8 per thread)
-template <typename T>
-DEVI void pack_one(const brats_pack_job& J, size_t idx) {
-  constexpr bool BF = std::is_same<T, bf16_t>::value;
-  constexpr int EPL = BF ? 8 : 4;
-  const int e = idx % EPL;
-  size_t t = idx / EPL;
-  const int lane = t % 64; t /= 64;
-  const int ft = t % J.rows16; t /= J.rows16;
-  const int ms = t % J.ms_n;
-  const int chunk = t / J.ms_n;
-  const int q = lane >> 4, row = ft * 16 + (lane & 15);
-  int tap, kc;
-  bool valid;
-  if (BF) {
-    const int upt = J.ck / 8, g = 4 * ms + q;
-    valid = g < J.taps * upt;
-    tap = g / upt;
-    kc = chunk * J.ck + (g % upt) * 8 + e;
-  } else {
-    const int g = 4 * (4 * ms + e) + q;
-    valid = g < J.taps * J.ck;
-    tap = g / J.ck;
-    kc = chunk * J.ck + g % J.ck;
-  }
-  float val = 0.f;
-  if (valid && row < J.rows && kc < J.kdim) {
-    // FWD: K = input channels (zero beyond cin_real); DGRAD: rows = input channels
-    if (J.mode == BRATS_PACK_FWD) { if (J.cin_off + kc < J.cin_real) val = J.w[((size_t)row * J.cin_real + J.cin_off + kc) * J.taps + tap]; }
-    else { if (J.cin_off + row < J.cin_real) val = J.w[((size_t)kc * J.cin_real + J.cin_off + row) * J.taps + (J.taps - 1 - tap)]; }
-  }
-  ((T*)J.out)[idx] = from_f<T>(val);
-}
+// blocks[i] = {job, block of that job (0 .. brats_conv3d_pack_blocks(kdim, ck, rows) - 1)}
 __global__ void __launch_bounds__(256) pack_weights_multi_kernel(const brats_pack_job* __restrict__ jobs, const int* __restrict__ blocks) {
+  __shared__ __attribute__((aligned(16))) float lds[PACK_LDS_FLOATS];
   const brats_pack_job J = jobs[blocks[blockIdx.x * 2]];
-  const size_t base = (size_t)blocks[blockIdx.x * 2 + 1] * PACK_BLOCK + (size_t)threadIdx.x * (PACK_BLOCK / 256);
-  if (base >= J.total) return;
-  if (J.dtype == BRATS_BF16 || J.dtype == BRATS_X3_BF16) {
-    // a thread owns one lane's 8 elements of a fragment (= 8 consecutive K channels of one tap): index math once, one
-    // 16-byte store.  (split precision: hi and lo fragments side by side, see pack_weights_kernel)
-    const bool x3 = J.dtype == BRATS_X3_BF16;
-    size_t t = base / 8;
-    const int lane = t % 64; t /= 64;
-    int hl = 0;
-    if (x3) { hl = t % 2; t /= 2; }
-    const int ft = t % J.rows16; t /= J.rows16;
-    const int ms = t % J.ms_n;
-    const int chunk = t / J.ms_n;
-    const int q = lane >> 4, row = ft * 16 + (lane & 15);
-    const int upt = J.ck / 8, g = 4 * ms + q;
-    const int tap = g / upt, kc0 = chunk * J.ck + (g % upt) * 8;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int kc = kc0 + e;
-      float val = 0.f;
-      if (g < J.taps * upt && row < J.rows && kc < J.kdim) {
-        if (J.mode == BRATS_PACK_FWD) { if (J.cin_off + kc < J.cin_real) val = J.w[((size_t)row * J.cin_real + J.cin_off + kc) * J.taps + tap]; }
-        else { if (J.cin_off + row < J.cin_real) val = J.w[((size_t)kc * J.cin_real + J.cin_off + row) * J.taps + (J.taps - 1 - tap)]; }
-      }
-      v[e] = hl ? val - bf2f(f2bf(val)) : val;
-    }
-    Vec<bf16_t, 8>::store((bf16_t*)J.out + base, v);
-  } else {
-#pragma unroll
-    for (int i = 0; i < PACK_BLOCK / 256; ++i)
-      if (base + i < J.total) pack_one<float>(J, base + i);
-  }
+  if (PACK_ROWS * J.ck * J.taps > PACK_LDS_FLOATS) __builtin_trap();
+  pack_tile(J, blocks[blockIdx.x * 2 + 1], lds);
 }
-extern "C" int BRATS_API(brats_conv3d_pack_block)(void) { return PACK_BLOCK; }
 extern "C" int BRATS_API(brats_conv3d_pack_weights_multi)(const brats_pack_job* jobs, const int* blocks, int nblocks, brats_stream_t s) {
   if (!jobs || !blocks || nblocks <= 0) BRATS_FAIL(BRATS_E_ARG, "pack_weights_multi: empty job / block table");
   hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)s, jobs, blocks);

@@ -517,8 +517,9 @@ class EquiUnet(_PackedWeightsModule):
         self._grad_sink = None  # set by brats21_amd.ddp.GradientBuckets
         self._grad_dest = None  # (ditto: parameter index -> its slice of an all-reduce bucket, or None)
         # training: one multi-tensor weight-packing launch per step (ops.PackPlan).  Off by default here: this network's
-        # step is GPU-bound and the single gather-heavy launch (0.21 ms) saves only 0.05 ms of GPU time over the 34 small
-        # ones while measuring 0.1 ms slower end to end (same-box A/B); EquiUnetASSPEvo (host-bound eager) gains 10 %.
+        # step is GPU-bound; the single launch (0.11 ms) saves 0.1 ms over the 33 per-layer ones (6.6 us each), and the
+        # convolutions lose 0.10-0.18 ms per step on weights that were packed long before their layer runs and have left
+        # L2 (same-box A/B); EquiUnetASSPEvo (host-bound eager) gains 10 %.
         self.pack_plan = os.environ.get("BRATS_PACK_PLAN", "0") != "0"
         # the output head's backward inside the GroupNorm backward of the last layer (brats_gn_act_bwd_head); 0: the two-call
         # path (brats_head_bwd + brats_gn_act_bwd) for same-box A/B runs

@@ -296,7 +296,6 @@ class PackPlan:
         # one job / block table per library flavour: fp16 jobs go to brats_conv3d_pack_weights_multi_f16 (where the job's
         # dtype code BF16 means "the 16-bit type"), everything else to the plain entry point
         jobs, blocks, entries, off = {False: [], True: []}, {False: [], True: []}, {}, 0
-        pb = _lib.lib().brats_conv3d_pack_block()
         for key, (wref, (dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1)) in self.recorded.items():
             w = wref()
             if w is None or w.dtype != torch.float32 or not w.is_contiguous():
@@ -317,7 +316,7 @@ class PackPlan:
             jobs[fl].append((w.data_ptr(), off, {F16: BF16, X3_F16: X3_BF16}.get(code, code), mode, k ** 3, cin_w, cin_real, cin_off,
                              rows, rows16, kdim, ck, ms_n, 0, total))
             j = len(jobs[fl]) - 1
-            blocks[fl].extend((j, b) for b in range((total + pb - 1) // pb))
+            blocks[fl].extend((j, b) for b in range(_lib.lib().brats_conv3d_pack_blocks(kdim, ck, rows)))
             off += (nbytes + 255) // 256 * 256
         self.buf = torch.empty(max(off, 256), dtype=torch.uint8, device=device)
         self.tables = []

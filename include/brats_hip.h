@@ -47,7 +47,8 @@ enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
  * memory (`slope_dev` of brats_affine_act / brats_gn_bwd_apply) + brats_prelu_slope_grad for its gradient. */
 enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_ELU = 3, BRATS_ACT_SWISH = 4, BRATS_ACT_MISH = 5 };
 
-int brats_abi_version(void); /* 2 since round 3: a changed signature (brats_maxpool2_fwd) bumps it; 3 in round 4 (additions only) */
+int brats_abi_version(void); /* 2 since round 3: a changed signature (brats_maxpool2_fwd) bumps it; 3 in round 4 (additions only), then
+                                 4 in round 4: the block table of brats_conv3d_pack_weights_multi changed meaning */
 const char* brats_last_error(void);
 
 /* ---- layout ---------------------------------------------------------------------------------
@@ -79,15 +80,17 @@ int brats_conv3d_pack_weights(const float* w, void* packed, int dtype, int mode,
 /* All weight tensors of a network in ONE launch (a training step re-packs every layer twice, forward and dgrad layout:
  * 34 launches of ~9 us for EquiUnet).  jobs / blocks are device arrays the caller builds once: job j describes one
  * brats_conv3d_pack_weights call (cin_real < cin_w: input channels >= cin_real are zero padding that is not present in
- * w, whose channel pitch is cin_real); blocks[b] = {job, block index inside the job}; a block packs
- * brats_conv3d_pack_block() consecutive output elements. */
+ * w, whose channel pitch is cin_real); blocks[b] = {job, block index inside the job}; a job has
+ * brats_conv3d_pack_blocks(kdim, ck, rows) blocks -- one per (K chunk, 16-row group, 8-row half): its torch-layout
+ * weights are contiguous runs, staged coalesced through LDS (ABI 4; ABI <= 3: brats_conv3d_pack_block() output
+ * elements per block, gathered from global memory). */
 typedef struct {
   const float* w;
   void* out;
   int dtype, mode, taps, cin_w, cin_real, cin_off, rows, rows16, kdim, ck, ms_n, reserved;
   unsigned long long total; /* output elements of this job */
 } brats_pack_job;
-int brats_conv3d_pack_block(void);
+int brats_conv3d_pack_blocks(int kdim, int ck, int rows);
 int brats_conv3d_pack_weights_multi(const brats_pack_job* jobs, const int* blocks /* [nblocks][2] */, int nblocks,
                                     brats_stream_t s);
 int brats_conv3d_pack_weights_multi_f16(const brats_pack_job* jobs, const int* blocks /* [nblocks][2] */, int nblocks,

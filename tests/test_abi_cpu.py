@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(l, n), f"{n} declared in include/brats_hip.h but not exported"
-    assert _lib.lib().brats_abi_version() == 3
+    assert _lib.lib().brats_abi_version() == 4
 
 
 def test_host_side_queries_and_argument_errors():

@@ -1,6 +1,8 @@
 """-m gpu: every HIP op through the C ABI against a plain torch fp32 CPU reference of the same op
 (the ATen calls the reference's CPU path makes).  f32 kernels: tight tolerances (exact-f32 MFMA);
 bf16 kernels: tolerance stated per test (bf16 storage has 8 mantissa bits)."""
+import contextlib
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -569,7 +571,34 @@ def test_conv3d_cout48_kernels_vs_torch(cin, cin2, cout, n, size, pitch, mode):
     torch.testing.assert_close(st[..., 1], ref2, atol=1e-3, rtol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def _pack_layout_oracle(wn, mode, cin_off, kdim, rows, ck, bf):
+    """numpy statement of the fragment layout out[chunk][ms][row16][lane][e] (csrc/conv_igemm.hpp) as f32 values."""
+    import numpy as np
+    taps = wn.shape[2]
+    rows16 = (rows + 15) // 16
+    epl = 8 if bf else 4
+    units = taps * (ck // 8) if bf else taps * ck
+    ms_n = (units + 3) // 4 if bf else (units // 4 + 3) // 4
+    # A[row][kc][tap]: the GEMM's left operand (rows zero-padded to whole 16-row fragments)
+    A = np.zeros((rows16 * 16, kdim, taps), dtype=np.float32)
+    if mode == 0:
+        A[:rows] = wn[:, cin_off:cin_off + kdim]
+    else:
+        A[:rows] = wn[:, cin_off:cin_off + rows, ::-1].transpose(1, 0, 2)
+    chunk, ms, ft, lane, e = np.meshgrid(np.arange(kdim // ck), np.arange(ms_n), np.arange(rows16), np.arange(64), np.arange(epl),
+                                         indexing="ij")
+    q, r = lane >> 4, lane & 15
+    if bf:
+        g = 4 * ms + q
+        tap, kc = g // (ck // 8), chunk * ck + (g % (ck // 8)) * 8 + e
+    else:
+        g = 4 * (4 * ms + e) + q
+        tap, kc = g // ck, chunk * ck + g % ck
+    valid = g < units
+    return np.where(valid, A[ft * 16 + r, kc, np.minimum(tap, taps - 1)], np.float32(0))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32, "x3"])
 @pytest.mark.parametrize("cout,cin,k,mode,cin_off,cin_cnt", [
     (48, 48, 3, 0, 0, None),     # forward layout, 48-channel chunk (or 24 / 16 by the kernel switch)
     (48, 96, 3, 1, 0, None),     # input-gradient layout: rows = input channels, taps flipped
@@ -577,44 +606,37 @@ def test_conv3d_cout48_kernels_vs_torch(cin, cin2, cout, n, size, pitch, mode):
     (96, 64, 3, 1, 16, 32),      # a channel slice of the weight tensor (two-source layers pack their halves separately)
     (24, 48, 1, 0, 0, None),     # 1x1x1
     (8, 8, 3, 0, 0, None),       # 8-channel chunk (first layer after padding)
+    (24, 8, 3, 1, 0, None),      # input-gradient layout with 8 rows: the second 8-row half of the fragment is padding
+    (384, 192, 3, 0, 0, None),   # the widest layers of EquiUnet-48 (8 / 4 chunks x 24 / 12 row groups)
+    (192, 384, 3, 1, 192, 192),
+    (16, 10, 3, 0, 0, 8),        # runs that do not start on 16-byte boundaries (the element-wise staging path)
+    (16, 10, 3, 1, 0, None),
+    (16, 6, 3, 1, 0, None),
 ])
 def test_pack_weights_matches_layout_oracle(dtype, cout, cin, k, mode, cin_off, cin_cnt):
-    """brats_conv3d_pack_weights (16-bit: coalesced reads + LDS transpose, round 3; f32: element-wise) against a numpy
-    statement of the fragment layout out[chunk][ms][row16][lane][e] (csrc/conv_igemm.hpp), bit for bit."""
+    """brats_conv3d_pack_weights (one workgroup per (K chunk, 16-row group, 8-row half): contiguous runs of the torch
+    layout staged through LDS) against a numpy statement of the fragment layout, bit for bit; "x3": the split-precision
+    layout out[chunk][ms][row16][hi | lo][lane][e] with hi = rn_fp16(w), lo = rn_fp16(w - hi)."""
     import numpy as np
     from brats21_amd import ops
     dev = _dev()
     w = _rand((cout, cin, k, k, k), 71)
-    packed = ops._pack_weights(w.to(dev), dtype, mode, None, cin_off, cin_cnt, 1, None)
-    torch.cuda.synchronize()
-    taps = k ** 3
+    x3 = dtype == "x3"
+    if x3 and k != 3:
+        pytest.skip("split precision: 3x3x3 only")
     cnt = cin - cin_off if cin_cnt is None else cin_cnt
     kdim, rows = (cnt, cout) if mode == 0 else (cout, cnt)
-    ck = ops.conv_chunk(dtype, k, 1, kdim, 0, rows)
-    rows16 = (rows + 15) // 16
-    bf = dtype != torch.float32
-    epl = 8 if bf else 4
-    units = taps * (ck // 8) if bf else taps * ck
-    ms_n = (units + 3) // 4 if bf else (units // 4 + 3) // 4
-    wn = w.numpy().reshape(cout, cin, taps)
-    ref = np.zeros((kdim // ck, ms_n, rows16, 64, epl), dtype=np.float32)
-    for chunk in range(kdim // ck):
-        for ms in range(ms_n):
-            for lane in range(64):
-                q, r = lane >> 4, lane & 15
-                for e in range(epl):
-                    if bf:
-                        g = 4 * ms + q
-                        valid, tap, kc = g < units, g // (ck // 8), chunk * ck + (g % (ck // 8)) * 8 + e
-                    else:
-                        g = 4 * (4 * ms + e) + q
-                        valid, tap, kc = g < units, g // ck, chunk * ck + g % ck
-                    if not valid:
-                        continue
-                    for ft in range(rows16):
-                        row = ft * 16 + r
-                        if row >= rows:
-                            continue
-                        ref[chunk, ms, ft, lane, e] = wn[row, cin_off + kc, tap] if mode == 0 else wn[kc, cin_off + row, taps - 1 - tap]
-    got = packed.view(dtype).float().cpu().numpy().reshape(ref.shape)
-    assert np.array_equal(got, torch.from_numpy(ref).to(dtype).float().numpy())
+    pdt = ops.X3F if x3 else dtype
+    packed = ops._pack_weights(w.to(dev), pdt, mode, None, cin_off, cin_cnt, 1, None)
+    ck = ops.conv_chunk(pdt, k, 1, kdim, 0, rows)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(_pack_layout_oracle(w.numpy().reshape(cout, cin, k ** 3), mode, cin_off, kdim, rows, ck, dtype != torch.float32))
+    if x3:
+        hi = ref.to(torch.float16)
+        lo = (ref - hi.float()).to(torch.float16)
+        want = torch.stack([hi, lo], dim=3)  # [chunk][ms][row16][hi | lo][lane][e]
+        got = packed.view(torch.float16).cpu().reshape(want.shape)
+    else:
+        want = ref.to(dtype)
+        got = packed.view(dtype).cpu().reshape(want.shape)
+    assert torch.equal(got.view(torch.int16 if dtype != torch.float32 else torch.int32), want.view(torch.int16 if dtype != torch.float32 else torch.int32))
