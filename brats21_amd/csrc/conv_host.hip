@@ -239,10 +239,14 @@ int conv_pre_launch(const ConvParams& p, int ck, int dil, hipStream_t st);
 
 struct ConvPre { const float* ss1 = nullptr; const float* ss2 = nullptr; int act = 0; float slope = 0.f; bool on = false; };
 
+bool conv_bst_supported(int ck, int dil, int rows16);                            // conv_bf16_k3_bst.hip
+int conv_bst_launch(const ConvParams& p, int ck, int dil, hipStream_t st);
+struct ConvBst { const void* by = nullptr; int bypitch = 0; const float* bss = nullptr; float slope = 0.f; bool on = false; };
+
 static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const float* xamax,
                          const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch,
                          int ysplit, float* stats, int dtype, int ksize, int dil, int N, int D, int H, int W,
-                         int cout, brats_stream_t s, const ConvPre& pre = ConvPre{}) {
+                         int cout, brats_stream_t s, const ConvPre& pre = ConvPre{}, const ConvBst& bst = ConvBst{}) {
   if (!x1 || !packed_w || !y || c1 <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0)
     BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: null pointer or non-positive size");
   if (c2 > 0 && !x2) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd: c2 > 0 but x2 is NULL");
@@ -265,6 +269,7 @@ static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int
   p.wpk = packed_w; p.bias = bias; p.y = y; p.ypitch = ypitch; p.stats = stats;
   p.y2 = y2; p.y2pitch = y2pitch; p.ysplit = ysplit; p.xamax = xamax;
   p.ss1 = pre.ss1; p.ss2 = pre.ss2; p.pre_act = pre.act; p.pre_slope = pre.slope;
+  p.by = bst.by; p.bypitch = bst.bypitch; p.bss = bst.bss; p.bslope = bst.slope;
   if (y2) {
     const ConvTileChoice tc = conv_choose_tile(ceil_div(cout, 16));
     if (ysplit <= 0 || ysplit >= cout || ysplit % (tc.nf * 16) || y2pitch % 4)
@@ -279,6 +284,7 @@ static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int
   hipStream_t st = (hipStream_t)s;
   if (ksize == 1) dil = 1;
   if (pre.on) return conv_pre_launch(p, ck, dil, st);
+  if (bst.on) return conv_bst_launch(p, ck, dil, st);
 #define GO(T) \
   if (ksize == 3 && dil == 1) return conv_launch<T, 3, 1>(p, ck, st); \
   if (ksize == 3 && dil == 2) return conv_launch<T, 3, 2>(p, ck, st); \
@@ -322,6 +328,26 @@ extern "C" int BRATS_API(brats_conv3d_fwd_pre)(const void* x1, int c1, int pitch
   pre.ss1 = ss1; pre.ss2 = ss2; pre.act = act; pre.slope = slope; pre.on = true;
   return conv_fwd_impl(x1, c1, pitch1, x2, c2, pitch2, nullptr, packed_w, bias, y, ypitch, nullptr, 0, 0, stats, dtype, 3, dil, N, D, H,
                        W, cout, s, pre);
+}
+
+extern "C" int BRATS_API(brats_conv3d_bstats_ok)(int dtype, int ksize, int dil, int c1, int cout) {
+  if (dtype != BRATS_BF16 || ksize != 3 || cout <= 0) return 0;
+  const int ck = BRATS_API(brats_conv3d_chunk)(dtype, ksize, dil, c1, 0, cout);
+  return ck > 0 && conv_bst_supported(ck, dil, ceil_div(cout, 16)) ? 1 : 0;
+}
+
+extern "C" int BRATS_API(brats_conv3d_fwd_bstats)(const void* x1, int c1, int pitch1, const void* packed_w, void* y, int ypitch,
+                                       const void* fwd_y, int fwd_pitch, const float* scale_shift, int act, float slope,
+                                       float* tile_stats, int dtype, int dil, int N, int D, int H, int W, int cout,
+                                       brats_stream_t s) {
+  if (dtype != BRATS_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd_bstats: 16-bit activations only");
+  if (act != BRATS_ACT_RELU && act != BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_fwd_bstats: relu / leakyrelu only (act %d)", act);
+  if (!fwd_y || !scale_shift || !tile_stats) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd_bstats: null pointer");
+  if (fwd_pitch % 4 || ((size_t)fwd_y & 7)) BRATS_FAIL(BRATS_E_ARG, "conv3d_fwd_bstats: the forward tensor must keep 8-byte loads aligned");
+  ConvBst bst;
+  bst.by = fwd_y; bst.bypitch = fwd_pitch; bst.bss = scale_shift; bst.slope = act == BRATS_ACT_RELU ? 0.f : slope; bst.on = true;
+  return conv_fwd_impl(x1, c1, pitch1, nullptr, 0, 0, nullptr, packed_w, nullptr, y, ypitch, nullptr, 0, 0, tile_stats, dtype, 3, dil, N, D,
+                       H, W, cout, s, ConvPre{}, bst);
 }
 
 extern "C" int BRATS_API(brats_conv3d_x3_fwd)(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,

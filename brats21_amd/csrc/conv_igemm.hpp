@@ -30,6 +30,12 @@ struct ConvParams {
   // PRE kernels only ("normalise + activate on load", inference): per-(sample, channel) {scale, shift} of source 1 / 2 (NULL =
   // that source is read as it is), applied to every staged value as act(x * scale + shift) before it enters LDS
   const float* ss1; const float* ss2; int pre_act; float pre_slope;
+  // BST kernels only ("backward statistics", training): this launch is the input gradient of the SECOND convolution of a
+  // block, its output dz the gradient of the first unit's activation.  by = that unit's raw convolution output (the dz
+  // shape, pitch bypitch), bss its {scale, shift} [N][cout][2]; the epilogue adds u = dz * act'(by * scale + shift) and
+  // u * by per tile and channel into `stats` -- GroupNorm backward's first pass (brats_gn_act_bwd: sum u, sum u * xhat)
+  // without reading dz and by back from HBM.  bslope: 0 = relu, else leakyrelu's slope
+  const void* by; int bypitch; const float* bss; float bslope;
 #ifdef BRATS_VS8_STAMPS
   long long* stamps;  // diagnostic build only
 #endif
@@ -194,6 +200,43 @@ DEVI float row16_sum(float x) {
   return x;
 }
 
+// ---- epilogue statistics of one output piece (the lane's 4 channels of one voxel) ------------------------------------------
+// Scalar on purpose: packed f32 instructions (v_pk_add_f32 / v_pk_fma_f32: half the instruction count) were built and
+// measured in round 4 -- the 4x8x16-tile kernel 1-2 % faster in isolation, the step 0.05-0.1 ms slower: beside the partner
+// workgroup's MFMA stream a packed f32 instruction costs more than the two scalar ones it replaces (MI355X_MICROARCH.md,
+// "packed f32 VALU ... an anti-lever beside MFMAs"; the reason the library is built with -fno-slp-vectorize).
+template <bool MASKED>
+DEVI void stat_fwd(float (&s1)[4], float (&s2)[4], const float (&o)[4], float m) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (MASKED) {
+      const float om = o[r] * m;
+      s1[r] += om;
+      s2[r] = __builtin_fmaf(om, o[r], s2[r]);
+    } else {
+      s1[r] += o[r];
+      s2[r] = __builtin_fmaf(o[r], o[r], s2[r]);
+    }
+  }
+}
+// backward statistics (ConvParams::by / bss): u = dz * act'(y * scale + shift), s1 += u, s2 += u * y for the lane's four
+// channels; yraw = their forward values (4 x 16 bit); slope 0 = relu
+template <bool MASKED>
+DEVI void stat_bst(float (&s1)[4], float (&s2)[4], const float (&o)[4], u32x2 yraw, const float (&sc)[4], const float (&sh)[4],
+                   float slope, float m) {
+  float yy[4];
+  unpack2(yraw[0], yy[0], yy[1]);
+  unpack2(yraw[1], yy[2], yy[3]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float pre = __builtin_fmaf(yy[r], sc[r], sh[r]);
+    float u = pre > 0.f ? o[r] : o[r] * slope;
+    if constexpr (MASKED) u *= m;
+    s1[r] += u;
+    s2[r] = __builtin_fmaf(u, yy[r], s2[r]);
+  }
+}
+
 // statistics of a 4x8x16 tile: sred[wm + 2 wn][NF*16][2] -> one entry per 4x4x16 sub-tile (y-half wn), summed over wm
 template <int NF>
 DEVI void vs8_stats_write(const ConvParams& p, int ty4, const float* sred, int tid, int n, int tzi, int tyi, int txi, int ct) {
@@ -248,9 +291,11 @@ DEVI void conv_pre_load(const float* ss, int n, int csrc, int cb, int part, floa
   }
 }
 
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false>
+// BST: backward statistics in the epilogue (ConvParams::by / bss; training, the input gradient of a block's second unit)
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false, bool BST = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   static_assert(!PRE || std::is_same<T, bf16_t>::value, "normalise-on-load exists for the 16-bit kernels");
+  static_assert(!BST || (std::is_same<T, bf16_t>::value && !KSPLIT), "backward statistics exist for the 16-bit kernels without K split");
   using G = ConvGeom<T, KS, CK, DIL>;
   using TL = ConvTile<NF, KSPLIT, VS>;
   constexpr int NB = TL::NB, YB = NB / 2;
@@ -418,6 +463,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         s2[f][r] = 0.f;
       }
     }
+    // BST: the forward values under this lane's outputs (4 channels per fragment and x-row, 8 bytes), requested one pair of
+    // x-rows ahead of their use (all of them up front spill), and the lane's channels' {scale, shift}; the tile sums become
+    // sum u, sum u * (forward value) with u = dz * act'(forward * scale + shift)  (GroupNorm backward's first pass)
+    u32x2 byv[BST ? NF : 1][BST ? NB : 1];
+    float bsc[BST ? NF : 1][4], bsh[BST ? NF : 1][4];
+    auto load_y = [&](int i, auto checked) {
+      if constexpr (BST) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
+        const bf16_t* rowp = (const bf16_t*)p.by + (sample_vox + (size_t)(z * p.H + y) * p.W + (x0 + v)) * p.bypitch + 4 * q;
+        const bool ok = !decltype(checked)::value || (z < p.D && y < p.H && x_ok);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bool cok = !decltype(checked)::value || (f0 + f) * 16 + 4 * q < p.cout;
+          byv[f][i] = ok && cok ? *(const u32x2*)(rowp + (f0 + f) * 16) : u32x2{0u, 0u};
+        }
+      }
+    };
+    if constexpr (BST) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int c = (f0 + f) * 16 + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool cok = c + r < p.cout;
+          bsc[f][r] = cok ? p.bss[((size_t)n * p.cout + c + r) * 2] : 0.f;
+          bsh[f][r] = cok ? p.bss[((size_t)n * p.cout + c + r) * 2 + 1] : 0.f;
+        }
+      }
+    }
+    // statistics of one output piece (4 channels of one voxel): sum x, sum x^2 -- or, BST, sum u, sum u * (forward value)
+    auto tally = [&](int f, int i, const float (&o)[4], auto masked, float m) {
+      constexpr bool MASKED = decltype(masked)::value;
+      if constexpr (BST) stat_bst<MASKED>(s1[f], s2[f], o, byv[f][i], bsc[f], bsh[f], p.bslope, m);
+      else stat_fwd<MASKED>(s1[f], s2[f], o, m);
+    };
     // interior tiles (the common case) take the mask-free path; edge tiles weight the statistics by a
     // 0/1 mask instead of branching around the accumulation (a branch makes hipcc copy all 8*NF
     // running sums through v_mov at every row)
@@ -429,8 +509,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       // rows of the first operand <-> even rows of the second) gives every lane 8 consecutive channels of ONE voxel:
       // rows 0 / 2 keep x-row i, rows 1 / 3 take x-row i + 1.
       const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
+      load_y(0, std::false_type{});
+      load_y(1, std::false_type{});
 #pragma unroll
       for (int i = 0; i < NB; i += 2) {
+        if (i + 2 < NB) {
+          load_y(i + 2, std::false_type{});
+          load_y(i + 3, std::false_type{});
+        }
+        if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every load to the top: 48 live registers, spills)
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
         T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
@@ -440,11 +527,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           for (int e = 0; e < 2; ++e) {
             float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              o[r] = acc[f][i + e][r];
-              s1[f][r] += o[r];
-              s2[f][r] = __builtin_fmaf(o[r], o[r], s2[f][r]);
-            }
+            for (int r = 0; r < 4; ++r) o[r] = acc[f][i + e][r];
+            tally(f, i + e, o, std::false_type{}, 1.f);
             pk[e][0] = pack2(o[0], o[1]);
             pk[e][1] = pack2(o[2], o[3]);
           }
@@ -454,25 +538,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         }
       }
     } else if (full) {
+      load_y(0, std::false_type{});
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
+        if (i + 1 < NB) load_y(i + 1, std::false_type{});
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
         T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            o[r] = acc[f][i][r];
-            s1[f][r] += o[r];
-            s2[f][r] = __builtin_fmaf(o[r], o[r], s2[f][r]);
-          }
+          for (int r = 0; r < 4; ++r) o[r] = acc[f][i][r];
+          tally(f, i, o, std::false_type{}, 1.f);
           Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
       }
     } else {
+      load_y(0, std::true_type{});
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
+        if (i + 1 < NB) load_y(i + 1, std::true_type{});
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
         const bool ok = z < p.D && y < p.H && x_ok;
         const float mk = ok ? 1.f : 0.f;
@@ -483,12 +568,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
           const float mf = cok ? mk : 0.f;
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            o[r] = acc[f][i][r];
-            const float om = o[r] * mf;
-            s1[f][r] += om;
-            s2[f][r] = __builtin_fmaf(om, o[r], s2[f][r]);
-          }
+          for (int r = 0; r < 4; ++r) o[r] = acc[f][i][r];
+          tally(f, i, o, std::true_type{}, mf);
           if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
       }
@@ -496,17 +577,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     if (p.stats) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
+        float t1[4], t2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s1[f][r] = row16_sum(s1[f][r]);
-          s2[f][r] = row16_sum(s2[f][r]);
+          t1[r] = row16_sum(s1[f][r]);
+          t2[r] = row16_sum(s2[f][r]);
         }
         if (v == 0) {
           const int cl = (f0 + f - ct * TL::NFW) * 16 + 4 * q;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            sred[(((VS ? wm + 2 * wn : wm) * TL::NFW * 16) + cl + r) * 2 + 0] = s1[f][r];
-            sred[(((VS ? wm + 2 * wn : wm) * TL::NFW * 16) + cl + r) * 2 + 1] = s2[f][r];
+            sred[(((VS ? wm + 2 * wn : wm) * TL::NFW * 16) + cl + r) * 2 + 0] = t1[r];
+            sred[(((VS ? wm + 2 * wn : wm) * TL::NFW * 16) + cl + r) * 2 + 1] = t2[r];
           }
         }
       }
@@ -533,10 +615,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------------
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false, bool BST = false>
 int conv_launch_one(const ConvParams& p, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT, VS>();
-  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS, PRE>;
+  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS, PRE, BST>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT, VS>::NFW));

@@ -42,9 +42,9 @@ DEVI void vs8_init_acc(const ConvParams& p, f32x4 (&acc)[NF][8], int f0, int q) 
 // Epilogue of the 4 x 8 x 16-tile kernels (conv_igemm_vs8_kernel, conv_igemm_ld_kernel): per-channel statistics of the
 // wave's 4x4x16 sub-tile half (DPP row sums -> sred[wm + 2 wn][NF*16][2]) and the NDHWC stores.  acc[f][i]: cout fragment f,
 // voxel fragment i = x-row (z = z0 + 2 wm + i / 4, y = y0 + 4 wn + i % 4).
-template <int NF>
+template <int NF, bool BST = false>
 DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sred, int wm, int wn, int q, int v,
-                             int z0, int y0, int x0, int ct, int f0, size_t sample_vox) {
+                             int z0, int y0, int x0, int ct, int f0, size_t sample_vox, int n = 0) {
   typedef bf16_t T;
   constexpr int NB = 8, YB = 4;
   const bool x_ok = x0 + v < p.W;
@@ -62,6 +62,40 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
       s2[f][rr] = 0.f;
     }
   }
+  // BST: the forward values under this lane's outputs (4 channels per fragment and x-row, 8 bytes), requested one pair of
+  // x-rows ahead of their use (all 24 pieces up front cost 48 registers and spilled), and the lane's channels' {scale, shift}
+  u32x2 byv[BST ? NF : 1][BST ? NB : 1];
+  float bsc[BST ? NF : 1][4], bsh[BST ? NF : 1][4];
+  auto load_y = [&](int i, auto checked) {
+    if constexpr (BST) {
+      const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
+      const T* rowp = (const T*)p.by + (sample_vox + (size_t)(z * p.H + y) * p.W + (x0 + v)) * p.bypitch + 4 * q;
+      const bool ok = !decltype(checked)::value || (z < p.D && y < p.H && x_ok);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const bool cok = !decltype(checked)::value || (f0 + f) * 16 + 4 * q < p.cout;
+        byv[f][i] = ok && cok ? *(const u32x2*)(rowp + (f0 + f) * 16) : u32x2{0u, 0u};
+      }
+    }
+  };
+  if constexpr (BST) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int c = (f0 + f) * 16 + 4 * q;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool cok = c + rr < p.cout;
+        bsc[f][rr] = cok ? p.bss[((size_t)n * p.cout + c + rr) * 2] : 0.f;
+        bsh[f][rr] = cok ? p.bss[((size_t)n * p.cout + c + rr) * 2 + 1] : 0.f;
+      }
+    }
+  }
+  // statistics of one output piece: forward kernels sum x and x^2; BST sums u = dz * act'(pre) and u * (forward value)
+  auto tally = [&](int f, int i, const float (&o)[4], auto masked, float m) {
+    constexpr bool MASKED = decltype(masked)::value;
+    if constexpr (BST) stat_bst<MASKED>(s1[f], s2[f], o, byv[f][i], bsc[f], bsh[f], p.bslope, m);
+    else stat_fwd<MASKED>(s1[f], s2[f], o, m);
+  };
   const bool full = z0 + CONV_TZ <= p.D && y0 + VS8_TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * NF * 16 <= p.cout;
   if (full && ypit % 8 == 0 && csub % 8 == 0 && ((size_t)ydst & 15) == 0) {
     // 16-byte stores: the lanes of MFMA rows q and q ^ 1 hold channels 4q..4q+3 and the next four of the SAME voxel;
@@ -69,8 +103,15 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
     // the second) gives every lane 8 consecutive channels of ONE voxel: rows 0 / 2 keep x-row i, rows 1 / 3 take x-row
     // i + 1.  Half the store instructions; worth ~1 % (the epilogue waits on the CU's ~10 B/clk store path, not on issue).
     const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
+    load_y(0, std::false_type{});
+    load_y(1, std::false_type{});
 #pragma unroll
     for (int i = 0; i < NB; i += 2) {
+      if (i + 2 < NB) {
+        load_y(i + 2, std::false_type{});
+        load_y(i + 3, std::false_type{});
+      }
+      if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every load to the top: 48 live registers, spills)
       const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
       T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
@@ -80,11 +121,8 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
         for (int e = 0; e < 2; ++e) {
           float o[4];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            o[rr] = acc[f][i + e][rr];
-            s1[f][rr] += o[rr];
-            s2[f][rr] = __builtin_fmaf(o[rr], o[rr], s2[f][rr]);
-          }
+          for (int rr = 0; rr < 4; ++rr) o[rr] = acc[f][i + e][rr];
+          tally(f, i + e, o, std::false_type{}, 1.f);
           pk[e][0] = pack2(o[0], o[1]);
           pk[e][1] = pack2(o[2], o[3]);
         }
@@ -94,8 +132,10 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
       }
     }
   } else {
+    load_y(0, std::true_type{});
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
+      if (i + 1 < NB) load_y(i + 1, std::true_type{});
       const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
       const bool ok = z < p.D && y < p.H && x_ok;
       const float mk = ok ? 1.f : 0.f;
@@ -106,12 +146,8 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
         const float mf = cok ? mk : 0.f;
         float o[4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          o[rr] = acc[f][i][rr];
-          const float om = o[rr] * mf;
-          s1[f][rr] += om;
-          s2[f][rr] = __builtin_fmaf(om, o[rr], s2[f][rr]);
-        }
+        for (int rr = 0; rr < 4; ++rr) o[rr] = acc[f][i][rr];
+        tally(f, i, o, std::true_type{}, mf);
         if (ok && cok) Vec<T, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
       }
     }
@@ -119,17 +155,18 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
   if (p.stats) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
+      float t1[4], t2[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        s1[f][rr] = row16_sum(s1[f][rr]);
-        s2[f][rr] = row16_sum(s2[f][rr]);
+        t1[rr] = row16_sum(s1[f][rr]);
+        t2[rr] = row16_sum(s2[f][rr]);
       }
       if (v == 0) {
         const int cl = f * 16 + 4 * q;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 0] = s1[f][rr];
-          sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 1] = s2[f][rr];
+          sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 0] = t1[rr];
+          sred[(((wm + 2 * wn) * NF * 16) + cl + rr) * 2 + 1] = t2[rr];
         }
       }
     }
@@ -156,7 +193,8 @@ DEVI void vs8_epilogue_stats(const ConvParams& p, int ty4, const float* sred, in
 // (Three workgroups per CU -- a 168-register build on a ring form of the MMA loop -- measured 0.39 -> 0.57 ms in round 3:
 // scripts/probes/experiments/conv_igemm_ld.hpp keeps that loop.)
 // PRE: normalise + activate on load (inference; conv_igemm.hpp: conv_pre_apply)
-template <int CK, int DIL, int NF, bool PRE = false>
+// BST: backward statistics in the epilogue (ConvParams::by / bss; training, the input gradient of a block's second unit)
+template <int CK, int DIL, int NF, bool PRE = false, bool BST = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams p, int ty4 /* 4-row tiles in y */) {
   using T = bf16_t;
   using G = ConvGeom<T, 3, CK, DIL, VS8_TY>;
@@ -279,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
   // --- epilogue: bias, statistics per 4x4x16 sub-tile, NDHWC store ---
   constexpr int LDS_MAIN = (G::LDS_TILE + 15) / 16 * 16;
   float* sred = (float*)(lds + LDS_MAIN);  // [4 (wm + 2 wn)][NF*16][2]
-  vs8_epilogue_store<NF>(p, acc, sred, wm, wn, q, v, z0, y0, x0, ct, f0, sample_vox);
+  vs8_epilogue_store<NF, BST>(p, acc, sred, wm, wn, q, v, z0, y0, x0, ct, f0, sample_vox, n);
 #ifdef BRATS_VS8_STAMPS
   VS8_STAMP(5);  // epilogue
   if (lane == 0 && p.stamps) {
@@ -301,10 +339,10 @@ static inline int conv_vs8_mode() {
   return v;
 }
 
-template <int CK, int DIL, int NF, bool PRE = false>
+template <int CK, int DIL, int NF, bool PRE = false, bool BST = false>
 int conv_launch_vs8(const ConvParams& p0, hipStream_t st) {
   constexpr int lds = conv_vs8_lds_bytes<CK, DIL, NF>();
-  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF, PRE>;
+  auto kern = conv_igemm_vs8_kernel<CK, DIL, NF, PRE, BST>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   ConvParams p = p0;

@@ -1054,6 +1054,59 @@ extern "C" int BRATS_API(brats_gn_act_bwd)(const void* dz, int dzpitch, const vo
   return rc < 0 ? rc : 0;
 }
 
+// GroupNorm + activation backward whose first pass was done by the producer of dz: the input-gradient convolution of the
+// block's second unit (brats_conv3d_fwd_bstats) left per tile and channel sum u and sum u * y (u = dz * act'(y * scale + shift),
+// y = this unit's raw convolution output) in the tile-statistics layout of the forward kernels.  Here: the tiles are added in a
+// fixed order in f64 (the forward pass's slab reduction), sum u * xhat = rstd * (sum u*y - mean * sum u), then pass 2 as in
+// brats_gn_act_bwd -- dz and y are read once instead of twice.
+__global__ void __launch_bounds__(256) gn_bwd_tiles_finish_kernel(const double* __restrict__ part, int splits, int N, int C, int groups,
+                                                                  const float* __restrict__ mean_rstd, float* __restrict__ red) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int z = 0; z < splits; ++z) {
+    s1 += part[(((size_t)z * N + n) * C + c) * 2];
+    s2 += part[(((size_t)z * N + n) * C + c) * 2 + 1];
+  }
+  const int g = c / (C / groups);
+  const double mean = mean_rstd[(n * groups + g) * 2], rstd = mean_rstd[(n * groups + g) * 2 + 1];
+  red[(size_t)i * 2] = (float)s1;
+  red[(size_t)i * 2 + 1] = (float)(rstd * (s2 - mean * s1));
+}
+
+extern "C" int BRATS_API(brats_gn_act_bwd_tiles)(const float* tile_stats, int tiles_per_sample, const void* dz, int dzpitch, const void* y,
+                                      int ypitch, const float* scale_shift, const float* mean_rstd, const float* gamma, void* dy,
+                                      int dypitch, float* red, float* dgamma, float* dbeta, int dtype, int act, float slope,
+                                      int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
+  if (!tile_stats || !dz || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma || tiles_per_sample <= 0)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_tiles: null pointer");
+  if (dtype != BRATS_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_tiles: 16-bit activations only");
+  if (act != BRATS_ACT_RELU && act != BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_tiles: relu / leakyrelu only (act %d)", act);
+  if (C % 8 || C % groups || dzpitch % 8 || ypitch % 8 || dypitch % 8 || C / 8 > 256)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_tiles: C=%d / pitches must be multiples of 8", C);
+  hipStream_t st = (hipStream_t)s;
+  // f64 slab partials behind the [N][C][2] totals, inside the workspace brats_gn_bwd_ws_floats() sizes (64 x N x C x 2 doubles)
+  double* part = (double*)(red + (((size_t)N * C * 2 + 1) / 2) * 2);
+  const int splits = gn_splits(tiles_per_sample);
+  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, splits), dim3(256), 0, st, tile_stats, tiles_per_sample, C, part);
+  hipLaunchKernelGGL(gn_bwd_tiles_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, splits, N, C, groups, mean_rstd, red);
+  const int cv = C / 8, vl = 256 / cv;
+  const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
+  const bool big = stream_nt((size_t)N * voxels * C * 2);
+  dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
+  const size_t lds2 = (size_t)2 * groups * sizeof(float);
+  const SlopeArg sl{slope, nullptr};
+  if (big)
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false, true, 0>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y, ypitch,
+                       scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, sl, N, voxels, C, groups, (uint32_t*)amax, HeadFold{});
+  else
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false, false, 0>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y, ypitch,
+                       scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, sl, N, voxels, C, groups, (uint32_t*)amax, HeadFold{});
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 // GroupNorm + activation backward of a layer whose output feeds only a 1x1x1 head convolution with K = 3 logit planes (the
 // network's last ConvBnRelu + outconv, networks/equiunet2020.py:488): dz is never materialised (HeadFold above), and the
 // head's dweight [K][C] / dbias [K] come out of the same passes.  Replaces brats_head_bwd(scale 1) + brats_gn_act_bwd.

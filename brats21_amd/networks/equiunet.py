@@ -213,13 +213,20 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
 
 
 def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None, head=None,
-             pool=None):
+             pool=None, bst=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
+    bst: the record of the unit that PRODUCED this unit's input (the first unit of the block).  Where the kernel form is built,
+    the input-gradient launch also takes the first pass of that unit's GroupNorm backward (ops.conv3d_bstats) and dx is
+    returned as (dx, tile_stats); handed on as `dz`, such a pair makes this function finish from the tile sums
+    (ops.gn_act_bwd_tiles) instead of reading dz and y twice.
     fp8 == "all": the input gradient (dgrad) and -- for the dilation-1 layers the all-taps kernel covers -- the weight
     gradient run on the e4m3 kernels too, scaled by the |max| of dy that the GroupNorm backward records (and the |max| of
     the layer input recorded in the forward pass)."""
     unit, x, x2, y, mean_rstd, scale_shift = rec
     cin = unit.conv.weight.shape[1]
+    tiles = None
+    if isinstance(dz, tuple):
+        dz, tiles = dz
     all8 = fp8 == "all" and ops.is16(dtype)
     f8 = all8 and need_dx and ops.conv_f8_chunk(y.shape[-1]) > 0
     # e4m3 weight gradient: where the all-taps kernel is built for the layer and the producers of x (x2) recorded |max|
@@ -258,6 +265,9 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         # (d_skip, d_pooled, arg-max bytes) -- the pooling backward's output tensor is never written (ops.gn_act_bwd_pool)
         dy, dgamma, dbeta = ops.gn_act_bwd_pool(pool[0], pool[1], pool[2], y, scale_shift, mean_rstd, unit.bn.weight.detach(),
                                                 unit.groups, kact, amax=amax)
+    elif tiles is not None:
+        dy, dgamma, dbeta = ops.gn_act_bwd_tiles(tiles, dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact,
+                                                 amax=amax)
     else:
         dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
                                            slope_t=slope_t)
@@ -297,6 +307,12 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         def dgrad(**kw):
             return ops.conv3d(dy, wpk, cin, 3, unit.dilation, amax=amax if x3s else None, **kw)
     if x2 is None:
+        if bst is not None and not f8 and not x3s:
+            u1, _, _, y1, mr1, ss1 = bst
+            kact1, slope1 = _unit_act(u1, act)
+            if (not u1.batch_norm and mr1 is not None and y1.shape[-1] == cin and y1.dtype == dy.dtype
+                    and ops.conv_bstats_ok(dtype, unit.dilation, dy.shape[-1], cin, kact1, slope1)):
+                return ops.conv3d_bstats(dy, wpk, cin, unit.dilation, y1, ss1, kact1)  # (dx, tile sums of u1's GroupNorm backward)
         dx, _ = dgrad()
         return dx
     c1 = x.shape[-1]
@@ -415,16 +431,19 @@ class _EquiUnetFn(torch.autograd.Function):
         for u in rec:
             u._side_small_only = m.wgrad_stream == "small"
 
-        def cbw(unit, dz, need_dx=True, head=None, pool=None):
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head, pool)
+        def cbw(unit, dz, need_dx=True, head=None, pool=None, first=None):
+            # first: the block's first unit, whose output is this unit's only input -- its GroupNorm backward's first pass rides
+            # in this unit's input-gradient launch (model.fold_bwd_stats)
+            bst = rec[first] if (first is not None and m.fold_bwd_stats) else None
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head, pool, bst)
 
-        def level_bwd(unit, down, d_pooled, d_skip, need_dx=True):
+        def level_bwd(unit, down, d_pooled, d_skip, need_dx=True, first=None):
             """Backward of the last layer of an encoder level: its output gradient = d_skip + max-pool backward(d_pooled)."""
             idx = getattr(down, "_pool_argmax", None)
             kact, slope_t = _unit_act(unit, act)
             if idx is not None and m.fold_pool_bwd and not unit.batch_norm and slope_t is None and kact in ("relu", "leakyrelu"):
-                return cbw(unit, None, need_dx, pool=(d_skip, d_pooled, idx))
-            return cbw(unit, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip), need_dx)
+                return cbw(unit, None, need_dx, pool=(d_skip, d_pooled, idx), first=first)
+            return cbw(unit, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip), need_dx, first=first)
 
         # heads: d(logits) -> gradient w.r.t. their NDHWC source tensors
         dsrc = {}
@@ -454,20 +473,31 @@ class _EquiUnetFn(torch.autograd.Function):
         def plus(a, b):
             return a if b is None else a + b
 
-        d_c1 = cbw(m.decoder1.ConvBnRelu2, None, head=top) if top is not None else cbw(m.decoder1.ConvBnRelu2, extra(up1) if extra(up1) is not None else torch.zeros_like(up1))
-        d_skip1, d_u1 = cbw(m.decoder1.ConvBnRelu1, d_c1)
+        def blk(b):  # (first, second) unit of a block
+            return b.ConvBnRelu1, b.ConvBnRelu2
+
+        c1, c2 = blk(m.decoder1)
+        d_c1 = cbw(c2, None, head=top, first=c1) if top is not None else cbw(c2, extra(up1) if extra(up1) is not None else torch.zeros_like(up1), first=c1)
+        d_skip1, d_u1 = cbw(c1, d_c1)
         d_up2 = plus(ops.upsample_bwd(d_u1, 2), extra(up2))
-        d_skip2, d_u2 = cbw(m.decoder2.ConvBnRelu1, cbw(m.decoder2.ConvBnRelu2, d_up2))
+        c1, c2 = blk(m.decoder2)
+        d_skip2, d_u2 = cbw(c1, cbw(c2, d_up2, first=c1))
         d_up3 = plus(ops.upsample_bwd(d_u2, 2), extra(up3))
-        d_skip3, d_u3 = cbw(m.decoder3.ConvBnRelu1, cbw(m.decoder3.ConvBnRelu2, d_up3))
+        c1, c2 = blk(m.decoder3)
+        d_skip3, d_u3 = cbw(c1, cbw(c2, d_up3, first=c1))
         d_b2 = plus(ops.upsample_bwd(d_u3, 2), extra(bottom_2))
         d_skip4, d_bot = cbw(m.bottom_2, d_b2)
         d_bottom = plus(d_bot, extra(bottom))
-        d_down4 = d_skip4 + cbw(m.bottom.ConvBnRelu1, cbw(m.bottom.ConvBnRelu2, d_bottom))
-        d_p3 = cbw(m.encoder4.ConvBnRelu1, cbw(m.encoder4.ConvBnRelu2, d_down4))
-        d_p2 = cbw(m.encoder3.ConvBnRelu1, level_bwd(m.encoder3.ConvBnRelu2, down3, d_p3, d_skip3))
-        d_p1 = cbw(m.encoder2.ConvBnRelu1, level_bwd(m.encoder2.ConvBnRelu2, down2, d_p2, d_skip2))
-        cbw(m.encoder1.ConvBnRelu1, level_bwd(m.encoder1.ConvBnRelu2, down1, d_p1, d_skip1), need_dx=False)
+        c1, c2 = blk(m.bottom)
+        d_down4 = d_skip4 + cbw(c1, cbw(c2, d_bottom, first=c1))
+        c1, c2 = blk(m.encoder4)
+        d_p3 = cbw(c1, cbw(c2, d_down4, first=c1))
+        c1, c2 = blk(m.encoder3)
+        d_p2 = cbw(c1, level_bwd(c2, down3, d_p3, d_skip3, first=c1))
+        c1, c2 = blk(m.encoder2)
+        d_p1 = cbw(c1, level_bwd(c2, down2, d_p2, d_skip2, first=c1))
+        c1, c2 = blk(m.encoder1)
+        cbw(c1, level_bwd(c2, down1, d_p1, d_skip1, first=c1), need_dx=False)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)  # every weight gradient is complete before autograd hands them on
         ctx.tape = ctx.bufs = None
@@ -526,6 +556,9 @@ class EquiUnet(_PackedWeightsModule):
         self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
         # the pooling backward + skip add inside the GroupNorm backward of the level's last layer (brats_gn_act_bwd_pool)
         self.fold_pool_bwd = os.environ.get("BRATS_FOLD_POOL", "1") != "0"
+        # GroupNorm backward's first pass (sum u, sum u * xhat) of a block's first unit inside the input-gradient launch of its
+        # second unit (brats_conv3d_fwd_bstats + brats_gn_act_bwd_tiles): dz and y are read once instead of twice
+        self.fold_bwd_stats = os.environ.get("BRATS_FOLD_BWD_STATS", "1") != "0"
         # ... and its forward on the last layer's raw convolution output (brats_gn_head_fwd): up1 is never stored
         self.fold_head_fwd = os.environ.get("BRATS_FOLD_HEAD_FWD", os.environ.get("BRATS_FOLD_HEAD", "1")) != "0"
         f = self.features

@@ -761,6 +761,49 @@ def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope
     return dy, dgamma, dbeta
 
 
+def conv_bstats_ok(dtype, dil, c1, cout, act="relu", slope_t=None):
+    """Is the "backward statistics" form of the 3x3x3 convolution (conv3d_bstats) built for this layer?"""
+    if not is16(dtype) or slope_t is not None or act not in ("relu", "leakyrelu"):
+        return False
+    return bool(_lib.lib().brats_conv3d_bstats_ok(_code(dtype), 3, dil, c1, cout))
+
+
+def conv3d_bstats(x, packed_w, cout, dil, fwd_y, scale_shift, act="relu", slope=0.01):
+    """The input gradient dz = conv(x = dy of a block's second unit, weights packed with PACK_DGRAD) that also leaves
+    GroupNorm backward's first pass for the block's FIRST unit (include/brats_hip.h: brats_conv3d_fwd_bstats): per tile and
+    channel sum u and sum u * fwd_y, u = dz * act'(fwd_y * scale + shift).  -> (dz, tile_stats) for gn_act_bwd_tiles()."""
+    ptr, c, p = _desc(x)
+    n, d, h, w, _ = x.shape
+    fp, fc, fpitch = _desc(fwd_y)
+    if fc != cout or fwd_y.dtype != x.dtype or tuple(fwd_y.shape[:4]) != (n, d, h, w):
+        raise _lib.BratsHipError("conv3d_bstats: the forward tensor must have the output's shape and dtype")
+    out = new_act(n, d, h, w, cout, x.dtype, x.device)
+    stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
+    # (a family of its own in the bench's kernel table: these launches carry a GroupNorm-backward pass in their epilogue and
+    #  are not the plain implicit GEMM the roofline line is about)
+    with _span("conv_igemm_bst", c, cout, 3, dil, n, d, h, w, str(x.dtype)):
+        _lib.check(_lib.lib().brats_conv3d_fwd_bstats(ptr, c, p, packed_w.data_ptr(), out.data_ptr(), cout, fp, fpitch,
+                                                      scale_shift.data_ptr(), ACTS[act], float(slope), stats.data_ptr(),
+                                                      _code(x.dtype), dil, n, d, h, w, cout, _stream()), "conv3d_fwd_bstats")
+    return out, stats
+
+
+def gn_act_bwd_tiles(tile_stats, dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None):
+    """gn_act_bwd whose first pass was taken by conv3d_bstats (tile_stats): -> (dy, dgamma, dbeta)."""
+    dzp, c, dzpitch = _desc(dz)
+    yp, _, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    dy = new_act(n, d, h, w, c, y.dtype, y.device)
+    red = torch.empty(_lib.lib().brats_gn_bwd_ws_floats(n, c), dtype=torch.float32, device=y.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().brats_gn_act_bwd_tiles(tile_stats.data_ptr(), tile_stats.shape[1], dzp, dzpitch, yp, ypitch,
+                                                 scale_shift.data_ptr(), mean_rstd.data_ptr(), _f32(gamma), dy.data_ptr(), c,
+                                                 red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _code(y.dtype), ACTS[act],
+                                                 float(slope), n, d * h * w, c, groups, _f32(amax), _stream()), "gn_act_bwd_tiles")
+    return dy, dgamma, dbeta
+
+
 def gn_act_bwd_head(dlogits, head_weight, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope=0.01, amax=None):
     """GroupNorm + activation backward of the layer under the 1x1x1 output head, the head's backward folded in
     (include/brats_hip.h: brats_gn_act_bwd_head): -> (dy, dgamma, dbeta, dhead_weight [K,C,1,1,1], dhead_bias [K])."""

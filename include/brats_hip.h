@@ -123,6 +123,19 @@ int brats_conv3d_pre_ok(int dtype, int ksize, int dil, int c1, int c2, int cout)
 int brats_conv3d_fwd_pre(const void* x1, int c1, int pitch1, const float* ss1, const void* x2, int c2, int pitch2,
                          const float* ss2, int act, float slope, const void* packed_w, const float* bias, void* y, int ypitch,
                          float* stats, int dtype, int dil, int N, int D, int H, int W, int cout, brats_stream_t s);
+/* "Backward statistics" form of the 16-bit 3x3x3 convolution (training).  In a ConvBnRelu pair (networks/equiunet2020.py:
+ * 105-123) the input gradient of the SECOND convolution is dz, the gradient of the first unit's activation
+ * z = act(GN(fwd_y)); GroupNorm backward's first pass over (dz, fwd_y) -- per (sample, channel) sum u and sum u * xhat with
+ * u = dz * act'(fwd_y * scale + shift) -- is taken here from the accumulators while the tile is stored: `tile_stats`
+ * [N][tiles_per_sample][cout][2] receives sum u and sum u * fwd_y per 4x4x16 tile (the layout of brats_conv3d_fwd's `stats`),
+ * and brats_gn_act_bwd_tiles() finishes from them.  fwd_y: the first unit's raw convolution output ([N][D][H][W][cout],
+ * pitch fwd_pitch), scale_shift [N][cout][2] as written by brats_gn_finalize; act BRATS_ACT_RELU or BRATS_ACT_LEAKY(slope).
+ * Saves one read of dz and of fwd_y per block (2 x 403 MB at the 128^3 level of EquiUnet-48).  Single source, no bias, no
+ * second destination; brats_conv3d_bstats_ok() = 1 where the form is built (cout a multiple of 48; c1 = the K channels). */
+int brats_conv3d_bstats_ok(int dtype, int ksize, int dil, int c1, int cout);
+int brats_conv3d_fwd_bstats(const void* x1, int c1, int pitch1, const void* packed_w, void* y, int ypitch,
+                            const void* fwd_y, int fwd_pitch, const float* scale_shift, int act, float slope,
+                            float* tile_stats, int dtype, int dil, int N, int D, int H, int W, int cout, brats_stream_t s);
 /* Split-precision form with an input scale (dtype BRATS_X3_F16 / BRATS_X3_BF16 only; 3x3x3): `xamax` (may be NULL = no
  * scaling) is a device scalar holding max|x| of the input -- written by the kernel that produced the tensor
  * (brats_gn_bwd_apply & co., brats_absmax).  The input is multiplied by the power of two that puts |max| into [2^14, 2^15)
@@ -235,6 +248,14 @@ int brats_gn_act_bwd(const void* dz, int dzpitch, const void* y, int ypitch, con
                      float* red /* workspace */, float* dgamma, float* dbeta,
                      int dtype, int act, float slope, const float* slope_dev, int N, int voxels, int C, int groups,
                      float* amax /* optional, zero before the call: receives max|dy| */, brats_stream_t s);
+/* The same backward with pass 1 replaced by the tile sums brats_conv3d_fwd_bstats() left (sum u, sum u * y per tile and
+ * channel): they are added in a fixed order in f64, sum u * xhat = rstd * (sum u*y - mean * sum u), then pass 2 as above.
+ * 16-bit activations, relu / leakyrelu; `red`: the same workspace. */
+int brats_gn_act_bwd_tiles(const float* tile_stats, int tiles_per_sample, const void* dz, int dzpitch, const void* y,
+                           int ypitch, const float* scale_shift, const float* mean_rstd, const float* gamma, void* dy,
+                           int dypitch, float* red /* workspace */, float* dgamma, float* dbeta, int dtype, int act,
+                           float slope, int N, int voxels, int C, int groups,
+                           float* amax /* optional, zero before the call: receives max|dy| */, brats_stream_t s);
 /* The same backward for the layer whose output feeds ONLY a 1x1x1 head convolution with K = 3 logit planes -- the network's
  * last ConvBnRelu + outconv (networks/equiunet2020.py:488): dz[v][c] = sum_k dlogits[k][v] * hw[k][c] is computed inside both
  * passes from the 12 bytes of dlogits per voxel instead of being written (2 * C bytes per voxel) by brats_head_bwd and read

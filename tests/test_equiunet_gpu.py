@@ -313,6 +313,58 @@ def test_prelu_network_vs_reference_golden_and_oracle(golden_dir):
     assert l1 < l0 and bool((after != before).all()) and bool(torch.isfinite(after).all())
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("act,norm", [("relu", "group"), ("leakyrelu", "instance")])
+def test_backward_statistics_fold_leaves_the_step_unchanged(precision, act, norm):
+    """model.fold_bwd_stats (round 4): the first pass of a block's first GroupNorm backward inside the input-gradient launch of
+    the block's second convolution (brats_conv3d_fwd_bstats + brats_gn_act_bwd_tiles), EquiUnet-48: all eight blocks take the
+    fused form, the forward is untouched, and the gradients equal the two-pass form's up to the rounding of dz (the fused
+    sums see the f32 accumulators, the two-pass sums the stored 16-bit values)."""
+    import argparse, contextlib, copy, io
+    from brats21_amd import get_model, ops, synth
+    from brats21_amd.losses import DiceLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ns = argparse.Namespace(model="equiunet", width=48, norm=norm, act=act, num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = get_model(ns).to(dev).train()
+    base.precision = precision
+    x = synth.random_image(2, 4, (32, 32, 32), seed=7, device=dev)
+    t = synth.nested_spheres(2, (32, 32, 32), device=dev)
+    crit = DiceLoss().to(dev)
+    calls = []
+    real = ops.conv3d_bstats
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    def run(fold):
+        model = copy.deepcopy(base)
+        model.fold_bwd_stats = fold
+        out, deep = model(x)
+        loss = crit(out.float(), t) + sum(crit(d.float(), t) for d in deep)
+        loss.backward()
+        return [p.grad.detach().clone() if p.grad is not None else None for p in model.parameters()]
+
+    ops.conv3d_bstats = counted
+    try:
+        g1 = run(True)
+        n_fused = len(calls)
+        g0 = run(False)
+    finally:
+        ops.conv3d_bstats = real
+    assert n_fused == 8 and len(calls) == 8
+    tol = 4e-2 if precision == "bf16" else 1e-2
+    for (n, _), a, b in zip(base.named_parameters(), g1, g0):
+        assert (a is None) == (b is None), n
+        if a is None:
+            continue
+        assert bool(torch.isfinite(a).all()), n
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= tol * scale, (n, float((a - b).abs().max()) / scale)
+
+
 @pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_fold_forms_leave_the_step_unchanged(name, precision):

@@ -640,3 +640,65 @@ def test_pack_weights_matches_layout_oracle(dtype, cout, cin, k, mode, cin_off, 
         want = ref.to(dtype)
         got = packed.view(dtype).cpu().reshape(want.shape)
     assert torch.equal(got.view(torch.int16 if dtype != torch.float32 else torch.int32), want.view(torch.int16 if dtype != torch.float32 else torch.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c2,c1,dil,n,size,act", [
+    (48, 48, 1, 2, (8, 16, 32), "relu"),        # the 4x8x16-tile kernel (24-channel chunks), whole tiles
+    (48, 48, 1, 1, (6, 10, 20), "leakyrelu"),   # ragged volume: masked statistics, partial tiles in every direction
+    (96, 96, 1, 1, (8, 8, 32), "relu"),         # 4x4x16 tile, 96-row workgroups
+    (96, 192, 1, 1, (4, 8, 16), "relu"),        # small grid: the y-split roles
+    (384, 384, 2, 1, (4, 4, 16), "relu"),       # the dilated bottom block
+    (48, 96, 1, 1, (4, 12, 16), "relu"),
+])
+def test_conv3d_bstats_matches_two_pass_groupnorm_backward(dtype, c2, c1, dil, n, size, act):
+    """brats_conv3d_fwd_bstats + brats_gn_act_bwd_tiles (GroupNorm backward's first pass taken from the accumulators of the
+    input-gradient convolution) against brats_conv3d_fwd + brats_gn_act_bwd on the same data: the same dz bit for bit; the
+    sums differ only by where dz was rounded to 16 bits (the two-pass form sums the stored values, the fused form the f32
+    accumulators) and by f64 against f32 partial sums."""
+    from brats21_amd import ops
+    dev = _dev()
+    d, h, w = size
+    groups = 8
+    assert ops.conv_bstats_ok(dtype, dil, c2, c1, act)
+    y1 = _rand((n, d, h, w, c1), 5).to(dev).to(dtype)
+    gamma, beta = (1.0 + 0.3 * _rand((c1,), 6)).to(dev), (0.2 * _rand((c1,), 7)).to(dev)
+    yf = y1.float().reshape(n, -1, groups, c1 // groups)
+    mean = yf.mean((1, 3))
+    rstd = (yf.var((1, 3), unbiased=False) + 1e-5).rsqrt()
+    mean_rstd = torch.stack([mean, rstd], -1).contiguous()                                   # [n][g][2]
+    sc = rstd.repeat_interleave(c1 // groups, 1) * gamma
+    scale_shift = torch.stack([sc, beta - mean.repeat_interleave(c1 // groups, 1) * sc], -1).contiguous()  # [n][c][2]
+    dy2 = (_rand((n, d, h, w, c2), 8) * 0.05).to(dev).to(dtype)
+    w2 = (_rand((c2, c1, 3, 3, 3), 9) * 0.05).to(dev)
+    wpk = ops.pack_weights(w2, dtype, ops.PACK_DGRAD, dil=dil)
+    dz_a, _ = ops.conv3d(dy2, wpk, c1, 3, dil)
+    dy_a, dg_a, db_a = ops.gn_act_bwd(dz_a, y1, scale_shift, mean_rstd, gamma, groups, act)
+    dz_b, tiles = ops.conv3d_bstats(dy2, wpk, c1, dil, y1, scale_shift, act)
+    dy_b, dg_b, db_b = ops.gn_act_bwd_tiles(tiles, dz_b, y1, scale_shift, mean_rstd, gamma, groups, act)
+    torch.cuda.synchronize()
+    assert torch.equal(dz_a, dz_b)
+    # f64 statements of the sums: from the stored 16-bit dz (what the two-pass form adds up) and from the unrounded dz (what
+    # the fused form sees in its accumulators; taken here from the exact-f32 kernel on the same 16-bit operands)
+    w2r = w2.to(dtype).float()
+    dz32, _ = ops.conv3d(dy2.float(), ops.pack_weights(w2r, torch.float32, ops.PACK_DGRAD, dil=dil), c1, 3, dil)
+    pre = y1.double() * scale_shift[..., 0].double()[:, None, None, None, :] + scale_shift[..., 1].double()[:, None, None, None, :]
+    mask = torch.where(pre > 0, 1.0, 0.0 if act == "relu" else 0.01)
+    xhat = ((y1.double().reshape(n, -1, groups, c1 // groups) - mean.double()[:, None, :, None]) * rstd.double()[:, None, :, None]).reshape(pre.shape)
+
+    def sums(dz):
+        u = dz.double() * mask
+        return u.sum((0, 1, 2, 3)), (u * xhat).sum((0, 1, 2, 3))
+
+    db_st, dg_st = sums(dz_a)
+    db_ex, dg_ex = sums(dz32)
+    scale = float(dg_ex.abs().max()) + float((dz32.double().abs() * xhat.abs()).sum((0, 1, 2, 3)).max()) * 1e-3
+    assert float((dg_a.double() - dg_st).abs().max()) <= 2e-5 * scale and float((db_a.double() - db_st).abs().max()) <= 2e-5 * scale
+    assert float((dg_b.double() - dg_ex).abs().max()) <= 2e-5 * scale, float((dg_b.double() - dg_ex).abs().max()) / scale
+    assert float((db_b.double() - db_ex).abs().max()) <= 2e-5 * scale, float((db_b.double() - db_ex).abs().max()) / scale
+    # the two forms against each other: the rounding of dz to 16 bits
+    eps16 = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    torch.testing.assert_close(dg_b, dg_a, atol=eps16 * scale, rtol=0)
+    torch.testing.assert_close(db_b, db_a, atol=eps16 * scale, rtol=0)
+    dscale = float(dy_a.float().abs().max())
+    torch.testing.assert_close(dy_b.float(), dy_a.float(), atol=4 * eps16 * dscale, rtol=0)
