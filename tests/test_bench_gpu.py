@@ -39,3 +39,25 @@ def test_bench_x3_precision_runs_the_split_kernels():
     r = _bench("--width", "8", "--patch", "32", "--steps", "3", "--warmup", "1", "--precision", "x3", "--no-infer", "--no-cpu-baseline",
                "--no-parity-leg")
     assert r["dtype"] == "x3" and r["roofline"]["peak"] < 1000.0  # a third of the 16-bit peak: three MFMAs per product
+
+
+def test_bench_roofline_stays_on_the_plain_kernel_beside_the_backward_statistics_form():
+    """Width 48: the blocks' second input-gradient launches carry a GroupNorm-backward pass (family conv_igemm_bst).  The
+    roofline line must name a plain implicit-GEMM launch (whole work = the FLOPs in its numerator) and list the fused form
+    beside it; with BRATS_FOLD_BWD_STATS=0 the family is absent."""
+    args = ("--width", "48", "--patch", "32", "--steps", "3", "--warmup", "1", "--no-infer", "--no-cpu-baseline", "--no-parity-leg")
+    r = _bench(*args)
+    rf = r["roofline"]
+    assert rf["kernel"].startswith("conv_igemm ") and "conv_igemm_bst" in rf["families"]
+    ff = rf["fused_epilogue_form"]
+    assert ff["kernel"].startswith("conv_igemm_bst ") and ff["launches"] > 0 and ff["avg_ms"] > 0
+    old = os.environ.get("BRATS_FOLD_BWD_STATS")
+    os.environ["BRATS_FOLD_BWD_STATS"] = "0"
+    try:
+        r0 = _bench(*args)
+    finally:
+        if old is None:
+            os.environ.pop("BRATS_FOLD_BWD_STATS")
+        else:
+            os.environ["BRATS_FOLD_BWD_STATS"] = old
+    assert "conv_igemm_bst" not in r0["roofline"]["families"] and "fused_epilogue_form" not in r0["roofline"]
