@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric on MI355X: train patches/s of EquiUnet width 48 on synthetic
 4x128^3 patches, batch 2 per GPU, bf16 (configs[1]); one "step" = forward + deep-supervision Dice
-loss + backward + gradient all-reduce (N > 1) + Adam step.  Prints ONE JSON line on rank 0.
+loss + backward + gradient all-reduce (N > 1) + fused Ranger2020 step (the reference's default optimizer; --optimizer adam for
+torch's Adam).  Prints ONE JSON line on rank 0; at N = 1 the line also carries the other stated configurations as short legs
+(configs2_per_gpu, configs4_per_gpu, fp16_mode, inference*, parity_mode) measured AFTER the headline's timed region.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
@@ -115,6 +117,85 @@ def parity_mode_leg(args, dev, x, t):
     return out
 
 
+def side_train_leg(dev, rank, model_name, width, batch, precision, warmup, steps, what, fp8=None, graph=False, patch=128):
+    """A short training leg of another stated configuration on a FRESH model (own weights, own optimizer), run after the
+    headline's timed region: ``warmup`` untimed + ``steps`` timed steps of the same step body as the headline (forward +
+    deep-supervision Dice + backward + fused Ranger2020), fp16 under the reference's GradScaler loop."""
+    import argparse as _ap, contextlib, io
+    from brats21_amd import get_model, synth
+    from brats21_amd.engine import GraphedTrainStep, TrainStep
+    from brats21_amd.optim import Ranger2020
+    torch.manual_seed(0)
+    ns = _ap.Namespace(model=model_name, width=width, norm="group", act="relu", num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = get_model(ns).to(dev).train()
+        opt = Ranger2020(m.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5,
+                         capturable=graph)
+    if fp8:
+        m.conv_fp8 = fp8
+    size = (patch,) * 3
+    x = synth.random_image(batch, 4, size, seed=1234 + rank, device=dev)
+    t = synth.nested_spheres(batch, size, device=dev)
+    amp_dtype = torch.float16 if precision == "fp16" else torch.bfloat16
+    step = TrainStep(m, opt, criterion=None, amp=True, amp_dtype=amp_dtype)
+    if graph:
+        step = GraphedTrainStep(step, warmup=2)
+    for _ in range(warmup):
+        step(x, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x, t)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"config": what, "dtype": precision + (f"+e4m3 conv ({fp8})" if fp8 else ""), "ms_per_step": round(ms, 2),
+           "patches_per_s": round(batch / ms * 1e3, 2), "patches_per_gpu": batch, "warmup": warmup, "steps": steps,
+           "loss": round(float(loss.item()), 5)}
+    if getattr(step, "scaler", None) is not None:
+        out["grad_scale"] = float(step.scaler.get_scale())
+    del step, opt, m, x, t
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_configs_legs(dev, rank, patch=128):
+    """The stated configurations the headline line does not time, ~1 s each on one GPU."""
+    legs = {}
+    legs["configs2_per_gpu"] = side_train_leg(
+        dev, rank, "equiunet_assp_evo", 48, 2, "bf16", 5, 10,
+        "equiunet_assp_evo width=48, 2 patches of 4x128^3 per GPU, bf16, eager step (BASELINE.json configs[2]: one rank's share of "
+        "the 8-GPU batch of 16; the all-reduce is not part of a world-1 leg)", patch=patch)
+    legs["configs2_per_gpu"]["as_one_hipgraph"] = side_train_leg(
+        dev, rank, "equiunet_assp_evo", 48, 2, "bf16", 3, 10, "the same step replayed as one hipGraph (GraphedTrainStep)", graph=True, patch=patch)
+    legs["fp16_mode"] = side_train_leg(
+        dev, rank, "equiunet", 48, 2, "fp16", 5, 10,
+        "the headline workload (equiunet width=48, 2 x 4x128^3) in the REFERENCE's own arithmetic: torch.autocast(float16) + "
+        "GradScaler loop (learning/engine.py:304,117-122), fp16 MFMA kernels", patch=patch)
+    legs["configs4_per_gpu"] = side_train_leg(
+        dev, rank, "equiunet_assp_evo", 64, 4, "fp16", 3, 6,
+        "equiunet_assp_evo width=64, 4 patches of 4x128^3 per GPU, fp16 storage + e4m3 MFMA convolutions forward / input gradient / "
+        "weight gradient (BASELINE.json configs[4]: one rank's share of the 8-GPU batch of 32)", fp8="all", patch=patch)
+    return legs
+
+
+def gpu_count_without_hip():
+    """GPUs of this node read from the KFD topology in sysfs -- no HIP / HSA call, so the launcher process stays a process that
+    never initialised the GPU (torch.cuda.device_count() may fall through to hipGetDeviceCount).  None = unknown."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for p in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(p) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n
+
+
 def kernel_source_sha():
     """Identity of the convolution kernels' source (what a committed PMC profile must have been taken with)."""
     import hashlib
@@ -217,8 +298,8 @@ def launch_ranks(n, argv, dry_run=False):
     import socket
     import subprocess
     if not dry_run and os.environ.get("BRATS_DIST_BACKEND") != "gloo":  # (gloo: the debugging set-up with ranks sharing a GPU)
-        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-        if have < n:
+        have = gpu_count_without_hip()  # (sysfs; unknown -> the ranks' own device / WORLD_SIZE checks fail loudly instead)
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but this node has {have} GPU(s)", file=sys.stderr)
             return 2
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -272,6 +353,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip the fp32 (1e-3 logit parity) timing leg")
     ap.add_argument("--no-infer", action="store_true", help="skip the sliding-window + TTA inference measurement")
+    ap.add_argument("--other-configs-patch", type=int, default=0, help="(tests) run the other-configuration legs at this patch size")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs of the other stated configurations (configs2_per_gpu, fp16_mode, configs4_per_gpu)")
     ap.add_argument("--infer-headline-only", action="store_true", help="only the configs[3] inference leg (8-flip, overlap 0.5)")
     ap.add_argument("--torch-dice", dest="fused_dice", action="store_false",
                     help="use the PyTorch Dice loss (reference path) instead of the fused HIP Dice passes")
@@ -496,6 +580,12 @@ def main():
         res["dtype_note"] = ("value is measured in bf16 storage / f32 accumulate: hard Dice within 1e-3 of the CPU oracle "
                              "(tests/test_headline_gpu.py), logits NOT within 1e-3 (max ~0.3 on |logits| <= 28); the 1e-3-logit "
                              "configuration is parity_mode")
+    if world == 1 and not args.no_other_configs and (args.model, args.width, args.precision, args.fp8, args.batch) == ("equiunet", 48, "bf16", None, 2) \
+            and (args.patch == 128 or args.other_configs_patch):
+        del train_step, opt
+        model.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        res.update(other_configs_legs(dev, rank, args.other_configs_patch or 128))
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.width, os.cpu_count() or 1)
     print(json.dumps(res))

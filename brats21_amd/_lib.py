@@ -86,7 +86,7 @@ def lib():
     # through BRATS_HIP_LIB whose entry points changed signature) would be called with the wrong argument lists
     want = _header_abi_version()
     got = l.brats_abi_version()
-    if want is not None and got != want:
+    if got != want:
         raise BratsHipError(f"{LIB_PATH} reports ABI version {got}, include/brats_hip.h declares {want}: rebuild the library "
                             "(an A/B library must come from a tree with the same entry-point signatures)")
     _lib = l
@@ -94,12 +94,11 @@ def lib():
 
 
 def _header_abi_version():
-    """The version the header's comment on brats_abi_version() states for this round ("N in round ..." / "N since ...")."""
-    m = re.search(r"int brats_abi_version\(void\);\s*/\*(.*?)\*/", open(HEADER_PATH).read(), flags=re.S)
+    """``#define BRATS_ABI_VERSION N`` of include/brats_hip.h (the one place the version is written; abi.hip returns it)."""
+    m = re.search(r"^#define\s+BRATS_ABI_VERSION\s+(\d+)\s*$", open(HEADER_PATH).read(), flags=re.M)
     if not m:
-        return None
-    nums = re.findall(r"(\d+) (?:since|in) round", m.group(1))
-    return max(int(n) for n in nums) if nums else None
+        raise BratsHipError(f"{HEADER_PATH} does not define BRATS_ABI_VERSION")
+    return int(m.group(1))
 
 
 def check(rc, what):

@@ -10,5 +10,4 @@ void brats_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* brats_last_error(void) { return g_err; }
-// 2: round 3 (brats_maxpool2_fwd gained the arg-max output; fold entry points added)
-extern "C" int brats_abi_version(void) { return 4; }
+extern "C" int brats_abi_version(void) { return BRATS_ABI_VERSION; }  // include/brats_hip.h

@@ -89,6 +89,19 @@ class _PackedWeightsModule(nn.Module):
     every grad-enabled forward, so weights changed without a version bump (``p.data.copy_`` of the reference's
     Ranger2020, learning/optimizer.py:243,253) are never served stale to a later evaluation."""
 
+    PRECISIONS = ("auto", "bf16", "fp16", "fp32", "x3", "fp16x3", "bf16x3", "x3fwd", "x3bwd")
+
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        # a typo ("X3", "x3 ") must not fall through to autocast / exact f32 under a parity-mode label (ADVICE r4)
+        if value not in self.PRECISIONS:
+            raise ValueError(f"model.precision / BRATS_PRECISION must be one of {self.PRECISIONS}, got {value!r}")
+        self._precision = value
+
     def train(self, mode=True):
         if mode != self.training:
             ops.invalidate_packed_weights()

@@ -47,8 +47,11 @@ enum { BRATS_E_ARG = -1, BRATS_E_UNSUPPORTED = -2, BRATS_E_HIP = -3 };
  * memory (`slope_dev` of brats_affine_act / brats_gn_bwd_apply) + brats_prelu_slope_grad for its gradient. */
 enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_ELU = 3, BRATS_ACT_SWISH = 4, BRATS_ACT_MISH = 5 };
 
-int brats_abi_version(void); /* 2 since round 3: a changed signature (brats_maxpool2_fwd) bumps it; 3 in round 4 (additions only), then
-                                 4 in round 4: the block table of brats_conv3d_pack_weights_multi changed meaning */
+/* THE version: brats_abi_version() returns this define, the Python binding (brats21_amd/_lib.py) and tests/test_abi_cpu.py parse
+ * it.  History: 2 since round 3 (a changed signature, brats_maxpool2_fwd); 3 in round 4 (additions only); 4 in round 4 (the block
+ * table of brats_conv3d_pack_weights_multi changed meaning). */
+#define BRATS_ABI_VERSION 4
+int brats_abi_version(void);
 const char* brats_last_error(void);
 
 /* ---- layout ---------------------------------------------------------------------------------

@@ -71,3 +71,35 @@ def random_image(n, c, size, seed=1234):
     zz, yy, xx = np.meshgrid(np.linspace(-1, 1, d), np.linspace(-1, 1, h), np.linspace(-1, 1, w), indexing="ij")
     mask = torch.from_numpy(((zz / 0.95) ** 2 + (yy / 0.9) ** 2 + (xx / 0.85) ** 2 <= 1.0).astype(np.float32))
     return x * mask
+
+
+def tumour_phantom(n, size, seed, contrast=1.0):
+    """A BraTS-shaped volume whose label is a FUNCTION OF THE IMAGE (tests/test_trained_gpu.py trains on it, so that the
+    network's logits sit near the decision surface because it learned the target, not because the weights are random):
+    4 modalities of i.i.d. N(0,1) noise inside the brain ellipsoid of ``random_image`` plus, per modality, intensity offsets
+    inside three nested ellipsoids WT > TC > ET whose centre, radii and aspect are drawn per sample from ``seed`` (the way
+    z-scored FLAIR / T1 / T1ce / T2 behave over oedema, core and enhancing tumour).  Returns (image [n,4,D,H,W] f32,
+    target [n,3,D,H,W] {0,1} f32 in the reference's channel order TC, WT, ET, utils/transforms.py:155-166).
+    ``contrast`` scales the offsets (the training uses 1.0; a test volume at 0.5 puts a large share of the voxels near the
+    decision surface).  CPU generator only: bit-identical here and on the GPU box."""
+    g = torch.Generator().manual_seed(int(seed))
+    d, h, w = size
+    zz, yy, xx = np.meshgrid(np.linspace(-1, 1, d), np.linspace(-1, 1, h), np.linspace(-1, 1, w), indexing="ij")
+    brain = torch.from_numpy(((zz / 0.95) ** 2 + (yy / 0.9) ** 2 + (xx / 0.85) ** 2 <= 1.0).astype(np.float32))
+    zz, yy, xx = (torch.from_numpy(a.astype(np.float32)) for a in (zz, yy, xx))
+    # offsets per modality (rows) in WT-only, TC-only, ET regions (columns)
+    amp = float(contrast) * torch.tensor([[1.6, 0.9, 0.6], [-0.3, -1.2, -0.8], [0.2, 0.5, 2.0], [1.1, 1.5, 0.9]])
+    img = torch.randn(n, 4, d, h, w, generator=g)
+    tgt = torch.zeros(n, 3, d, h, w)
+    for i in range(n):
+        u = torch.rand(8, generator=g)
+        c = (u[:3] - 0.5) * 0.7
+        r = 0.34 + 0.2 * float(u[3])
+        asp = 0.8 + 0.4 * u[4:7]
+        q = ((zz - c[0]) / asp[0]) ** 2 + ((yy - c[1]) / asp[1]) ** 2 + ((xx - c[2]) / asp[2]) ** 2
+        wt, tc, et = (q <= r * r).float() * brain, (q <= (0.68 * r) ** 2).float() * brain, (q <= (0.42 * r) ** 2).float() * brain
+        for m in range(4):
+            img[i, m] += amp[m, 0] * (wt - tc) + amp[m, 1] * (tc - et) + amp[m, 2] * et
+        img[i] *= brain
+        tgt[i, 0], tgt[i, 1], tgt[i, 2] = tc, wt, et
+    return img, tgt

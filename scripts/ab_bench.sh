@@ -14,7 +14,7 @@ for rep in $(seq $reps); do for cfg in "${cfgs[@]}"; do
   set -- $cfg; label=$1; shift
   lib=$PWD/brats21_amd/libbrats_$label.so; envs=("$@"); [ -f "$lib" ] && [ "$label" != hip ] && envs+=("BRATS_HIP_LIB=$lib")
   echo -n "rep $rep | $cfg | " >> $out/ab.log
-  env "${envs[@]}" timeout 900 python3 bench.py --steps 30 --warmup 10 --no-infer --no-cpu-baseline --no-parity-leg "${extra[@]}" 2>>$out/ab.err | tail -1 | \
+  env "${envs[@]}" timeout 900 python3 bench.py --steps 30 --warmup 10 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs "${extra[@]}" 2>>$out/ab.err | tail -1 | \
     python3 -c "import json,sys; r=json.loads(sys.stdin.read()); f=r['roofline'] or {}; print(r['ms_per_step'], 'ms  loss', r['config']['loss'], '| dominant', f.get('avg_ms'), 'ms frac', f.get('frac'), 'of box', f.get('frac_of_box'), '| box', (r.get('box') or {}).get('mfma_TFLOPs'), 'TF', (r.get('box') or {}).get('stream_TBps'), 'TB/s |', {k: v['ms_per_step'] for k, v in (f.get('families') or {}).items()})" >> $out/ab.log 2>&1
 done; done
 cat $out/ab.log

@@ -2,8 +2,8 @@
 # Same-box per-kernel comparison of two builds: brats21_amd/libbrats_hip_ab.so (A) against the in-tree library (B).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/abprof; rm -rf $out; mkdir -p $out
-BRATS_HIP_LIB=$PWD/brats21_amd/libbrats_hip_ab.so BRATS_BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/A -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > $out/A.log 2>&1
-BRATS_BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/B -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg > $out/B.log 2>&1
+BRATS_HIP_LIB=$PWD/brats21_amd/libbrats_hip_ab.so BRATS_BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/A -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs > $out/A.log 2>&1
+BRATS_BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/B -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs > $out/B.log 2>&1
 python3 - <<'PY'
 import csv, glob, os
 def load(d):

@@ -61,3 +61,16 @@ def test_bench_roofline_stays_on_the_plain_kernel_beside_the_backward_statistics
         else:
             os.environ["BRATS_FOLD_BWD_STATS"] = old
     assert "conv_igemm_bst" not in r0["roofline"]["families"] and "fused_epilogue_form" not in r0["roofline"]
+
+
+def test_bench_other_stated_configurations_are_on_the_line():
+    """configs[2] (ASSP-48 bf16, eager + graph), the reference's fp16 + GradScaler loop and configs[4] (ASSP-64 fp16 + e4m3) ride
+    the default line as short legs; here at a 32^3 patch."""
+    r = _bench("--width", "48", "--patch", "32", "--steps", "3", "--warmup", "1", "--no-infer", "--no-cpu-baseline", "--no-parity-leg",
+               "--other-configs-patch", "32")
+    for leg, dtype in (("configs2_per_gpu", "bf16"), ("fp16_mode", "fp16"), ("configs4_per_gpu", "fp16+e4m3 conv (all)")):
+        assert leg in r, leg
+        assert r[leg]["dtype"] == dtype and r[leg]["ms_per_step"] > 0 and r[leg]["loss"] == r[leg]["loss"]
+        assert abs(r[leg]["patches_per_s"] - r[leg]["patches_per_gpu"] / (r[leg]["ms_per_step"] * 1e-3)) < 0.02 * r[leg]["patches_per_s"]
+    assert r["configs2_per_gpu"]["as_one_hipgraph"]["ms_per_step"] > 0 and "grad_scale" in r["fp16_mode"]
+    assert r["metric"].startswith("train patches/sec") and r["dtype"] == "bf16"  # headline fields unchanged

@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from brats21_amd import inferers, tta
@@ -116,3 +117,34 @@ def test_oracle_input_pipeline_known_answers():
     assert [int(i.max() - i.min()) + 1 for i in nz] == [3, 13, 9]
     assert abs(float(g.sum()) - 1.0) < 2e-4 and np.isclose(g[7, 7, 7], g.max())
     assert np.allclose(g, g[::-1, ::-1, ::-1])
+
+
+def test_precision_is_validated_at_construction_and_on_assignment(monkeypatch):
+    """a mistyped model.precision / BRATS_PRECISION must raise instead of silently running another mode."""
+    import argparse
+    import contextlib
+    import io
+    import warnings
+    from brats21_amd import get_model
+
+    def make(model, width):
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return get_model(argparse.Namespace(model=model, width=width, norm="group", act="relu", num_classes=3, dropout=0))
+
+    for model, width in (("equiunet", 8), ("equiunet_assp_evo", 16)):
+        m = make(model, width)
+        assert m.precision == "auto"
+        for ok in ("bf16", "fp16", "fp32", "x3", "bf16x3", "auto"):
+            m.precision = ok
+            assert m.precision == ok
+        for bad in ("X3", "x3 ", "float32", None):
+            with pytest.raises(ValueError):
+                m.precision = bad
+        assert m.precision == "auto"
+        monkeypatch.setenv("BRATS_PRECISION", "x3")
+        assert make(model, width).precision == "x3"
+        monkeypatch.setenv("BRATS_PRECISION", "x3 ")
+        with pytest.raises(ValueError):
+            make(model, width)
+        monkeypatch.delenv("BRATS_PRECISION")

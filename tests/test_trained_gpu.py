@@ -1,0 +1,168 @@
+"""-m gpu: the Dice / logit bars of north_star on TRAINED weights ("next round" item 1).
+
+Every other parity test runs the networks at their initialisation, where the thresholded prediction has little to do with
+the target (hard Dice 0.0 ... 0.19 on two of three channels): "Dice within 1e-3" says nothing there.  Here both width-48
+networks are first TRAINED on the GPU -- split-precision mode (model.precision = "x3"), GraphedTrainStep, fused Dice, Ranger2020
+-- on oracle.synth.tumour_phantom volumes, whose label is a function of the image (intensity offsets of nested ellipsoids
+under unit noise), until the logits sit around the decision surface because the network learned the target.  Then, with
+those weights and on volumes the training never saw:
+
+  * the CPU oracle (oracle/unet.py, the reference's CPU arithmetic) must itself reach hard Dice >= 0.5 on all three channels
+    -- otherwise the test FAILS rather than compare degenerate numbers;
+  * f32 and x3 logits within 1e-3 abs of the oracle (one 128^3 patch; the stitched logits of a configs[3] volume,
+    4x240x240x155 padded to 160, 18 windows, for EquiUnet);
+  * bf16 and fp16 (the reference's own autocast dtype, learning/engine.py:304): hard Dice against the target within 1e-3 of
+    the oracle's, with the margin and the fraction of thresholded voxels that flipped printed;
+  * the benchmarked chain (sliding window + 8-flip TTA, Evaluator: learning/engine.py:236-259, src/definer.py:696-697) in
+    bf16 / fp16 against the same chain in f32, whose network arithmetic the stitched-logit check has just pinned.
+The numbers land in profiles/ through scripts/gpu_suite.sh (pytest -s)."""
+import argparse
+import contextlib
+import io
+import os
+import warnings
+
+import pytest
+import torch
+
+from oracle import inference as oinf
+from oracle import synth, unet
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+LOGIT_ATOL = 1e-3
+DICE_ATOL = 1e-3
+PATCH = (128, 128, 128)
+VOL = (240, 240, 155)
+STEPS = {"equiunet": 320, "equiunet_assp_evo": 320}
+POOL = 12  # training batches of 2 patches, cycled
+
+
+def _get(model):
+    from brats21_amd import get_model
+    torch.manual_seed(0)
+    ns = argparse.Namespace(model=model, width=48, norm="group", act="relu", num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return get_model(ns)
+
+
+_trained = {}
+
+
+def _train(model):
+    """x3-mode training run on the phantom; returns (module on the GPU in eval mode, CPU state dict, loss curve)."""
+    if model in _trained:
+        return _trained[model]
+    from brats21_amd.engine import GraphedTrainStep, TrainStep
+    from brats21_amd.optim import Ranger2020
+    m = _get(model).to(DEV).train()
+    m.precision = "x3"
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = Ranger2020(m.parameters(), lr=2e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5,
+                         capturable=True)
+    step = GraphedTrainStep(TrainStep(m, opt, criterion=None, amp=False))
+    pool = [tuple(a.to(DEV) for a in synth.tumour_phantom(2, PATCH, 5000 + i)) for i in range(POOL)]
+    curve = []
+    for it in range(STEPS[model]):
+        x, t = pool[it % POOL]
+        loss = step(x, t)
+        if it % 20 == 0 or it == STEPS[model] - 1:
+            curve.append((it, float(loss.item())))
+    del step, pool
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    print(f"\n{model}-48 trained {STEPS[model]} x3 steps on 2x4x128^3 phantoms: loss " + " ".join(f"{i}:{l:.3f}" for i, l in curve))
+    _trained[model] = (m, sd, curve)
+    return _trained[model]
+
+
+def _oracle(model, sd, x):
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    fwd = unet.equiunet_forward if model == "equiunet" else unet.assp_evo_forward
+    with torch.no_grad():
+        return fwd(sd, x)[0]
+
+
+def _report(tag, out, ref, t, d_ref):
+    dev = (out - ref).abs()
+    d = unet.hard_dice(out, t)
+    flips = float(((out > 0) != (ref > 0)).float().mean())
+    margin = float((d - d_ref).abs().max())
+    print(f"  {tag}: logits max {float(dev.max()):.3e} mean {float(dev.mean()):.3e}; hard Dice {[round(v, 5) for v in d.flatten().tolist()]} "
+          f"|dDice| max {margin:.2e} (bar {DICE_ATOL:.0e}); thresholded voxels flipped {flips:.3e}")
+    return margin, flips
+
+
+@pytest.mark.parametrize("model", ["equiunet", "equiunet_assp_evo"])
+def test_trained_patch_logits_and_dice_vs_oracle(model):
+    """Two volumes the training never saw: one like the training set (contrast 1.0: Dice ~0.98, few voxels near the decision
+    surface) and one at HALF the contrast, where the trained network is unsure over a large share of the lesion."""
+    m, sd, curve = _train(model)
+    assert curve[-1][1] < 0.6 * curve[0][1], curve  # it did learn
+    xd_all = {}
+    for contrast, seed in ((1.0, 777), (0.5, 778)):
+        x, t = synth.tumour_phantom(1, PATCH, seed, contrast=contrast)
+        ref = _oracle(model, sd, x)
+        d_ref = unet.hard_dice(ref, t)
+        near = float((ref.abs() < 0.5).float().mean())
+        print(f"\n{model}-48 TRAINED, fresh 4x128^3 phantom at contrast {contrast}: oracle hard Dice (TC, WT, ET) "
+              f"{[round(v, 4) for v in d_ref.flatten().tolist()]}, |logits| max {float(ref.abs().max()):.2f}, voxels with |logit| < 0.5: {near:.3e}")
+        assert float(d_ref.min()) >= 0.5, f"the oracle's own Dice with the trained weights is degenerate: {d_ref}"
+        xd = x.to(DEV)
+        res = {}
+        with torch.no_grad():
+            for prec in ("fp32", "x3", "bf16", "fp16"):
+                m.precision = prec
+                out = m(xd)
+                out = (out[0] if isinstance(out, (tuple, list)) else out).float().cpu()
+                res[prec] = _report(prec, out, ref, t, d_ref) + (float((out - ref).abs().max()),)
+        m.precision = "x3"
+        assert res["fp32"][2] < LOGIT_ATOL and res["x3"][2] < LOGIT_ATOL, res
+        for prec in ("fp32", "x3", "bf16", "fp16"):
+            assert res[prec][0] <= DICE_ATOL, (contrast, prec, res[prec])
+
+
+def test_trained_config3_sliding_window_flip8_vs_oracle():
+    """configs[3] with the trained EquiUnet-48: one phantom volume 4x240x240x155, padded to 160, 128^3 windows, overlap 0.5."""
+    from brats21_amd import tta
+    from brats21_amd.evaluate import Evaluator, hard_dice_metric, shape_to_divisible
+    from brats21_amd.inferers import sliding_window_inference
+    m, sd, _ = _train("equiunet")
+    m.skip_deep_heads_in_eval = True
+    x, t = synth.tumour_phantom(1, VOL, 888)
+    xd, td = x.to(DEV), t.to(DEV)
+    padded, p_b, p_a = shape_to_divisible(xd, k=8)
+    assert tuple(padded.shape[2:]) == (240, 240, 160)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = oinf.sliding_window_inference(padded.cpu(), PATCH, 1, lambda w: unet.equiunet_forward(sd, w)[0], overlap=0.5)
+    crop = (slice(None), slice(None), slice(None), slice(None), slice(p_b[2], 160 - p_a[2]))
+    d_ref = unet.hard_dice(ref[crop], t)
+    print(f"\nEquiUnet-48 TRAINED, configs[3] phantom volume: oracle stitched hard Dice (TC, WT, ET) {[round(v, 4) for v in d_ref.flatten().tolist()]}")
+    assert float(d_ref.min()) >= 0.5, d_ref
+    errs = {}
+    with torch.no_grad():
+        for prec in ("fp32", "x3", "bf16", "fp16"):
+            m.precision = prec
+            out = sliding_window_inference(padded, PATCH, 3, lambda w: m(w), overlap=0.5).float().cpu()
+            errs[prec] = _report(f"stitched, identity TTA, {prec}", out[crop], ref[crop], t, d_ref) + (float((out - ref).abs().max()),)
+    assert errs["fp32"][2] < LOGIT_ATOL and errs["x3"][2] < LOGIT_ATOL, errs
+    for prec in errs:
+        assert errs[prec][0] <= DICE_ATOL, (prec, errs[prec])
+    # the benchmarked chain: 8-flip TTA + threshold + background removal, 16-bit against f32
+    dice, seg = {}, {}
+    for prec, amp, dt in (("fp32", False, None), ("bf16", True, torch.bfloat16), ("fp16", True, torch.float16)):
+        m.precision = prec
+        ev = Evaluator(m, tta_transforms=tta.flip8(), sliding_window_size=PATCH, sw_batch_size=3, overlap=0.5, k_divisible=8, amp=amp)
+        out = ev(xd, target=td)
+        seg[prec], dice[prec] = out["seg"].cpu(), hard_dice_metric(out["seg"], td).cpu()
+        del ev
+    for prec in ("bf16", "fp16"):
+        margin = float((dice[prec] - dice["fp32"]).abs().max())
+        flips = float((seg[prec] != seg["fp32"]).float().mean())
+        print(f"  8-flip chain {prec}: hard Dice {[round(v, 5) for v in dice[prec].flatten().tolist()]} vs f32 "
+              f"{[round(v, 5) for v in dice['fp32'].flatten().tolist()]}: |dDice| max {margin:.2e}, segmentation voxels flipped {flips:.3e}")
+        assert margin <= DICE_ATOL, (prec, dice)
+    m.precision = "x3"
