@@ -1107,6 +1107,7 @@ extern "C" int BRATS_API(brats_conv3d_set_wgrad_alltaps)(int mode) {
 }
 
 static size_t x3_align(size_t b);
+static size_t wgrad_x3_fused_ws_bytes(int N, int D, int H, int W, int c1, int c2, int cout);
 extern "C" size_t BRATS_API(brats_conv3d_wgrad_ws_bytes)(int dtype, int ksize, int N, int D, int H, int W, int c1, int c2, int cout) {
   if (ksize != 3) return 0;
   if (dtype == BRATS_X3_BF16) {
@@ -1114,7 +1115,8 @@ extern "C" size_t BRATS_API(brats_conv3d_wgrad_ws_bytes)(int dtype, int ksize, i
     const size_t vox = (size_t)N * D * H * W;
     const size_t slab = BRATS_API(brats_conv3d_wgrad_ws_bytes)(BRATS_BF16, 3, N, D, H, W, c1, c2, cout) * 3;
     auto sp = [&](int c) { return c > 0 ? 2 * x3_align(vox * c * 2) : (size_t)0; };
-    return x3_align(slab) + sp(c1) + sp(c2) + sp(cout);
+    const size_t three = x3_align(slab) + sp(c1) + sp(c2) + sp(cout), fused = wgrad_x3_fused_ws_bytes(N, D, H, W, c1, c2, cout);
+    return three > fused ? three : fused;
   }
   int cof, cif;
   wgrad_tiles(dtype, c1, c2, cout, &cof, &cif);
@@ -1300,6 +1302,13 @@ static int wgrad_x3(const void* x1, int c1, int pitch1, const void* x2, int c2, 
   return 0;
 }
 
+#include "conv_wgrad_x3.hpp"  // the fused form: split in the staging path, one launch (round 5)
+extern "C" int BRATS_API(brats_conv3d_set_x3_wgrad_fused)(int mode) {  // (here, not in the header: gen_twin_dispatch.py scans the .hip files)
+  const int old = g_x3_wgrad_fused_mode;
+  g_x3_wgrad_fused_mode = mode < 0 ? -1 : (mode > 2 ? 2 : mode);
+  return old;
+}
+
 static int wgrad_impl(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch,
                       const float* amax_dy, float* ws, float* dw, float* dbias, int dtype, int ksize, int dil, int N, int D, int H,
                       int W, int cout, brats_stream_t s) {
@@ -1319,8 +1328,11 @@ static int wgrad_impl(const void* x1, int c1, int pitch1, const void* x2, int c2
   }
   hipStream_t st = (hipStream_t)s;
   if (x3) {
-    const size_t slab = BRATS_API(brats_conv3d_wgrad_ws_bytes)(BRATS_BF16, 3, N, D, H, W, c1, c2, cout) * 3;
-    const int rc = wgrad_x3(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, amax_dy, ws, dw, slab, dil, N, D, H, W, cout, st);
+    int rc = wgrad_x3_fused(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, amax_dy, ws, dw, dil, N, D, H, W, cout, st);
+    if (rc == 1) {  // not a layer of the fused kernel: the split pass + three 16-bit launches
+      const size_t slab = BRATS_API(brats_conv3d_wgrad_ws_bytes)(BRATS_BF16, 3, N, D, H, W, c1, c2, cout) * 3;
+      rc = wgrad_x3(x1, c1, pitch1, x2, c2, pitch2, dy, dypitch, amax_dy, ws, dw, slab, dil, N, D, H, W, cout, st);
+    }
     if (rc) return rc;
   } else {
     int nsplit = 0;

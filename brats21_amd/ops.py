@@ -442,6 +442,12 @@ def set_vs8(mode):
     return old
 
 
+def set_x3_wgrad_fused(mode):
+    """brats_conv3d_set_x3_wgrad_fused: 1 = the fused split-precision weight gradient where it is built and pays, 2 = for any tile
+    count (tests), 0 = the split pass + three 16-bit launches everywhere, -1 = default.  Returns the previous setting."""
+    return _lib.lib().brats_conv3d_set_x3_wgrad_fused(mode)
+
+
 def split_granule(cout):
     return _lib.lib().brats_conv3d_split_granule(cout)
 

@@ -178,6 +178,12 @@ size_t brats_conv3d_wgrad_ws_bytes(int dtype, int ksize, int N, int D, int H, in
  * everywhere, -1 = default (1, or the BRATS_WGRAD_ALLTAPS environment variable).  Same values up
  * to f32 summation order; returns the previous setting. */
 int brats_conv3d_set_wgrad_alltaps(int mode);
+/* Tuning / test knob of the split-precision weight gradient (brats_conv3d_x3_wgrad): 1 = the fused kernel (f32 tiles staged
+ * once, split into fp16 / bf16 pairs on their way into LDS, three MFMA products per staged tile: csrc/conv_wgrad_x3.hpp) for
+ * dilation-1 layers with 48-channel blocks that have enough tiles, 2 = the fused kernel for ANY tile count (tests), 0 = the
+ * round-4 form everywhere (one split pass to HBM + three launches of the 16-bit kernels), -1 = default (1, or the
+ * BRATS_X3_WGRAD_FUSED environment variable).  Same values up to f32 summation order; returns the previous setting. */
+int brats_conv3d_set_x3_wgrad_fused(int mode);
 int brats_conv3d_wgrad(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2,
                        const void* dy, int dypitch, float* ws, float* dw, float* dbias,
                        int dtype, int ksize, int dil, int N, int D, int H, int W, int cout,

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; out=gpurun_out/$1; shift; mkdir -p $out
+for lib in hip "$@"; do
+  echo "=== $lib" >> $out/log.txt
+  BRATS_HIP_LIB=$PWD/brats21_amd/libbrats_$lib.so timeout 600 python scripts/time_x3_wgrad.py >> $out/log.txt 2>&1
+done
+timeout 1500 python -m pytest tests/test_x3_gpu.py -m gpu -x -q 2>&1 | tail -5 >> $out/log.txt
+for f in 0 1; do
+  echo "=== bench x3, BRATS_X3_WGRAD_FUSED=$f" >> $out/log.txt
+  BRATS_X3_WGRAD_FUSED=$f python3 bench.py --precision x3 --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs 2>/dev/null | tail -1 | python3 -c "import json,sys; r=json.loads(sys.stdin.read()); print(r['ms_per_step'], r['config']['loss'], r['roofline']['families'])" >> $out/log.txt 2>&1
+done
+cat $out/log.txt

@@ -101,7 +101,6 @@ def test_trained_patch_logits_and_dice_vs_oracle(model):
     surface) and one at HALF the contrast, where the trained network is unsure over a large share of the lesion."""
     m, sd, curve = _train(model)
     assert curve[-1][1] < 0.6 * curve[0][1], curve  # it did learn
-    xd_all = {}
     for contrast, seed in ((1.0, 777), (0.5, 778)):
         x, t = synth.tumour_phantom(1, PATCH, seed, contrast=contrast)
         ref = _oracle(model, sd, x)

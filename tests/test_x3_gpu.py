@@ -100,6 +100,56 @@ def test_conv3d_x3_fwd_dgrad_wgrad_vs_f64(cin, cin2, cout, dil, size):
         torch.testing.assert_close(s[..., 1], (got[0] ** 2).sum((2, 3, 4)), atol=1e-2, rtol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cin2,cout,size", [
+    (48, 0, 48, (8, 16, 32)),     # the dominant layer's channel block, whole half tiles
+    (48, 48, 48, (6, 8, 16)),     # decoder: two sources, each its own 48-channel ci block
+    (96, 0, 96, (5, 6, 19)),      # ragged volume (every face cuts a half tile), 2 x 2 channel blocks
+    (8, 0, 48, (8, 8, 16)),       # first layer: one 16-channel ci block of which 8 are real
+    (48, 0, 48, (32, 64, 64)),    # enough half tiles (2048) for the default switch: persistent workgroups walking 8 tiles each
+])
+def test_conv3d_x3_wgrad_fused_vs_f64_and_vs_three_launch_form(cin, cin2, cout, size):
+    """The fused split-precision weight gradient (csrc/conv_wgrad_x3.hpp: f32 tiles staged once, split into 16-bit pairs on their
+    way into LDS, three MFMA products per staged tile) against autograd of F.conv3d in float64 and against round 4's form (split
+    pass to HBM + three launches of the 16-bit kernels), for fp16 and bf16 pairs; bitwise reproducible run to run."""
+    from brats21_amd import ops
+    n = 2
+    ct = cin + cin2
+    x = _rand((n, ct, *size), 11)
+    dy = _rand((n, cout, *size), 13) * 1e-4
+    big = size[0] * size[1] * size[2] > 100000
+    if big:  # the f64 reference on the host: the weight gradient alone, as a convolution of x with dy
+        xr = x.double()
+        ref = torch.stack([F.conv3d(xr[:, c:c + 1].transpose(0, 1), dy.double().transpose(0, 1), None, 1, 1, 1)[0] for c in range(ct)], 1)
+        ref = ref.permute(0, 1, 2, 3, 4).contiguous()  # [cout, ct, 3, 3, 3]
+    else:
+        w = torch.zeros((cout, ct, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+        F.conv3d(x.double(), w, None, 1, 1, 1).backward(dy.double())
+        ref = w.grad
+    xd1, xd2 = _nd(x[:, :cin]), (_nd(x[:, cin:]) if cin2 else None)
+    dyd = _nd(dy)
+    amax = ops.absmax(dyd)
+
+    def run(mode, fused):
+        old = ops.set_x3_wgrad_fused(fused)
+        try:
+            with ops.split_precision(mode):
+                dw, _ = ops.conv3d_wgrad(xd1, dyd, 3, 1, x2=xd2, amax_dy=amax)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_x3_wgrad_fused(old)
+        return dw
+
+    for mode, bar in ((ops.X3F, 3e-6), (ops.X3B, 6e-5)):
+        fused = run(mode, 1 if big else 2)
+        three = run(mode, 0)
+        e_f, e_3 = _relmax(fused.double().cpu(), ref), _relmax(three.double().cpu(), ref)
+        print(f"{mode} wgrad {cin}+{cin2}->{cout} @{size}: fused rel-to-max err {e_f:.2e}, three-launch form {e_3:.2e}")
+        assert e_f < bar and e_3 < bar, (mode, e_f, e_3)
+        assert e_f < 4.0 * max(e_3, 3e-7), (mode, e_f, e_3)
+        assert not torch.equal(fused, three) or cin == 8  # (really another kernel: another summation order)
+        assert torch.equal(fused, run(mode, 1 if big else 2))  # fixed-order slab reduction: bitwise reproducible
+
+
 def test_conv3d_x3_small_operands_keep_their_low_halves():
     """fp16 split of operands in [2^-10, 2^-7]: every lo half is an fp16 SUBNORMAL.  A matrix pipe that flushed subnormal
     inputs (MI200 did) would leave the plain fp16 product (2^-11 relative); gfx950 keeps them, so the result must stay at
