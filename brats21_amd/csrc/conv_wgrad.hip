@@ -24,6 +24,7 @@ struct WgradParams {
   int tz, ty, tx, ntiles, nsplit;
   int nlane;  // tile ranges (8 = one per XCD; fewer for small volumes so that fewer split-K slabs are written)
   int ntaps, dil;  // KS = 1 form only: 1 tap (a 1x1x1 convolution) or 27 shifted taps (3x3x3 at any dilation)
+  int seglen, nsegz;  // split-precision z-walk kernel only (conv_wgrad_x3.hpp): tiles per column segment, segments per column
 };
 
 constexpr int WG_TZ = 4, WG_TY = 4, WG_TX = 16, WG_VOX = 256;  // tile = 16 x-rows of 16 voxels
