@@ -16,16 +16,26 @@
 //     recorded |max| into fp16's top binades -- and written as FOUR 16-bit LDS tiles (X hi, X lo: 4 planes x 10.4 KB each;
 //     dY hi, dY lo: 12.3 KB each; 107.5 KB) whose rows are the lane-linear image of the piece order: conflict-free
 //     ds_write_b64 runs;
-//   * the NEXT tile's pieces are in flight during the MFMA phase without costing the 60 registers a register prefetch
-//     needs (that form spilled 93-147 registers and ran at 165 TF/s; a 4-wave / 512-register form at 236): dY and the first
-//     128 columns of every new X row arrive by LDS-DMA in a 48 KB staging area beside the tiles (each lane later reads back
-//     exactly the 16 bytes its own DMA lane wrote: no barrier in between), only the rows' tails (3 pieces per lane) in registers;
+//   * the NEXT tile's pieces are fetched during the MFMA phase without costing the 60 registers a register prefetch needs
+//     (that form spilled 93-147 registers and ran at 165 TF/s; a 4-wave / 512-register form at 236): dY and the first 128
+//     columns of every new X row arrive by LDS-DMA in a 48 KB staging area beside the tiles, only the rows' tails in registers.
+//     WHO issues them matters (s_memtime stamps, scripts/probes/x3w_stamps.py): an LDS-DMA instruction stalls its wave for
+//     150-300 cycles, and with every wave issuing its share in front of its MFMA loop the matrix pipe idled 2 k of a tile's
+//     18.5 k cycles.  Waves 0-3 ("group A") win the matrix pipe's arbitration anyway (older wave slots; s_setprio on top changes
+//     nothing), finish their MFMA loop while waves 4-7 -- their SIMD partners -- still have a third of theirs to go, and issue
+//     ALL the next tile's loads in that shadow (1.28 -> 1.23 ms at 48 -> 48 @2x128^3).  What is left (stamps of that layer: a
+//     tile = 17.5 k cycles): group B's MFMA loop 14.7 k (two waves sharing a SIMD reach 87 % of the pipe rate; a wave alone
+//     64 %, whichever group goes first: alternating the priority in time measured 8-19 % SLOWER), the split + tile writes of
+//     66 KB 2.4 k (VALU-bound, and not overlappable without a second set of tiles LDS has no room for);
 //   * MFMA phase = the all-taps kernel's roles (81 (tap, ci-fragment) pairs dealt to 8 waves, 3 co fragments each, 132
 //     accumulator registers kept over everything the workgroup walks), operands by the transposing LDS read from the hi / lo
 //     tiles (96-byte voxel stride: conflict-free), 9 MFMAs per (k-step, pair): a_hi*b_lo, a_lo*b_hi, a_hi*b_hi per co fragment;
 //   * slabs and the fixed-order reduction (times 2^-k) are the 16-bit kernels' (bitwise reproducible).
 // CIF = 3: 48-channel ci blocks; CIF = 1: the first layer (<= 16 input channels; 77 KB of LDS, 128 registers: two workgroups per CU).
 #pragma once
+#ifndef X3_PRIO
+#define X3_PRIO 2  // s_setprio of waves 0-3 during their MFMA loop
+#endif
 
 template <int CIF> struct Wg3z {
   static constexpr int NW = 8;                                                            // waves per workgroup
@@ -72,12 +82,10 @@ DEVI int lane_now() {
   return l;
 }
 
-// PF: the next tile's loads fly during the MFMA phase (LDS-DMA + 3 register pieces); false: every load at the top of its tile
-template <int CIF, bool PF>
+template <int CIF>
 __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_kernel(const WgradParams p, const float* __restrict__ amax_dy) {
   using G = Wg3z<CIF>;
   constexpr int NW = G::NW;
-  constexpr bool DMA = PF;  // (without prefetch the "DMA" pieces are plain register loads)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const ldxh = lds;
   char* const ldxl = lds + G::LDS_XH;
@@ -169,29 +177,23 @@ __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_ker
     return ((gz * p.H + gy) * p.W + (c.x0 - 1)) * xpb;  // (may be negative at the low faces)
   };
 
-  u32x4 rxr[3], rxd[G::XJD ? 3 : 1], ryd[3];  // register pieces (rxd / ryd only without DMA)
-  // loads of the two NEW planes gz0, gz0 + 1 and of the dY tile at z0
-  auto issue_tile = [&](const Col& c, int z0) {
-#ifdef X3_ABL_NOLOAD
-    return;
-#endif
-    const LaneX LD = lane_x(wave & 1), LR = lane_x(G::XJD + (wave & 1));
+  u32x4 rxr[2][3];  // the register pieces (group A only: [own share | the partner wave's][row])
+  // loads of the two NEW planes z0 + 1, z0 + 2 and of the dY tile at z0: the share of wave ww (0..7), issued by a group-A wave
+  // for itself (h = 0) and for its partner ww = wave + 4 (h = 1).  DMA'd pieces land in ww's staging slots.
+  auto issue_for = [&](const Col& c, int z0, int ww, auto h_) {
+    constexpr int h = h_;
+    const LaneX LD = lane_x(ww & 1), LR = lane_x(G::XJD + (ww & 1));
     const bool okD = G::XJD && ((c.xm >> LD.hx) & 1u), okR = (c.xm >> LR.hx) & 1u;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int r = (wave >> 1) + 4 * k;  // 0..11
+      const int r = (ww >> 1) + 4 * k;  // 0..11
       bool row_ok;
       const int rb = xrow(c, z0 + 1 + r / G::HY, r % G::HY, row_ok);
-      if (G::XJD) {
-        const int vo = (row_ok && okD) ? rb + LD.col : -1;
-        if (DMA) lds_dma16_async(c.xrs4, stage_x + (wave * 3 + k) * 1024, vo);
-        else rxd[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c.xrs, vo, 0, 0));
-      }
-      const int vr = (row_ok && okR) ? rb + LR.col : -1;
-      rxr[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c.xrs, vr, 0, 0));
+      if (G::XJD) lds_dma16_async(c.xrs4, stage_x + (ww * 3 + k) * 1024, (row_ok && okD) ? rb + LD.col : -1);
+      rxr[h][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c.xrs, (row_ok && okR) ? rb + LR.col : -1, 0, 0));
     }
     {
-      const int gz = z0 + (wave >> 2), gy = c.y0 + (wave & 3);
+      const int gz = z0 + (ww >> 2), gy = c.y0 + (ww & 3);
       const bool row_ok = gz < p.D && gy < p.H;
       const int rb = ((gz * p.H + gy) * p.W + c.x0) * ypb;
       const int l = lane_now();
@@ -199,41 +201,55 @@ __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_ker
       for (int j = 0; j < 3; ++j) {
         const int pc = l + 64 * j, vx = pc / G::YPPV;
         const int vo = (row_ok && ((c.xm >> (vx + 1)) & 1u)) ? rb + vx * ypb + (pc - vx * G::YPPV) * 16 : -1;
-        if (DMA) lds_dma16_async(c.yrs4, stage_y + (wave * 3 + j) * 1024, vo);
-        else ryd[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(c.yrs, vo, 0, 0));
+        lds_dma16_async(c.yrs4, stage_y + (ww * 3 + j) * 1024, vo);
       }
     }
   };
-  // split + LDS tile writes of what issue_tile fetched; sb = ring slot of the first new plane
-  auto convert_tile = [&](int sb) {
-    const int l = lane_now();
-    const int xldsD = (l + 64 * (wave & 1)) * 8, xldsR = (l + 64 * (G::XJD + (wave & 1))) * 8;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int r = (wave >> 1) + 4 * k;
-      const int rowoff = (((sb + r / G::HY) & 3) * G::HY + r % G::HY) * G::XROWB;  // scalar
-      if (G::XJD) {
-        const u32x4 d = DMA ? *(const u32x4*)(stage_x + (wave * 3 + k) * 1024 + l * 16) : rxd[k];
-        u32x2 hi, lo;
-        x3_split4(d, 1.f, hi, lo);
-        *(u32x2*)(ldxh + rowoff + xldsD) = hi;
-        *(u32x2*)(ldxl + rowoff + xldsD) = lo;
-      }
-      if (xldsR < G::XROWB) {  // (the last load of a row is partly beyond it)
-        u32x2 hi, lo;
-        x3_split4(rxr[k], 1.f, hi, lo);
-        *(u32x2*)(ldxh + rowoff + xldsR) = hi;
-        *(u32x2*)(ldxl + rowoff + xldsR) = lo;
-      }
-    }
+  auto issue_tile = [&](const Col& c, int z0) {  // group A only
+    issue_for(c, z0, wave, std::integral_constant<int, 0>{});
+    issue_for(c, z0, wave + 4, std::integral_constant<int, 1>{});
+  };
+  // split + LDS tile writes of what issue_tile fetched; sb = ring slot of the first new plane.  Nine pieces per wave: group A
+  // converts its six register pieces and its own three DMA'd X pieces, group B its own DMA'd X and dY pieces and the dY pieces
+  // of its partner (after the barrier behind group A's vmcnt(0) every staging slot is readable by everybody).
+  auto put_x = [&](const u32x4 d, int ww, int k, int ldsoff, int sb) {
+    const int r = (ww >> 1) + 4 * k;
+    const int rowoff = (((sb + r / G::HY) & 3) * G::HY + r % G::HY) * G::XROWB;  // scalar
+    u32x2 hi, lo;
+    x3_split4(d, 1.f, hi, lo);
+    *(u32x2*)(ldxh + rowoff + ldsoff) = hi;
+    *(u32x2*)(ldxl + rowoff + ldsoff) = lo;
+  };
+  auto put_y = [&](int ww, int l) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const u32x4 d = DMA ? *(const u32x4*)(stage_y + (wave * 3 + j) * 1024 + l * 16) : ryd[j];
+      const u32x4 d = *(const u32x4*)(stage_y + (ww * 3 + j) * 1024 + l * 16);
       u32x2 hi, lo;
       x3_split4(d, ysc, hi, lo);
-      const int o = (wave * G::YPR + l + 64 * j) * 8;
+      const int o = (ww * G::YPR + l + 64 * j) * 8;
       *(u32x2*)(ldyh + o) = hi;
       *(u32x2*)(ldyl + o) = lo;
+    }
+  };
+  auto convert_tile = [&](int sb) {
+    const int l = lane_now();
+    if (G::XJD) {
+      const int xldsD = (l + 64 * (wave & 1)) * 8;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) put_x(*(const u32x4*)(stage_x + (wave * 3 + k) * 1024 + l * 16), wave, k, xldsD, sb);
+    }
+    if (wave < 4) {
+      const int xldsR = (l + 64 * (G::XJD + (wave & 1))) * 8;  // (wave and wave + 4 have the same parity: the same column)
+      if (xldsR < G::XROWB) {  // (the last load of a row is partly beyond it)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          put_x(rxr[0][k], wave, k, xldsR, sb);
+          put_x(rxr[1][k], wave + 4, k, xldsR, sb);
+        }
+      }
+    } else {
+      put_y(wave, l);
+      put_y(wave - 4, l);
     }
   };
 
@@ -280,20 +296,30 @@ __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_ker
         }
       }
     }
-    if (PF) issue_tile(c, 2 * t0);
-    X3_STAMP(5);
-    for (int t = t0; t < t1; ++t) {
-      if (!PF) issue_tile(c, 2 * t);
-      if (PF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my DMA pieces have landed (the asm form is invisible to hipcc's counters)
+    // fetch (group A) -> everybody's pieces have landed and the previous MFMA phase is over -> split into the tiles.  (The loop
+    // is written MFMA-first so that the register pieces are loaded and consumed inside ONE iteration: with their live range
+    // across the back edge hipcc spilled each of them right behind its load.)
+    auto stage_tile = [&](int t) {
+      // (defined on both paths: with the pieces undefined for group B hipcc spills each of them right behind its load)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rxr[h][k] = u32x4{0u, 0u, 0u, 0u};
+      if (wave < 4) issue_tile(c, 2 * t);  // (t > t0: in the shadow of group B's MFMA loop)
+      X3_STAMP(3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group A: the DMA pieces have landed (the asm form is invisible to hipcc's counters)
       X3_STAMP(0);
-      __syncthreads();  // previous tile's LDS reads are done (and the prologue's writes of OTHER rows cannot collide: distinct slots)
+      __syncthreads();  // the previous tile's LDS reads are done (the prologue's writes went to other ring slots)
       X3_STAMP(1);
       convert_tile(2 * ((t + 1) & 1));
       __syncthreads();
       X3_STAMP(2);
-      if (PF && t + 1 < t1) issue_tile(c, 2 * (t + 1));
-      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMA phase
-      X3_STAMP(3);
+    };
+    stage_tile(t0);
+    X3_STAMP(5);
+    for (int t = t0; t < t1; ++t) {
+      if (wave < 4) __builtin_amdgcn_s_setprio(X3_PRIO);  // group A first at the matrix pipe: it has the next tile's loads to issue afterwards
+      __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA over the 128 voxels of the tile.  k-step s = x-rows 2s, 2s+1 (row = z*4 + y); fragment layout: see
       // conv_wgrad_kernel.  The plane of (tile z = s >> 1, tap z) sits in ring slot (2 (t & 1) + (s >> 1) + tapz) & 3.
       const int tpar = 2 * (t & 1);
@@ -308,7 +334,7 @@ __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_ker
 #define X3_AB 2
 #endif
       constexpr int PD = CIF == 1 ? 2 : X3_PD;             // X fragment pairs in flight
-      constexpr int AB = CIF == 1 ? 1 : (PF ? 1 : X3_AB);  // dY fragment buffers (the prefetch form has 12 registers less)
+      constexpr int AB = CIF == 1 ? 1 : X3_AB;             // dY fragment buffers
       bf16x8 ah[AB][3], al[AB][3], bh[PD + 1], bl[PD + 1];
       auto read_a = [&](auto s_) {
         constexpr int s = s_;
@@ -326,13 +352,9 @@ __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_ker
         bh[u % (PD + 1)] = tr_pair(ldxh + xoff, ldxh + xoff + G::XROWB);
         bl[u % (PD + 1)] = tr_pair(ldxl + xoff, ldxl + xoff + G::XROWB);
       };
-#ifdef X3_ABL_NOMMA
-      constexpr int NU = 0;
-#else
       constexpr int NU = 4 * G::PPW;
       read_a(std::integral_constant<int, 0>{});
       static_for<0, PD>([&](auto u_) { read_b(u_); });
-#endif
       static_for<0, NU>([&](auto u_) {
         constexpr int u = u_;
         constexpr int s = u / G::PPW, jj = u % G::PPW;
@@ -349,7 +371,9 @@ __global__ __launch_bounds__(512, CIF == 1 ? 4 : 2) void conv_wgrad_x3_zwalk_ker
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (AB == 1 && jj == G::PPW - 1 && s + 1 < 4) read_a(std::integral_constant<int, s + 1>{});  // (single buffer: after its last use)
       });
+      __builtin_amdgcn_s_setprio(0);
       X3_STAMP(4);
+      if (t + 1 < t1) stage_tile(t + 1);
     }
   }
 #ifdef BRATS_X3W_STAMPS
@@ -421,12 +445,7 @@ static size_t wgrad_x3_fused_ws_bytes(int N, int D, int H, int W, int c1, int c2
   return (size_t)sh.nl * sh.g8 * 27 * cout * (c1 + (c2 > 0 ? c2 : 0)) * sizeof(float);
 }
 
-#ifndef X3_PF
-#define X3_PF true
-#endif
-#ifndef X3_PF1
-#define X3_PF1 false  // the first layer's kernel (128 registers for two workgroups per CU) has no room for the three register pieces
-#endif
+
 // one launch + the fixed-order reduction; returns 1 when the layer is not taken (the caller falls back to wgrad_x3)
 static int wgrad_x3_fused(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const void* dy, int dypitch,
                           const float* amax_dy, float* ws, float* dw, int dil, int N, int D, int H, int W, int cout, hipStream_t st) {
@@ -441,12 +460,12 @@ static int wgrad_x3_fused(const void* x1, int c1, int pitch1, const void* x2, in
   p.ntiles = sh.nseg; p.nlane = sh.nl; p.nsplit = sh.nl * sh.g8; p.ntaps = 27; p.dil = 1;
   p.seglen = sh.seglen; p.nsegz = sh.nsegz;
   static std::atomic<uint64_t> attr_a{0}, attr_b{0};
-  BRATS_ENSURE_LDS_ATTR((conv_wgrad_x3_zwalk_kernel<3, X3_PF>), Wg3z<3>::LDS, attr_a);
-  BRATS_ENSURE_LDS_ATTR((conv_wgrad_x3_zwalk_kernel<1, X3_PF1>), Wg3z<1>::LDS, attr_b);
+  BRATS_ENSURE_LDS_ATTR(conv_wgrad_x3_zwalk_kernel<3>, Wg3z<3>::LDS, attr_a);
+  BRATS_ENSURE_LDS_ATTR(conv_wgrad_x3_zwalk_kernel<1>, Wg3z<1>::LDS, attr_b);
   if (sh.narrow)  // the slab columns of the padded ci lanes (c1 < 16) are never written and never read (cin = c1)
-    hipLaunchKernelGGL((conv_wgrad_x3_zwalk_kernel<1, X3_PF1>), dim3(p.nsplit, cout / 48, 1), dim3(512), Wg3z<1>::LDS, st, p, amax_dy);
+    hipLaunchKernelGGL(conv_wgrad_x3_zwalk_kernel<1>, dim3(p.nsplit, cout / 48, 1), dim3(512), Wg3z<1>::LDS, st, p, amax_dy);
   else
-    hipLaunchKernelGGL((conv_wgrad_x3_zwalk_kernel<3, X3_PF>), dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3z<3>::LDS, st, p, amax_dy);
+    hipLaunchKernelGGL(conv_wgrad_x3_zwalk_kernel<3>, dim3(p.nsplit, cout / 48, p.cin / 48), dim3(512), Wg3z<3>::LDS, st, p, amax_dy);
   BRATS_CHECK_LAUNCH();
   wgrad_reduce_launch((const float*)ws, dw, p.nsplit, cout, p.cin, 27, st, amax_dy);
   return 0;
