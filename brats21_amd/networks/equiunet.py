@@ -198,7 +198,8 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
                                  amax2=getattr(x2, "_amax", None) if x2 is not None else None)
     else:
         wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=c1)
-        y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2)
+        # (_x3amax: the network input in split-precision mode -- the only conv input no normalisation has bounded; see _EquiUnetFn)
+        y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2, amax=getattr(x, "_x3amax", None))
     n, d, h, wd, _ = y.shape
     if unit.batch_norm:
         return _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training)
@@ -383,6 +384,14 @@ class _EquiUnetFn(torch.autograd.Function):
             return _inherit_amax(ops.upsample(t, 2), t)
 
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if (ops.is16(dtype) or ops.x3_active()) else 4)
+        if ops.x3_mode() == ops.X3F:
+            # fp16 pairs overflow at |x| >= 65504 (hi = inf, lo = NaN: silently NaN logits).  Every other convolution
+            # input is a normalised activation; the network INPUT is whatever the caller passes (un-normalised volumes reach
+            # 3e4 and more), so its |max| is recorded (one 134 MB pass at 2 x 128^3) and the first layer's forward scales by the
+            # matching power of two (brats_conv3d_x3_fwd's xamax: exact).  The first layer's WEIGHT gradient still splits the
+            # unscaled input: split-precision training expects z-scored inputs like the reference's pipeline produces
+            # (utils/transforms.py:364-385), inference does not.
+            x0._x3amax = ops.absmax(x0)
         # encoder (networks/equiunet2020.py:469-475); every tensor is dense NDHWC, the decoder convolutions
         # read the virtual concat [skip | up-sampled] from two pointers (no torch.cat, no strided slices)
         # (the last layer of a level writes its activation -- the skip connection -- and the max-pooled tensor in one pass)

@@ -117,7 +117,8 @@ def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
                                  amax=getattr(x, "_amax", None))
         return y, stats, (x, dil)
     wpk = ops.pack_weights(w, cx.dtype, PACK_FWD, cin_pad=x.shape[-1], dil=dil)
-    y, stats = ops.conv3d(x, wpk, cout, k, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats)
+    y, stats = ops.conv3d(x, wpk, cout, k, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats,
+                          amax=getattr(x, "_x3amax", None) if k == 3 else None)  # (the network input in split-precision mode: EquiUnet)
     return y, stats, (x, dil)
 
 
@@ -289,6 +290,8 @@ class _AsspFn(torch.autograd.Function):
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
         x0 = ops.ncdhw_to_ndhwc(x, dtype, cpad=8 if (ops.is16(dtype) or ops.x3_active()) else 4)
+        if ops.x3_mode() == ops.X3F:
+            x0._x3amax = ops.absmax(x0)  # fp16 pairs: the first layer's forward scales the un-normalised input (networks/equiunet.py)
         will_bwd = any(ctx.needs_input_grad) and model._fwd_grad  # (needs_input_grad ignores no_grad)
 
         def pool(t):  # max and average of a 2x2x2 cell never exceed the |max| of the input

@@ -1,17 +1,33 @@
 #!/bin/bash
 # Collects the round's committed evidence on the GPU box: bench line, rocprofv3 kernel stats of the same command,
 # per-layer conv table, and separate --pmc passes over the dominant conv shapes.  Outputs under gpurun_out/final/.
-# usage: bash scripts/final_profile.sh [tag]     (tag = round prefix of the files copied to profiles/, e.g. r02)
+# usage: bash scripts/final_profile.sh [tag]     (tag = round prefix of the files copied to profiles/, e.g. r05; default r05)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out
-python3 bench.py --steps 20 --warmup 5 --kernel-table > $out/bench.json 2> $out/conv_table.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs > $out/bench_profiled.log 2>&1
-cp $out/stats/*/*kernel_stats.csv $out/bench_kernel_stats.csv
+tag=${1:-r05}
+# 1. the separate --pmc passes FIRST: bench.py's roofline.traffic is the committed per-launch figure of these passes, accepted only
+#    when the record carries the hash of the kernel sources that are running (bench.py: profiled_traffic) -- so the record is
+#    written into profiles/ of this box before the bench line is taken, and the run FAILS if the line still says null
 bash scripts/pmc.sh final/pmc scripts/prof_conv.py all > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc > $out/pmc_conv.txt
 bash scripts/pmc.sh final/pmc_dom scripts/prof_conv.py dom > /dev/null 2>&1
 python3 scripts/pmc_report.py final/pmc_dom > $out/pmc_dominant.txt
 python3 scripts/pmc_report.py final/pmc_dom --json "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128" "conv_igemm_vs8_kernel<24, 1, 3, false, false>" > $out/pmc_dominant.json
+cp $out/pmc_dominant.json profiles/${tag}_final_pmc_dominant.json
+python3 bench.py --steps 20 --warmup 5 --kernel-table > $out/bench.json 2> $out/conv_table.txt
+python3 - <<PY || { echo "FINAL PROFILE FAILED: roofline.traffic is null / stale (see above)" | tee $out/FAILED; exit 1; }
+import json, sys
+sys.path.insert(0, ".")
+import bench
+rec = json.load(open("$out/pmc_dominant.json"))
+line = json.loads(open("$out/bench.json").read().strip().splitlines()[-1])
+want = bench.kernel_source_sha()
+ok = rec.get("source_sha16") == want and line["roofline"]["traffic"] is not None
+print("pmc record sha", rec.get("source_sha16"), "kernel sources", want, "roofline.traffic", line["roofline"]["traffic"])
+sys.exit(0 if ok else 1)
+PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs > $out/bench_profiled.log 2>&1
+cp $out/stats/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 # round 4: the split-precision parity mode as the timed configuration (per-layer table), and the inference leg's kernel statistics
 python3 bench.py --precision x3 --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs --kernel-table > $out/bench_x3.json 2> $out/conv_table_x3.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_x3 -- python3 bench.py --precision x3 --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs > /dev/null 2>&1

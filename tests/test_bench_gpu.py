@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+def _bench(*args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout  # ONE JSON line on stdout
@@ -74,3 +75,19 @@ def test_bench_other_stated_configurations_are_on_the_line():
         assert abs(r[leg]["patches_per_s"] - r[leg]["patches_per_gpu"] / (r[leg]["ms_per_step"] * 1e-3)) < 0.02 * r[leg]["patches_per_s"]
     assert r["configs2_per_gpu"]["as_one_hipgraph"]["ms_per_step"] > 0 and "grad_scale" in r["fp16_mode"]
     assert r["metric"].startswith("train patches/sec") and r["dtype"] == "bf16"  # headline fields unchanged
+
+
+def test_bench_two_ranks_on_one_gpu_exercise_the_ddp_block():
+    """`bench.py --gpus 2` with both ranks on this box's one GPU (gloo: RCCL refuses two ranks per device): the launcher, the
+    patient sharding, the bucketed gradient all-reduce overlapped with the backward program and the `ddp` block of the JSON line
+    (allreduce_ms, exposed_ms, overlap_frac, per-rank step times) run every round, not only on the day an 8-GPU node appears
+    (VERDICT r4 item 8).  The numbers mean nothing as a scaling result: two ranks share one GPU and gloo reduces on the host."""
+    r = _bench("--gpus", "2", "--width", "8", "--patch", "32", "--steps", "6", "--warmup", "2", "--no-infer", "--no-cpu-baseline",
+               "--no-parity-leg", "--no-other-configs", env={"BRATS_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "4"})
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
+    assert abs(r["value"] - 4 / (r["ms_per_step"] * 1e-3)) < 0.02 * r["value"]  # whole-job patches/s = 2 ranks x 2 patches / step time
+    d = r["ddp"]
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and len(d["ms_per_step_by_rank"]) == 2 and d["buckets"] >= 1
+    assert d["payload_MB"] > 0 and d["allreduce_ms"] > 0 and d["comm_dtype"] == "float32" and d["graph_captured_collectives"] is False
+    assert d["exposed_ms"] is not None and d["exposed_ms"] >= 0 and 0.0 <= d["overlap_frac"] <= 1.0
+    assert max(d["ms_per_step_by_rank"]) <= r["ms_per_step"] * 1.05  # the line reports the MAX over ranks

@@ -24,6 +24,28 @@ def test_bare_gpus_2_starts_two_ranks_and_relays_one_json_line():
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["dry_run"] is True
 
 
+def test_bare_gpus_8_starts_eight_ranks():
+    """The driver's full-node launch shape (--gpus 8): launcher, rendezvous on 127.0.0.1, one all-reduce over eight gloo ranks,
+    ONE JSON line relayed."""
+    p = _run(["--gpus", "8", "--dry-run"], {"OMP_NUM_THREADS": "1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == 8 and rec["dry_run"] is True
+
+
+def test_gpu_count_comes_from_sysfs_not_from_hip():
+    """the launcher counts GPUs from the KFD topology (no HIP call in the parent); unknown topology = None."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.gpu_count_without_hip()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launch = src[src.index("def launch_ranks"):src.index("def dry_run")]
+    assert "device_count" not in launch
+
+
 def test_world_size_mismatch_fails_loudly():
     p = _run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert p.returncode != 0

@@ -365,6 +365,54 @@ def test_backward_statistics_fold_leaves_the_step_unchanged(precision, act, norm
         assert float((a - b).abs().max()) <= tol * scale, (n, float((a - b).abs().max()) / scale)
 
 
+@pytest.mark.parametrize("offset", [0.0, 0.03])
+def test_backward_statistics_fold_is_no_worse_than_the_two_pass_form_against_the_f64_oracle(offset):
+    """the fused sums (f32 accumulators) and the two-pass sums (stored 16-bit dz) are both judged against the
+    oracle's float64 gradients -- not only against each other -- on EquiUnet-48 in fp16 storage (the forward, hence every ReLU
+    mask, is bit-identical in both forms).  offset > 0 adds a constant to every 3x3x3 weight, so that each channel's raw
+    convolution output has a mean several times its standard deviation: the regime where  sum(u*y) - mean*sum(u)  cancels."""
+    import copy
+    from brats21_amd import get_model
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.manual_seed(0)
+    ns = argparse.Namespace(model="equiunet", width=48, norm="group", act="relu", num_classes=3, dropout=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = get_model(ns)
+    sd = {k: (v + offset if (v.dim() == 5 and v.shape[2] == 3) else v).detach().clone() for k, v in base.state_dict().items()}
+    base.load_state_dict(sd)
+    base = base.to(dev).train()
+    base.precision = "fp16"
+    size = (32, 32, 32)
+    x, t = synth.random_image(1, 4, size, seed=11), synth.nested_spheres(1, size)
+    sd64 = {k: (v.double().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    unet.deep_supervision_loss(unet.equiunet_forward(sd64, x.double()), t.double()).backward()
+    if offset:  # the premise: |channel mean| >> channel std of a raw convolution output (here: encoder1's first layer)
+        with torch.no_grad():
+            y = torch.nn.functional.conv3d(x, sd["encoder1.ConvBnRelu1.conv.weight"], None, 1, 1)
+        ratio = float((y.mean((0, 2, 3, 4)).abs() / y.std((0, 2, 3, 4))).median())
+        assert ratio > 1.0, ratio
+
+    def run(fold):
+        model = copy.deepcopy(base)
+        model.fold_bwd_stats = fold
+        out, deep = model(x.to(dev))
+        unet.deep_supervision_loss((out.float(), [d.float() for d in deep]), t.to(dev)).backward()
+        return {k: p.grad.detach().double().cpu() for k, p in model.named_parameters()}
+
+    g_f, g_2 = run(True), run(False)
+    rel = lambda g, k: float((g[k] - sd64[k].grad).norm() / (sd64[k].grad.norm() + 1e-30))  # noqa: E731
+    e_f = {k: rel(g_f, k) for k in g_f}
+    e_2 = {k: rel(g_2, k) for k in g_2}
+    med = lambda d: sorted(d.values())[len(d) // 2]  # noqa: E731
+    worst = max(e_f, key=lambda k: e_f[k] / (e_2[k] + 1e-6))
+    print(f"\nfold_bwd_stats vs f64 oracle (offset {offset}): fused median {med(e_f):.3e} max {max(e_f.values()):.3e}; two-pass median "
+          f"{med(e_2):.3e} max {max(e_2.values()):.3e}; worst ratio {e_f[worst] / (e_2[worst] + 1e-6):.2f} ({worst})")
+    assert med(e_f) <= 1.2 * med(e_2) + 1e-4 and max(e_f.values()) <= 1.2 * max(e_2.values()) + 1e-3
+    for k in e_f:
+        assert e_f[k] <= 1.2 * e_2[k] + 0.25 * med(e_2) + 1e-4, (k, e_f[k], e_2[k])
+
+
 @pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_fold_forms_leave_the_step_unchanged(name, precision):

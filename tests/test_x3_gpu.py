@@ -237,6 +237,28 @@ def test_equiunet48_x3_vs_oracle(size):
     assert errs["x3"][0] < 4 * max(errs["fp32"][0], 5e-5), errs  # f32-class, not merely under the bar
 
 
+@pytest.mark.parametrize("name", ["equiunet", "equiunet_assp_evo"])
+def test_x3_forward_survives_unnormalised_inputs(name):
+    """fp16 pairs overflow at |x| >= 65504 -- the network INPUT is the one convolution operand no normalisation has
+    bounded.  An un-normalised volume (|x| up to 1.4e5 here) must give finite logits within the bar of the CPU oracle on the SAME
+    input (the first layer's forward scales by the power of two of the recorded |max|, brats_conv3d_x3_fwd's xamax)."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    m = _get(name, 16)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).eval()
+    x = synth.random_image(1, 4, (32, 32, 32), seed=21) * 3.0e4
+    assert float(x.abs().max()) > 65504.0
+    fwd = unet.equiunet_forward if name == "equiunet" else unet.assp_evo_forward
+    with torch.no_grad():
+        ref = fwd(sd, x)[0]
+        m.precision = "x3"
+        out = m(x.to(DEV))[0].cpu()
+    assert bool(torch.isfinite(out).all())
+    err = float((out - ref).abs().max())
+    print(f"\n{name}-16 x3 forward on an un-normalised volume (|x| max {float(x.abs().max()):.3g}): max abs logit err {err:.2e}")
+    assert err < LOGIT_ATOL, err
+
+
 def _step_grads(m, prec, x, t):
     m.zero_grad()
     m.precision = prec
