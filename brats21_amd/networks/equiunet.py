@@ -12,6 +12,7 @@ Precision follows the reference's switch (learning/engine.py:304 ``autocast(enab
 under autocast the bf16-storage / f32-accumulate kernels run, otherwise the exact-f32 MFMA kernels
 (the 1e-3 logit parity mode).  ``model.precision = "bf16" | "fp32"`` overrides it.
 """
+import contextlib
 import math
 
 import os
@@ -50,6 +51,73 @@ class _NormParams(nn.Module):
             self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
 
+class _EstBNParams(nn.Module):
+    """EstBN's parameters and buffers under its state-dict names (networks/factory.py:150-160)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.register_buffer("estbn_moving_speed", torch.zeros(1))
+
+
+class _BCNormParams(nn.Module):
+    """``--norm bcn`` = BCNorm(C, 8, estimate=True) (networks/factory.py:125-147,189-190): per-GROUP weight / bias [1, 8, 1]
+    around a per-(sample, group) normalisation of EstBN's output.  How it runs here (no new kernel): EstBN is a per-channel
+    affine map with constants -- u = a_c * y + b_c, a_c = weight_c / sqrt(running_var_c + 1e-5), b_c = bias_c - running_mean_c *
+    a_c -- because nothing in the reference ever sets ``estbn_moving_speed`` away from 0, so its running buffers never move.  A
+    per-output-channel affine map behind a convolution IS a convolution: the unit packs a_c * W_c and passes b_c as the
+    bias, the implicit-GEMM kernel writes u directly, and what is left of BCNorm is GroupNorm(8) whose per-channel gamma /
+    beta are the group's weight / bias -- the existing statistics, apply and backward kernels.  The chain rule back to W, EstBN's
+    weight / bias and the group parameters is [C]- and weight-sized torch algebra (_bcn_param_grads)."""
+
+    def __init__(self, c, groups=8):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(1, groups, 1))
+        self.bias = nn.Parameter(torch.zeros(1, groups, 1))
+        self.bn = _EstBNParams(c)
+        self.num_groups = groups
+        self._speed_checked = False
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._speed_checked = False
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def tables(self):
+        """(a_c, b_c, gamma_c, beta_c): EstBN as a per-channel affine map; the group weight / bias expanded per channel."""
+        if not self._speed_checked:  # (the reference reads it with .item() in EVERY forward; once per load is enough here)
+            if float(self.bn.estbn_moving_speed.reshape(-1)[0]) != 0.0:
+                raise NotImplementedError("--norm bcn: EstBN with estbn_moving_speed != 0 is not implemented (the reference "
+                                          "never sets it: networks/factory.py:160 is its only mention)")
+            self._speed_checked = True
+        c = self.bn.weight.numel()
+        a = self.bn.weight.detach() * torch.rsqrt(self.bn.running_var + 1e-5)
+        b = self.bn.bias.detach() - self.bn.running_mean * a
+        cpg = c // self.num_groups
+        gamma = self.weight.detach().reshape(-1).repeat_interleave(cpg)
+        beta = self.bias.detach().reshape(-1).repeat_interleave(cpg)
+        return a.float().contiguous(), b.float().contiguous(), gamma.float().contiguous(), beta.float().contiguous()
+
+
+def _bcn_param_grads(unit, dw_eff, db_eff, dgamma_c, dbeta_c):
+    """Chain rule of the BCNorm unit (see _BCNormParams): W' = a_c W, bias' = b_c, gamma_c = group weight, beta_c = group bias.
+    Returns {parameter: gradient} for conv.weight, bn.weight, bn.bias, bn.bn.weight, bn.bn.bias."""
+    bcn = unit.bn
+    a, _, _, _ = bcn.tables()
+    w = unit.conv.weight.detach()
+    k = torch.rsqrt(bcn.bn.running_var + 1e-5)
+    da = (dw_eff * w).sum((1, 2, 3, 4))
+    g = bcn.num_groups
+    return {unit.conv.weight: dw_eff * a.view(-1, 1, 1, 1, 1),
+            bcn.weight: dgamma_c.view(g, -1).sum(1).view(1, g, 1),
+            bcn.bias: dbeta_c.view(g, -1).sum(1).view(1, g, 1),
+            bcn.bn.weight: k * (da - bcn.bn.running_mean * db_eff),
+            bcn.bn.bias: db_eff}
+
+
 class ConvBnRelu(nn.Module):
     """conv3x3x3 (no bias) -> norm -> act -> Dropout(p)   (networks/equiunet2020.py:51-75).  The norm is GroupNorm(8)
     (``--norm group``) or InstanceNorm3d(affine=True) (``--norm instance``, the CLI default; networks/factory.py:
@@ -64,11 +132,12 @@ class ConvBnRelu(nn.Module):
         super().__init__()
         self.conv = _ConvParams(inplanes, planes, 3, bias=False)
         self.batch_norm = norm == "batch"
-        self.bn = _NormParams(planes, batch=self.batch_norm)
+        self.bcn = norm == "bcn"
+        self.bn = _BCNormParams(planes, 8) if self.bcn else _NormParams(planes, batch=self.batch_norm)
         if act == "prelu":
             self.prelu = nn.PReLU()
         self.dilation = dilation
-        self.groups = 8 if norm == "group" else planes
+        self.groups = 8 if norm in ("group", "bcn") else planes
 
 
 class UBlock(nn.Module):
@@ -153,7 +222,7 @@ def _one_sample(t):
     return t.view(1, n * d, h, w, c)
 
 
-def _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training):
+def _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training, drop=None):
     """BatchNorm3d + activation behind the convolution (see ConvBnRelu)."""
     n, d, h, wd, c = y.shape
     bn = unit.bn
@@ -172,17 +241,31 @@ def _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training):
         scale_shift = torch.stack([scale, bn.bias.detach() - bn.running_mean * scale], -1).reshape(1, c, 2).contiguous().float()
     kact, slope_t = _unit_act(unit, act)
     z = ops.affine_act(_one_sample(y), scale_shift, kact, slope_t=slope_t).view(n, d, h, wd, c)
+    if drop is not None:
+        ops.dropout(z, drop[0], drop[1], drop[2], out=z)
     rec = (unit, x, x2, y, mean_rstd, scale_shift)
     if pool:
         return (z, ops.maxpool2(z, want_argmax=pool == "argmax")), rec
     return z, rec
 
 
-def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False, lazy=False, training=True):
+def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_act=False, pool=False, lazy=False, training=True,
+             drop=None):
     """One ConvBnRelu: pack -> implicit-GEMM conv over the virtual concat [x | x2] (+ tile statistics)
     -> finalize -> normalise+act.  fp8: the convolution runs on the e4m3 kernel (scales from the |max| the producer of
     x recorded); the normalise+act pass records the |max| of its own output for the next layer."""
+    # drop = (p, state, unit id): nn.Dropout(p) behind the activation (networks/equiunet2020.py:62; training mode only).  The
+    # activation is then always materialised (no fused pooling / head / on-load forms) and dropped in place (ops.dropout).
+    if drop is not None:
+        lazy = False
     w = unit.conv.weight
+    cbias, gamma_c, beta_c = None, unit.bn.weight.detach(), unit.bn.bias.detach()
+    if unit.bcn:
+        # BCNorm (see _BCNormParams): EstBN's per-channel affine map rides in the convolution (weights a_c * W, bias b_c), the
+        # rest is GroupNorm(8) with the group's weight / bias as per-channel gamma / beta
+        a_c, cbias, gamma_c, beta_c = unit.bn.tables()
+        w = w.detach() * a_c.view(-1, 1, 1, 1, 1)
+        fp8, lazy = None, False
     cout = w.shape[0]
     cin_pad = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
     c1 = x.shape[-1] if x2 is not None else None
@@ -197,20 +280,21 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
         y, stats = ops.conv3d_f8(x, wpk, cout, unit.dilation, want_stats=True, x2=x2, amax=getattr(x, "_amax", None),
                                  amax2=getattr(x2, "_amax", None) if x2 is not None else None)
     else:
-        wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=c1)
+        with ops.use_plan(None) if unit.bcn else contextlib.nullcontext():  # (a_c * W is a new tensor every step: not a plan entry)
+            wpk = ops.pack_weights(w, dtype, PACK_FWD, cin_pad=cin_pad, dil=unit.dilation, c1=c1)
         # (_x3amax: the network input in split-precision mode -- the only conv input no normalisation has bounded; see _EquiUnetFn)
-        y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2, amax=getattr(x, "_x3amax", None))
+        y, stats = ops.conv3d(x, wpk, cout, 3, unit.dilation, want_stats=True, x2=x2, amax=getattr(x, "_x3amax", None), bias=cbias)
     n, d, h, wd, _ = y.shape
     if unit.batch_norm:
-        return _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training)
-    mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, unit.bn.weight.detach(), unit.bn.bias.detach())
+        return _bn_fwd_tail(unit, x, x2, y, stats, act, pool, training, drop)
+    mean_rstd, scale_shift = ops.gn_finalize(stats, n, cout, unit.groups, d * h * wd, gamma_c, beta_c)
     if no_act:  # the last layer under the fused output head (ops.gn_head): the activation is applied on load there
         return y, (unit, x, x2, y, mean_rstd, scale_shift)
     amax = slots.take() if slots is not None else None
     kact, slope_t = _unit_act(unit, act)
     if lazy and slope_t is None and kact in ("relu", "leakyrelu") and amax is None and not pool:
         return ops.Pending(y, scale_shift, kact), None  # (no_grad only: nothing is taped)
-    if pool and kact in ("relu", "leakyrelu") and y.numel() * y.element_size() >= (256 << 20):
+    if pool and drop is None and kact in ("relu", "leakyrelu") and y.numel() * y.element_size() >= (256 << 20):
         # the layer ends an encoder level: normalise + act and the 2x2x2 max pool of the result in one pass -- for tensors
         # beyond the Infinity Cache (the 128^3 level: 188 us against 148 + 85); smaller ones are re-read from the cache by
         # the pooling kernel at no HBM cost and the two plain kernels are as fast (measured: 70 against 63 us)
@@ -221,13 +305,15 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
     z = ops.affine_act(y, scale_shift, kact, out=out, amax=amax, slope_t=slope_t)
     if amax is not None:
         z._amax = amax
+    if drop is not None:
+        ops.dropout(z, drop[0], drop[1], drop[2], out=z)
     if pool:
         return (z, _inherit_amax(ops.maxpool2(z, want_argmax=pool == "argmax"), z)), (unit, x, x2, y, mean_rstd, scale_shift)
     return z, (unit, x, x2, y, mean_rstd, scale_shift)
 
 
 def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=None, slots=None, side=None, dest=None, head=None,
-             pool=None, bst=None):
+             pool=None, bst=None, drop=None):
     """Returns dx, or (dx1, dx2) -- two dense tensors from one dgrad launch -- for a two-source unit.
     bst: the record of the unit that PRODUCED this unit's input (the first unit of the block).  Where the kernel form is built,
     the input-gradient launch also takes the first pass of that unit's GroupNorm backward (ops.conv3d_bstats) and dx is
@@ -238,9 +324,17 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     the layer input recorded in the forward pass)."""
     unit, x, x2, y, mean_rstd, scale_shift = rec
     cin = unit.conv.weight.shape[1]
+    gamma_c = unit.bn.weight.detach()
+    w_bwd = unit.conv.weight
+    if unit.bcn:
+        a_c, _, gamma_c, _ = unit.bn.tables()
+        w_bwd = unit.conv.weight.detach() * a_c.view(-1, 1, 1, 1, 1)  # the weights the forward convolved with
+        fp8 = None
     tiles = None
     if isinstance(dz, tuple):
         dz, tiles = dz
+    if drop is not None:  # the forward's mask, regenerated: d(dropout(z)) / dz = the same multiplier (ops.dropout)
+        dz = ops.dropout(dz, drop[0], drop[1], drop[2])
     all8 = fp8 == "all" and ops.is16(dtype)
     f8 = all8 and need_dx and ops.conv_f8_chunk(y.shape[-1]) > 0
     # e4m3 weight gradient: where the all-taps kernel is built for the layer and the producers of x (x2) recorded |max|
@@ -259,7 +353,7 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         if mean_rstd is None:
             raise NotImplementedError("--norm batch: backward through an eval-mode forward (running statistics) is not implemented")
         n_, d_, h_, w_, c_ = y.shape
-        dy, dgamma, dbeta = ops.gn_act_bwd(_one_sample(dz), _one_sample(y), scale_shift, mean_rstd, unit.bn.weight.detach(), c_, kact,
+        dy, dgamma, dbeta = ops.gn_act_bwd(_one_sample(dz), _one_sample(y), scale_shift, mean_rstd, gamma_c, c_, kact,
                                            amax=amax, slope_t=slope_t)
         dy = dy.view(n_, d_, h_, w_, c_)
         if amax is not None:
@@ -268,7 +362,7 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         # the last layer: its output feeds only the 1x1x1 head, whose backward is folded into the GroupNorm backward --
         # d(up1) is never written, the head's weight / bias gradients come out of the same passes (ops.gn_act_bwd_head)
         hd, dout = head
-        dy, dgamma, dbeta, dhw, dhb = ops.gn_act_bwd_head(dout, hd.weight, y, scale_shift, mean_rstd, unit.bn.weight.detach(),
+        dy, dgamma, dbeta, dhw, dhb = ops.gn_act_bwd_head(dout, hd.weight, y, scale_shift, mean_rstd, gamma_c,
                                                           unit.groups, kact, amax=amax)
         for prm, g in ((hd.weight, dhw), (hd.bias, dhb)):
             grads[names[prm]] = g
@@ -277,13 +371,13 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
     elif pool is not None:
         # the layer ends an encoder level: dz = skip gradient + max-pool backward, composed inside the GroupNorm backward from
         # (d_skip, d_pooled, arg-max bytes) -- the pooling backward's output tensor is never written (ops.gn_act_bwd_pool)
-        dy, dgamma, dbeta = ops.gn_act_bwd_pool(pool[0], pool[1], pool[2], y, scale_shift, mean_rstd, unit.bn.weight.detach(),
+        dy, dgamma, dbeta = ops.gn_act_bwd_pool(pool[0], pool[1], pool[2], y, scale_shift, mean_rstd, gamma_c,
                                                 unit.groups, kact, amax=amax)
     elif tiles is not None:
-        dy, dgamma, dbeta = ops.gn_act_bwd_tiles(tiles, dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact,
+        dy, dgamma, dbeta = ops.gn_act_bwd_tiles(tiles, dz, y, scale_shift, mean_rstd, gamma_c, unit.groups, kact,
                                                  amax=amax)
     else:
-        dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, unit.bn.weight.detach(), unit.groups, kact, amax=amax,
+        dy, dgamma, dbeta = ops.gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma_c, unit.groups, kact, amax=amax,
                                            slope_t=slope_t)
     # data-parallel: the weight gradient is written straight into its slice of the all-reduce bucket
     wdst = dest(names[unit.conv.weight]) if dest is not None else None
@@ -297,17 +391,20 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         if w8 and amax is not None:
             dw = ops.conv3d_wgrad_f8(x, dy, ax, amax, x2=x2, amax2=ax2, out=wdst)
         elif x2 is not None and x.shape[-1] % 16:  # narrow test widths only: the wgrad ci tile (16) would straddle x | x2
-            dw, _ = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation, amax_dy=amax if x3s else None)
+            dw, db = ops.conv3d_wgrad(torch.cat([x, x2], -1), dy, 3, unit.dilation, amax_dy=amax if x3s else None, want_dbias=unit.bcn)
         else:
-            dw, _ = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2, out=wdst, amax_dy=amax if x3s else None)
+            dw, db = ops.conv3d_wgrad(x, dy, 3, unit.dilation, x2=x2, out=None if unit.bcn else wdst, amax_dy=amax if x3s else None,
+                                      want_dbias=unit.bcn)
         dw = dw[:, :cin].contiguous() if dw.shape[1] != cin else dw
         on_side(dw)
-    grads[names[unit.conv.weight]] = dw
-    grads[names[unit.bn.weight]] = dgamma
-    grads[names[unit.bn.bias]] = dbeta
-    if sink is not None:  # data-parallel: hand finished gradients to the bucketed all-reduce right away
-        for prm in (unit.conv.weight, unit.bn.weight, unit.bn.bias):
-            sink(names[prm], grads[names[prm]])
+    if unit.bcn:
+        pg = _bcn_param_grads(unit, dw, db, dgamma, dbeta)  # dw / db are the gradients of a_c * W and b_c
+    else:
+        pg = {unit.conv.weight: dw, unit.bn.weight: dgamma, unit.bn.bias: dbeta}
+    for prm, g in pg.items():
+        grads[names[prm]] = g
+        if sink is not None:  # data-parallel: hand finished gradients to the bucketed all-reduce right away
+            sink(names[prm], g)
     if not need_dx:
         return None
     if f8:
@@ -316,7 +413,8 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         def dgrad(**kw):
             return ops.conv3d_f8(dy, wpk, cin, unit.dilation, amax=amax, **kw)
     else:
-        wpk = ops.pack_weights(unit.conv.weight, dtype, PACK_DGRAD, dil=unit.dilation)
+        with ops.use_plan(None) if unit.bcn else contextlib.nullcontext():
+            wpk = ops.pack_weights(w_bwd, dtype, PACK_DGRAD, dil=unit.dilation)
 
         def dgrad(**kw):
             return ops.conv3d(dy, wpk, cin, 3, unit.dilation, amax=amax if x3s else None, **kw)
@@ -324,7 +422,7 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         if bst is not None and not f8 and not x3s:
             u1, _, _, y1, mr1, ss1 = bst
             kact1, slope1 = _unit_act(u1, act)
-            if (not u1.batch_norm and mr1 is not None and y1.shape[-1] == cin and y1.dtype == dy.dtype
+            if (not u1.batch_norm and not u1.bcn and not unit.bcn and mr1 is not None and y1.shape[-1] == cin and y1.dtype == dy.dtype
                     and ops.conv_bstats_ok(dtype, unit.dilation, dy.shape[-1], cin, kact1, slope1)):
                 return ops.conv3d_bstats(dy, wpk, cin, unit.dilation, y1, ss1, kact1)  # (dx, tile sums of u1's GroupNorm backward)
         dx, _ = dgrad()
@@ -373,10 +471,20 @@ class _EquiUnetFn(torch.autograd.Function):
         # convolution -- it is never stored (ops.Pending: normalise + act applied on load, model.norm_on_load)
         lazy_ok = (not will_bwd) and (not torch.is_grad_enabled()) and m.norm_on_load and ops.is16(dtype)
 
+        # nn.Dropout(p) behind every unit's activation, training mode only (networks/equiunet2020.py:62): the state (seed, step
+        # counter) is advanced on the device and a copy travels to the backward, which regenerates the masks from it
+        drop_state = m._advance_dropout(dev) if (m.training and m.dropout_p > 0.0) else None
+        ctx.drop_state = drop_state
+        if drop_state is not None and fp8:
+            raise NotImplementedError("--dropout > 0 with the e4m3 convolution path is not implemented")
+
+        def drop_of(unit):
+            return (m.dropout_p, drop_state, m._unit_ids[unit]) if drop_state is not None else None
+
         def cgr(unit, xin, x2=None, pool=False, lazy=False):
             # (training: the fused pooling pass also records the arg-max bytes its backward reads)
             z, rec = _cgr_fwd(unit, xin, dtype, act, None, x2, fp8, slots, pool=("argmax" if will_bwd else True) if pool else False,
-                              lazy=lazy and lazy_ok, training=m.training)
+                              lazy=lazy and lazy_ok, training=m.training, drop=drop_of(unit))
             tape.append(rec)
             return z
 
@@ -412,7 +520,7 @@ class _EquiUnetFn(torch.autograd.Function):
         # needs (ops.gn_act_bwd_head) -- up1 (2 x 403 MB written + read at 2 x 48 x 128^3) is never stored
         kact, slope_t = _unit_act(m.decoder1.ConvBnRelu2, act)
         nk = m.outconv.weight.shape[0]
-        fuse_top = (m.fold_head_fwd and not m.decoder1.ConvBnRelu2.batch_norm and slope_t is None and kact in ("relu", "leakyrelu") and nk <= 4
+        fuse_top = (m.fold_head_fwd and drop_state is None and not m.decoder1.ConvBnRelu2.batch_norm and slope_t is None and kact in ("relu", "leakyrelu") and nk <= 4
                     and (not will_bwd or (m.fold_head_bwd and ops.head_fold_ok(m.outconv.weight, kact, slope_t))))
         if fuse_top:
             y1, rec1 = _cgr_fwd(m.decoder1.ConvBnRelu2, u1, dtype, act, None, None, fp8, slots, no_act=True)
@@ -453,17 +561,22 @@ class _EquiUnetFn(torch.autograd.Function):
         for u in rec:
             u._side_small_only = m.wgrad_stream == "small"
 
+        drop_state = ctx.drop_state  # dropout: the folds that never materialise a unit's output gradient are off
+
         def cbw(unit, dz, need_dx=True, head=None, pool=None, first=None):
             # first: the block's first unit, whose output is this unit's only input -- its GroupNorm backward's first pass rides
             # in this unit's input-gradient launch (model.fold_bwd_stats)
-            bst = rec[first] if (first is not None and m.fold_bwd_stats) else None
-            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head, pool, bst)
+            bst = rec[first] if (first is not None and m.fold_bwd_stats and drop_state is None) else None
+            drop = (m.dropout_p, drop_state, m._unit_ids[unit]) if drop_state is not None else None
+            return _cgr_bwd(rec[unit], dz, dtype, act, grads, names, need_dx, m._grad_sink, fp8, slots, side, m._grad_dest, head, pool, bst,
+                            drop)
 
         def level_bwd(unit, down, d_pooled, d_skip, need_dx=True, first=None):
             """Backward of the last layer of an encoder level: its output gradient = d_skip + max-pool backward(d_pooled)."""
             idx = getattr(down, "_pool_argmax", None)
             kact, slope_t = _unit_act(unit, act)
-            if idx is not None and m.fold_pool_bwd and not unit.batch_norm and slope_t is None and kact in ("relu", "leakyrelu"):
+            if (idx is not None and m.fold_pool_bwd and drop_state is None and not unit.batch_norm and slope_t is None
+                    and kact in ("relu", "leakyrelu")):
                 return cbw(unit, None, need_dx, pool=(d_skip, d_pooled, idx), first=first)
             return cbw(unit, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip), need_dx, first=first)
 
@@ -476,7 +589,7 @@ class _EquiUnetFn(torch.autograd.Function):
                 dout = torch.zeros((ctx.out_shape), dtype=torch.float32, device=douts_device(douts))
             if dout is None:
                 continue
-            if hd is m.outconv and (ctx.top_fused or (m.fold_head_bwd and not m.decoder1.ConvBnRelu2.batch_norm
+            if hd is m.outconv and (ctx.top_fused or (m.fold_head_bwd and drop_state is None and not m.decoder1.ConvBnRelu2.batch_norm
                                                        and ops.head_fold_ok(hd.weight, *_unit_act(m.decoder1.ConvBnRelu2, act)))):
                 top = (hd, dout)
                 continue
@@ -534,15 +647,14 @@ class EquiUnet(_PackedWeightsModule):
     def __init__(self, inplanes, num_classes, features, norm_layer=None, act="relu", deep_supervision=False, dropout=0,
                  refinement=False):
         super().__init__()
-        if norm_layer not in ("group", "instance", "batch"):
-            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance|batch (got {norm_layer!r}; 'bcn' = the "
-                                      "reference's BCNorm with EstBN is outside the accelerated path)")
+        if norm_layer not in ("group", "instance", "batch", "bcn"):
+            raise NotImplementedError(f"brats21_amd.EquiUnet implements --norm group|instance|batch|bcn (got {norm_layer!r})")
         if norm_layer == "batch" and act == "prelu":
             raise NotImplementedError("--norm batch with --act prelu is not implemented")
         if act not in ("relu", "leakyrelu", "elu", "prelu", "swish", "mish"):
             raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu|elu|prelu|swish|mish (got {act!r})")
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not implemented (the published configs use 0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         if refinement:
             raise NotImplementedError("equiunet_ref (RefUnet) is outside the accelerated hot path")
         if inplanes != 4 or num_classes > 4 or any(c % 8 for c in features):
@@ -551,6 +663,11 @@ class EquiUnet(_PackedWeightsModule):
         self.deep_supervision = deep_supervision
         self.act = act
         self.features = list(features)
+        # nn.Dropout(p) behind every ConvBnRelu's activation (networks/equiunet2020.py:62; --dropout, src/arguments_train.py:52).
+        # The masks come from this library's Philox stream (csrc/dropout.hip), seeded from torch's CPU generator at construction
+        # (torch.manual_seed makes a run repeatable); not part of the state dict, like torch's own RNG state
+        self.dropout_p = float(dropout)
+        self.register_buffer("_dropout_state", torch.tensor([int(torch.randint(0, 2 ** 62, (1,))), 0], dtype=torch.int64), persistent=False)
         # "auto" = follow torch.autocast; BRATS_PRECISION=x3 makes the split-precision parity mode the default of an unmodified
         # training script run with --no_amp
         self.precision = os.environ.get("BRATS_PRECISION", "auto")
@@ -600,6 +717,7 @@ class EquiUnet(_PackedWeightsModule):
             self.deep_bottom2 = _head(f[2], num_classes)
             self.deep3 = _head(f[1], num_classes)
             self.deep2 = _head(f[0], num_classes)
+        self._unit_ids = {u: i for i, u in enumerate(mod for mod in self.modules() if isinstance(mod, ConvBnRelu))}
         # init_weights(self, "kaiming"), networks/factory.py:203-224: kaiming-normal fan_out on conv weights
         print("initialize network with kaiming")
         for mod in self.modules():
@@ -608,6 +726,14 @@ class EquiUnet(_PackedWeightsModule):
             elif isinstance(mod, _NormParams) and norm_layer == "batch":  # factory.py:219-221: BatchNorm3d weights ~ N(1, 0.02)
                 nn.init.normal_(mod.weight.data, 1.0, 0.02)
                 nn.init.constant_(mod.bias.data, 0.0)
+
+    def _advance_dropout(self, device):
+        """Next step's dropout state: the counter moves ON THE DEVICE (a captured step draws fresh masks at every replay); the
+        returned copy belongs to this forward / backward pair."""
+        if self._dropout_state.device != device:
+            raise BratsHipError("brats21_amd.EquiUnet: module and input are on different devices")
+        self._dropout_state[1] += 1
+        return self._dropout_state.clone()
 
     def _dtype(self):
         if self.precision == "bf16":

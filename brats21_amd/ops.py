@@ -731,6 +731,24 @@ def affine_act(y, scale_shift, act="relu", out=None, slope=0.01, amax=None, slop
     return out
 
 
+def dropout(x, p, state, unit, out=None):
+    """nn.Dropout(p) on an NDHWC activation (or, with the same arguments, on the gradient flowing back through it): x * keep /
+    (1 - p) with keep a pure function of (state[0] = seed, state[1] = step counter, unit id, element index) -- brats_dropout.
+    state: int64[2] DEVICE tensor.  out=x: in place."""
+    ptr, c, pitch = _desc(x)
+    n, d, h, w, _ = x.shape
+    if state.dtype != torch.int64 or state.numel() != 2 or not state.is_cuda:
+        raise _lib.BratsHipError("dropout: state must be an int64[2] device tensor (seed, step counter)")
+    if out is None:
+        out = new_act(n, d, h, w, c, x.dtype, x.device)
+    optr, oc, op = _desc(out)
+    if oc != c or out.dtype != x.dtype:
+        raise _lib.BratsHipError("dropout: bad output tensor")
+    _lib.check(_lib.lib().brats_dropout(ptr, pitch, optr, op, _code(x.dtype), n * d * h * w, c, float(p), state.data_ptr(), int(unit),
+                                        _stream()), "dropout")
+    return out
+
+
 def affine_act_pool(y, scale_shift, act="relu", slope=0.01, amax=None, slope_t=None, with_avg=False, want_argmax=False):
     """(z, pooled) = (affine_act(y), maxpool2(z)) in one pass (include/brats_hip.h: brats_affine_act_pool_fwd).
     want_argmax: z._pool_argmax = the uint8 window index of every pooled element, which maxpool2_bwd(z, ...) then reads

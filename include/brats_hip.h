@@ -54,6 +54,15 @@ enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_EL
 int brats_abi_version(void);
 const char* brats_last_error(void);
 
+/* ---- dropout ---------------------------------------------------------------------------------
+ * nn.Dropout(p) of a ConvBnRelu unit (networks/equiunet2020.py:62,72; --dropout, src/arguments_train.py:52):
+ * out[v][c] = x[v][c] * keep / (1 - p) over `voxels` (N * D * H * W) voxels of C channels (NDHWC, pitches in elements; in place
+ * allowed).  keep is a pure function of (state[0] = seed, state[1] = step counter, unit, v * C + c) -- Philox4x32-10 -- and
+ * never stored: the backward pass calls the same function on the incoming gradient with the same arguments.  `state`: two
+ * uint64 in DEVICE memory (read by the kernel, so a hipGraph replay sees an advanced counter).  dtype F32 | BF16 | F16. */
+int brats_dropout(const void* x, int xpitch, void* out, int opitch, int dtype, size_t voxels, int C, float p,
+                  const void* state, int unit, brats_stream_t s);
+
 /* ---- layout ---------------------------------------------------------------------------------
  * NCDHW f32 (the reference's tensor layout, learning/engine.py:89) <-> NDHWC dtype.  `cpad` >= C
  * channels are written, the extra ones as zeros (first layer: 4 -> 8 so K is MFMA-friendly). */

@@ -29,6 +29,8 @@ def fill_state_dict(shapes):
             sd[k] = closed_form(k, shp, 0.2, 1.0)
         elif k.endswith("bn.running_mean"):
             sd[k] = closed_form(k, shp, 0.05, 0.0)
+        elif leaf == "estbn_moving_speed":   # EstBN's buffer: zeros(1), never set by the reference (networks/factory.py:160)
+            sd[k] = torch.zeros(shp)
         elif leaf == "num_batches_tracked":
             sd[k] = torch.tensor(0, dtype=torch.long)
         elif leaf in ("v", "running_var"):

@@ -38,7 +38,7 @@ def _act(x, act, slope=None):
     raise ValueError(act)
 
 
-def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group", training=True, new_stats=None):
+def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group", training=True, new_stats=None, drop=None):
     """ConvBnRelu, networks/equiunet2020.py:51-75: conv3x3x3 (no bias, pad=dil) -> norm -> act -> Dropout(p=0)
     (identity).  norm "group" = GroupNorm(8, C, affine), "instance" = InstanceNorm3d(C, affine=True) (the CLI
     default, src/arguments_train.py:48) = per-(sample, channel) statistics, biased variance, eps 1e-5, "batch" =
@@ -55,15 +55,42 @@ def conv_gn_act(sd, pre, x, dilation=1, act="relu", norm="group", training=True,
         y = F.batch_norm(y, rm, rv, sd[pre + ".bn.weight"], sd[pre + ".bn.bias"], training, 0.1, 1e-5)
         if training and new_stats is not None:
             new_stats[pre + ".bn.running_mean"], new_stats[pre + ".bn.running_var"] = rm, rv
+    elif norm == "bcn":
+        y = bcnorm(sd, pre + ".bn", y)
     else:
         raise ValueError(norm)
-    return _act(y, act, sd.get(pre + ".prelu.weight"))
+    y = _act(y, act, sd.get(pre + ".prelu.weight"))
+    # nn.Dropout(p) behind the activation (networks/equiunet2020.py:62).  The oracle is a pure function: the caller passes the
+    # multiplier keep / (1 - p) of every unit ({unit prefix: tensor}), e.g. the masks the product's generator drew
+    return y if drop is None else y * drop[pre]
 
 
-def ublock(sd, pre, x, dilation=(1, 1), act="relu", norm="group", training=True, new_stats=None):
+def bcnorm(sd, pre, x, groups=8, eps=1e-5):
+    """--norm bcn = BCNorm(C, 8, estimate=True), networks/factory.py:125-176,189-190.
+    (i) EstBN (:150-176): (x - running_mean_c) / sqrt(running_var_c + 1e-5) * weight_c + bias_c with the running BUFFERS in
+    training and eval mode alike; its training-mode update of the buffers moves them by ``estbn_moving_speed``, a buffer
+    initialised to 0 that nothing in the reference ever sets (grep: only factory.py mentions it) -- so the buffers stay what
+    they were initialised / loaded as, and the oracle (a pure function) refuses a non-zero speed instead of mutating sd.
+    (ii) torch.batch_norm over the view [1, N * groups, -1] with training=True, no affine (:143-144): per (sample, group)
+    mean and BIASED variance over C/groups x D x H x W, eps 1e-5.  (iii) per-GROUP weight / bias of shape [1, groups, 1] (:146)."""
+    ms = float(sd[pre + ".bn.estbn_moving_speed"].reshape(-1)[0])
+    if ms != 0.0:
+        raise NotImplementedError("EstBN with estbn_moving_speed != 0 (the reference never sets it)")
+    shp = (1, -1, 1, 1, 1)
+    k = torch.rsqrt(sd[pre + ".bn.running_var"].detach().to(x.dtype) + 1e-5).view(shp)
+    u = (x - sd[pre + ".bn.running_mean"].detach().to(x.dtype).view(shp)) * k * sd[pre + ".bn.weight"].view(shp) + sd[pre + ".bn.bias"].view(shp)
+    n = x.shape[0]
+    ug = u.reshape(n, groups, -1)
+    mean = ug.mean(-1, keepdim=True)
+    var = ug.var(-1, unbiased=False, keepdim=True)
+    out = (ug - mean) * torch.rsqrt(var + eps) * sd[pre + ".weight"] + sd[pre + ".bias"]
+    return out.reshape(x.shape)
+
+
+def ublock(sd, pre, x, dilation=(1, 1), act="relu", norm="group", training=True, new_stats=None, drop=None):
     """UBlock, networks/equiunet2020.py:105-123."""
-    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act, norm, training, new_stats)
-    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act, norm, training, new_stats)
+    x = conv_gn_act(sd, pre + ".ConvBnRelu1", x, dilation[0], act, norm, training, new_stats, drop)
+    return conv_gn_act(sd, pre + ".ConvBnRelu2", x, dilation[1], act, norm, training, new_stats, drop)
 
 
 def _up(x, s):
@@ -76,16 +103,16 @@ def _c1(sd, pre, x):
     return F.conv3d(x, sd[pre + ".weight"], sd[pre + ".bias"])
 
 
-def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group", training=True, new_stats=None):
+def equiunet_forward(sd, x, act="relu", deep_supervision=True, norm="group", training=True, new_stats=None, drop=None):
     """EquiUnet.forward, networks/equiunet2020.py:467-500. Returns (logits, [4 deep heads]).  training / new_stats: only
     --norm batch distinguishes the two modes (conv_gn_act)."""
-    kw = dict(act=act, norm=norm, training=training, new_stats=new_stats)
+    kw = dict(act=act, norm=norm, training=training, new_stats=new_stats, drop=drop)
     down1 = ublock(sd, "encoder1", x, **kw)
     down2 = ublock(sd, "encoder2", F.max_pool3d(down1, 2, 2), **kw)
     down3 = ublock(sd, "encoder3", F.max_pool3d(down2, 2, 2), **kw)
     down4 = ublock(sd, "encoder4", F.max_pool3d(down3, 2, 2), **kw)
     bottom = ublock(sd, "bottom", down4, (2, 2), **kw)
-    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act, norm, training, new_stats)
+    bottom_2 = conv_gn_act(sd, "bottom_2", torch.cat([down4, bottom], 1), 1, act, norm, training, new_stats, drop)
     up3 = ublock(sd, "decoder3", torch.cat([down3, _up(bottom_2, 2)], 1), **kw)
     up2 = ublock(sd, "decoder2", torch.cat([down2, _up(up3, 2)], 1), **kw)
     up1 = ublock(sd, "decoder1", torch.cat([down1, _up(up2, 2)], 1), **kw)
@@ -110,8 +137,18 @@ def equiunet_state_shapes(width, inplanes=4, num_classes=3, act="relu", norm="gr
 
     def cbr(pre, cin, cout):
         shapes[pre + ".conv.weight"] = (cout, cin, 3, 3, 3)
-        shapes[pre + ".bn.weight"] = (cout,)
-        shapes[pre + ".bn.bias"] = (cout,)
+        if norm == "bcn":  # BCNorm: per-group weight / bias, then its EstBN (networks/factory.py:127-139,152-160), in state-dict order
+            shapes[pre + ".bn.weight"] = (1, 8, 1)
+            shapes[pre + ".bn.bias"] = (1, 8, 1)
+            shapes[pre + ".bn.bn.weight"] = (cout,)
+            shapes[pre + ".bn.bn.bias"] = (cout,)
+            shapes[pre + ".bn.bn.running_mean"] = (cout,)
+            shapes[pre + ".bn.bn.running_var"] = (cout,)
+            shapes[pre + ".bn.bn.num_batches_tracked"] = ()
+            shapes[pre + ".bn.bn.estbn_moving_speed"] = (1,)
+        else:
+            shapes[pre + ".bn.weight"] = (cout,)
+            shapes[pre + ".bn.bias"] = (cout,)
         if norm == "batch":  # nn.BatchNorm3d's buffers, in its state-dict order
             shapes[pre + ".bn.running_mean"] = (cout,)
             shapes[pre + ".bn.running_var"] = (cout,)

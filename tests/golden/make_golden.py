@@ -96,6 +96,14 @@ def equiunet_elu_fixture():
     _model_fixture(m, unet.equiunet_state_shapes, 8, (16, 16, 16), "equiunet_w8_16_elu.npz", 1)
 
 
+def equiunet_bcn_fixture():
+    """--norm bcn (BCNorm(C, 8, estimate=True) = EstBN + per-(sample, group) normalisation + per-group affine,
+    networks/factory.py:125-176,189-190) with non-trivial running buffers (as after loading a checkpoint)."""
+    import functools
+    m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="bcn", act="relu", deep_supervision=True, dropout=0)
+    _model_fixture(m, functools.partial(unet.equiunet_state_shapes, norm="bcn"), 8, (16, 16, 16), "equiunet_w8_16_bcn.npz", 1)
+
+
 def equiunet_instance_fixture():
     """--norm instance is the CLI default (src/arguments_train.py:48): InstanceNorm3d(affine=True)."""
     m = EquiUnet(4, 3, [8, 16, 32, 64], norm_layer="instance", act="relu", deep_supervision=True, dropout=0)
@@ -353,7 +361,7 @@ if __name__ == "__main__":
     m.get_tta = lambda t: t.Compose([t.OnAxes(axes=["zxy", "xyz"]), t.HorizontalFlip(),
                                      t.Rotate90(angles=[0, 90, 180, 270])])
     sys.modules["src_definer_tta"] = m
-    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance", "equiunet_elu", "equiunet_prelu", "equiunet_batch"]
+    which = sys.argv[1:] or ["equiunet", "assp", "ops", "inference", "post", "ranger", "prep", "equiunet_instance", "equiunet_elu", "equiunet_prelu", "equiunet_batch", "equiunet_bcn"]
     if "equiunet" in which:
         equiunet_fixtures()
     if "equiunet_instance" in which:
@@ -364,6 +372,8 @@ if __name__ == "__main__":
         equiunet_prelu_fixture()
     if "equiunet_batch" in which:
         equiunet_batch_fixture()
+    if "equiunet_bcn" in which:
+        equiunet_bcn_fixture()
     if "assp" in which:
         assp_fixture()
     if "ops" in which:

@@ -86,7 +86,17 @@ def test_state_dict_contract_and_factory_errors():
     with pytest.raises(NameError):
         get_model(argparse.Namespace(model="nnunet", **ns))
     with pytest.raises(NotImplementedError):
-        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "bcn"}))
+        get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "layer"}))
+    # --norm bcn (round 5): BCNorm + EstBN parameter / buffer names and order (networks/factory.py:125-160)
+    mc = get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "bcn"}))
+    shapes_c = unet.equiunet_state_shapes(8, norm="bcn")
+    assert list(mc.state_dict().keys()) == list(shapes_c.keys())
+    assert all(tuple(mc.state_dict()[k].shape) == tuple(v) for k, v in shapes_c.items())
+    # --dropout (round 5): constructs for p in [0, 1), no extra state-dict entry, bad values raise like nn.Dropout
+    md = get_model(argparse.Namespace(model="equiunet", **{**ns, "dropout": 0.1}))
+    assert md.dropout_p == 0.1 and list(md.state_dict().keys()) == list(shapes.keys())
+    with pytest.raises(ValueError):
+        get_model(argparse.Namespace(model="equiunet", **{**ns, "dropout": 1.0}))
     # --norm batch (round 4): nn.BatchNorm3d's parameter / buffer names and order
     mb = get_model(argparse.Namespace(model="equiunet", **{**ns, "norm": "batch"}))
     shapes_b = unet.equiunet_state_shapes(8, norm="batch")

@@ -249,6 +249,41 @@ def test_equiunet_prelu_oracle_matches_reference(golden_dir):
             np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=1e-6, rtol=1e-4)
 
 
+def test_equiunet_bcn_oracle_matches_reference(golden_dir):
+    """--norm bcn (BCNorm(C, 8, estimate=True): EstBN on its running buffers + per-(sample, group) normalisation + per-group
+    affine, networks/factory.py:125-176,189-190) against the reference's own outputs: state-dict keys and shapes, logits, deep
+    heads, loss, gradient norms (the parameters whose gradient is analytically zero -- EstBN's weight / bias where a group
+    holds ONE channel -- are noise of 1e-8 in the reference itself: absolute tolerance)."""
+    import functools
+    g = _load(golden_dir, "equiunet_w8_16_bcn.npz")
+    meta = json.loads(str(g["meta"]))
+    shapes = functools.partial(unet.equiunet_state_shapes, norm="bcn")(meta["width"])
+    assert list(shapes.keys()) == meta["keys"] and [list(v) for v in shapes.values()] == meta["shapes"]
+    buffers = ("running_mean", "running_var", "num_batches_tracked", "estbn_moving_speed")
+    sd = {k: (v if k.rsplit(".", 1)[-1] in buffers else v.requires_grad_(True)) for k, v in synth.fill_state_dict(shapes).items()}
+    size = tuple(meta["size"])
+    x, t = synth.closed_form_image(1, 4, size), synth.nested_spheres(1, size)
+    out = unet.equiunet_forward(sd, x, norm="bcn")
+    loss = unet.deep_supervision_loss(out, t)
+    loss.backward()
+    np.testing.assert_allclose(out[0].detach().numpy(), g["logits"], atol=TOL, rtol=0)
+    for i, d in enumerate(out[1]):
+        np.testing.assert_allclose(d.detach().numpy()[:, :, ::2, ::2, ::2], g[f"deep{i}"], atol=TOL, rtol=0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    names = json.loads(str(g["grad_names"]))
+    assert sum(n.endswith(".bn.bn.weight") for n in names) == 17 and sum(n.endswith(".bn.weight") for n in names) == 34
+    norms = np.array([float(sd[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=2e-8)
+    for k in g.files:
+        if k.startswith("grad:") and ".bn." in k:
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], atol=1e-6 * max(1.0, float(np.abs(g[k]).max()) * 1e3), rtol=1e-3)
+    # a moving EstBN is refused, not silently frozen
+    sd2 = dict(sd)
+    sd2["encoder1.ConvBnRelu1.bn.bn.estbn_moving_speed"] = torch.full((1,), 0.1)
+    with pytest.raises(NotImplementedError):
+        unet.equiunet_forward(sd2, x, norm="bcn")
+
+
 def test_equiunet_batch_norm_oracle_matches_reference(golden_dir):
     """--norm batch (nn.BatchNorm3d, networks/factory.py:185-186): training-mode step on two patches (logits, loss, gradients,
     updated running buffers) and the eval-mode forward on those buffers, against the reference's own outputs."""
