@@ -176,6 +176,23 @@ class _PackedWeightsModule(nn.Module):
             ops.invalidate_packed_weights()
         return super().train(mode)
 
+    def _init_dropout(self, p):
+        """--dropout p (src/arguments_train.py:52).  The masks come from this library's Philox stream (csrc/dropout.hip), seeded
+        from torch's CPU generator at construction (torch.manual_seed makes a run repeatable); the (seed, step counter) pair is a
+        non-persistent buffer: not part of the state dict, like torch's own RNG state."""
+        if not 0.0 <= float(p) < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+        self.dropout_p = float(p)
+        self.register_buffer("_dropout_state", torch.tensor([int(torch.randint(0, 2 ** 62, (1,))), 0], dtype=torch.int64), persistent=False)
+
+    def _advance_dropout(self, device):
+        """Next step's dropout state: the counter moves ON THE DEVICE (a captured step draws fresh masks at every replay); the
+        returned copy belongs to this forward / backward pair."""
+        if self._dropout_state.device != device:
+            raise BratsHipError("brats21_amd: module and input are on different devices")
+        self._dropout_state[1] += 1
+        return self._dropout_state.clone()
+
     def _weights_may_have_changed(self):
         if torch.is_grad_enabled():
             ops.invalidate_packed_weights()
@@ -653,8 +670,6 @@ class EquiUnet(_PackedWeightsModule):
             raise NotImplementedError("--norm batch with --act prelu is not implemented")
         if act not in ("relu", "leakyrelu", "elu", "prelu", "swish", "mish"):
             raise NotImplementedError(f"brats21_amd.EquiUnet implements --act relu|leakyrelu|elu|prelu|swish|mish (got {act!r})")
-        if not 0.0 <= float(dropout) < 1.0:
-            raise ValueError(f"dropout probability has to be in [0, 1), got {dropout}")
         if refinement:
             raise NotImplementedError("equiunet_ref (RefUnet) is outside the accelerated hot path")
         if inplanes != 4 or num_classes > 4 or any(c % 8 for c in features):
@@ -663,11 +678,8 @@ class EquiUnet(_PackedWeightsModule):
         self.deep_supervision = deep_supervision
         self.act = act
         self.features = list(features)
-        # nn.Dropout(p) behind every ConvBnRelu's activation (networks/equiunet2020.py:62; --dropout, src/arguments_train.py:52).
-        # The masks come from this library's Philox stream (csrc/dropout.hip), seeded from torch's CPU generator at construction
-        # (torch.manual_seed makes a run repeatable); not part of the state dict, like torch's own RNG state
-        self.dropout_p = float(dropout)
-        self.register_buffer("_dropout_state", torch.tensor([int(torch.randint(0, 2 ** 62, (1,))), 0], dtype=torch.int64), persistent=False)
+        # nn.Dropout(p) behind every ConvBnRelu's activation (networks/equiunet2020.py:62; --dropout, src/arguments_train.py:52)
+        self._init_dropout(dropout)
         # "auto" = follow torch.autocast; BRATS_PRECISION=x3 makes the split-precision parity mode the default of an unmodified
         # training script run with --no_amp
         self.precision = os.environ.get("BRATS_PRECISION", "auto")
@@ -726,14 +738,6 @@ class EquiUnet(_PackedWeightsModule):
             elif isinstance(mod, _NormParams) and norm_layer == "batch":  # factory.py:219-221: BatchNorm3d weights ~ N(1, 0.02)
                 nn.init.normal_(mod.weight.data, 1.0, 0.02)
                 nn.init.constant_(mod.bias.data, 0.0)
-
-    def _advance_dropout(self, device):
-        """Next step's dropout state: the counter moves ON THE DEVICE (a captured step draws fresh masks at every replay); the
-        returned copy belongs to this forward / backward pair."""
-        if self._dropout_state.device != device:
-            raise BratsHipError("brats21_amd.EquiUnet: module and input are on different devices")
-        self._dropout_state[1] += 1
-        return self._dropout_state.clone()
 
     def _dtype(self):
         if self.precision == "bf16":

@@ -87,6 +87,15 @@ class _Ctx:
         self.slots = None
         self.names = {p: i for i, p in enumerate(model.parameters())}
         self.grads = {}
+        # nn.Dropout(p) behind every EvoNorm but the ASPP's (networks/equiunet2021.py:200,203,219; :178 pins the ASPP's to 0),
+        # training mode only: (p, state) with state = (seed, step counter) on the device; None = off
+        self.drop = None
+
+    def dropped(self, t, uid, out=None):
+        """t * keep / (1 - p) with unit uid's mask of this step (forward: in place on the activation; backward: on the gradient)."""
+        if self.drop is None or uid is None:
+            return t
+        return ops.dropout(t, self.drop[0], self.drop[1], uid, out=out)
 
     def slot(self, device, force=False):
         if not self.fp8 and not force:
@@ -195,7 +204,8 @@ def _aspp_bwd(cx, aspp, x, d_acat):
     return dx
 
 
-def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
+def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False, uid=None):
+    """uid: the unit's dropout stream (None: no dropout behind this EvoNorm)."""
     y, stats, saved = _conv_any_fwd(cx, conv, x, 1, True)
     n, d, h, w, c = y.shape
     mr, chan = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
@@ -203,11 +213,13 @@ def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False):
     z, cs = ops.evonorm(y, mr, _flat(evo.gamma), _flat(evo.beta), 8, out=out, want_chansum=want_chansum, amax=amax)
     if amax is not None:
         z._amax = amax
-    return z, cs, (conv, evo, saved, y, mr, chan)
+    cx.dropped(z, uid, out=z)
+    return z, cs, (conv, evo, saved, y, mr, chan, uid)
 
 
 def _conv_evo_bwd(cx, rec, dz, need_dx=True, gscale=None, gadd=None):
-    conv, evo, saved, y, mr, chan = rec
+    conv, evo, saved, y, mr, chan, uid = rec
+    dz = cx.dropped(dz, uid)
     amax = cx.slot(y.device, cx.x3s) if (cx.fp8 == "all" or cx.x3s) else None  # scale source of the e4m3 / fp16-pair gradients
     dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax, gscale=gscale, gadd=gadd)
     if amax is not None:
@@ -221,7 +233,22 @@ def _block_fwd(cx, blk, x, out=None, head=None):
     """head: the 1x1x1 output head module when the block's output feeds nothing else -- the block then returns the head's
     logits instead of its output tensor, which is recomputed on load inside the head kernel and never stored."""
     s = blk.conv_conv_se
-    z1, _, r1 = _conv_evo_fwd(cx, s[0], s[1], x)
+    uid = cx.m._unit_ids[blk] if cx.drop is not None else None
+    z1, _, r1 = _conv_evo_fwd(cx, s[0], s[1], x, uid=uid)
+    if cx.drop is not None:
+        # dropout between the second EvoNorm and the SE layer (networks/equiunet2021.py:201-205): the fused EvoNorm + SE forms derive
+        # the layer's global average from sums of the UN-dropped values, so the three steps run one by one on a stored z2
+        conv, evo = s[3], s[4]
+        y, stats, saved = _conv_any_fwd(cx, conv, z1, 1, True)
+        n, d, h, w, c = y.shape
+        mr, chan = ops.evonorm_finalize(stats, n, c, 8, d * h * w)
+        z2, _ = ops.evonorm(y, mr, _flat(evo.gamma), _flat(evo.beta), 8)
+        cx.dropped(z2, uid + 1, out=z2)
+        fc1, fc2 = s[6].fc[0], s[6].fc[2]
+        cs = ops.channel_dot(z2)
+        gate1p, hidden = ops.se_gate(cs, d * h * w, fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+        o = ops.channel_scale(z2, gate1p, out=out)
+        return o, (blk, r1, (conv, evo, saved, y, mr, chan), cs, hidden, gate1p, z2)
     # second conv + EvoNorm + ResidualSELayer (out = z2 + z2 * sigmoid(W2 relu(W1 gap + b1) + b2)) as one call: a statistics
     # pass over y, the gate (csrc/se.hip), then the EvoNorm pass writes z2 * (1 + gate) -- z2 itself is never stored
     conv, evo = s[3], s[4]
@@ -246,9 +273,25 @@ def _block_fwd(cx, blk, x, out=None, head=None):
 def _block_bwd(cx, rec, do, need_dx=True, head=None, pool=None):
     """head = (head module, dlogits) instead of `do`: the block's output feeds only the 1x1x1 output head, whose backward is
     folded into the same call (d(up1) is never written)."""
-    blk, r1, r2, cs, hidden, gate1p = rec
-    s = blk.conv_conv_se
+    s = rec[0].conv_conv_se
     fc1, fc2 = s[6].fc[0], s[6].fc[2]
+    if len(rec) == 7:  # the dropout form of _block_fwd: SE backward, dropout, EvoNorm backward one by one
+        blk, r1, r2, cs, hidden, gate1p, z2 = rec
+        conv, evo, saved, y, mr, chan = r2
+        uid = cx.m._unit_ids[blk]
+        n, d, h, w, c = y.shape
+        dgate = ops.channel_dot(do, z2)  # out = z2 * (1 + gate): d loss / d gate = sum_v do * z2
+        gadd, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, cs, d * h * w, hidden, gate1p, fc1.weight, fc2.weight)
+        dz2 = cx.dropped(ops.channel_scale(do, gate1p, add=gadd), uid + 1)
+        amax = cx.slot(y.device, cx.x3s) if cx.x3s else None
+        dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz2, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax)
+        if amax is not None:
+            dy._amax = amax
+        for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2), (evo.gamma, dgamma), (evo.beta, dbeta)):
+            cx.put(prm, g)
+        dz1 = _conv_any_bwd(cx, conv, saved, dy, True, db=dcb)
+        return _conv_evo_bwd(cx, r1, dz1, need_dx)
+    blk, r1, r2, cs, hidden, gate1p = rec
     # one call: pass 1 of the EvoNorm backward over (do, y) also yields d loss / d gate = sum_v do * z2 (linear in its sums),
     # the SE backward runs on those, pass 2 reads the gradient as do * (1 + gate) + dgap / V  (csrc/se.hpp)
     conv, evo, saved, y, mr, chan = r2
@@ -286,6 +329,13 @@ class _AsspFn(torch.autograd.Function):
         m = model
         f = m.features
         cx = _Ctx(m, dtype)
+        if m.training and m.dropout_p > 0.0:
+            if cx.fp8:
+                raise NotImplementedError("--dropout > 0 with the e4m3 convolution path is not implemented")
+            cx.drop = (m.dropout_p, m._advance_dropout(x.device))
+
+        def uid(mod):  # dropout stream of a ConvEvo unit (the ASPP's has p = 0: networks/equiunet2021.py:178)
+            return m._unit_ids[mod] if cx.drop is not None else None
         n, _, d, h, w = x.shape
         dev = x.device
         h0, h1, h2 = f[0] // 2, f[1] // 2, f[2] // 2
@@ -315,24 +365,24 @@ class _AsspFn(torch.autograd.Function):
         cat1 = ops.new_act(n, d, h, w, 2 * h0, dtype, dev)
         cat2 = ops.new_act(n, d // 2, h // 2, w // 2, 2 * h1, dtype, dev)
         cat3 = ops.new_act(n, d // 4, h // 4, w // 4, 2 * h2, dtype, dev)
-        br1, _, rbr1 = _conv_evo_fwd(cx, m.bridge1.conv, m.bridge1.evo, down1, out=cat1[..., :h0])
-        br2, _, rbr2 = _conv_evo_fwd(cx, m.bridge2.conv, m.bridge2.evo, down2, out=cat2[..., :h1])
-        br3, _, rbr3 = _conv_evo_fwd(cx, m.bridge3.conv, m.bridge3.evo, down3, out=cat3[..., :h2])
-        uc3, _, ru3 = _conv_evo_fwd(cx, m.upconv3.conv, m.upconv3.evo, assp)
+        br1, _, rbr1 = _conv_evo_fwd(cx, m.bridge1.conv, m.bridge1.evo, down1, out=cat1[..., :h0], uid=uid(m.bridge1))
+        br2, _, rbr2 = _conv_evo_fwd(cx, m.bridge2.conv, m.bridge2.evo, down2, out=cat2[..., :h1], uid=uid(m.bridge2))
+        br3, _, rbr3 = _conv_evo_fwd(cx, m.bridge3.conv, m.bridge3.evo, down3, out=cat3[..., :h2], uid=uid(m.bridge3))
+        uc3, _, ru3 = _conv_evo_fwd(cx, m.upconv3.conv, m.upconv3.evo, assp, uid=uid(m.upconv3))
         ops.upsample(uc3, 2, out=cat3[..., h2:])
         cat_amax(cat3, br3, uc3)
         up3, rd3 = _block_fwd(cx, m.decoder3, cat3)
-        uc2, _, ru2 = _conv_evo_fwd(cx, m.upconv2.conv, m.upconv2.evo, up3)
+        uc2, _, ru2 = _conv_evo_fwd(cx, m.upconv2.conv, m.upconv2.evo, up3, uid=uid(m.upconv2))
         ops.upsample(uc2, 2, out=cat2[..., h1:])
         cat_amax(cat2, br2, uc2)
         up2, rd2 = _block_fwd(cx, m.decoder2, cat2)
-        uc1, _, ru1 = _conv_evo_fwd(cx, m.upconv1.conv, m.upconv1.evo, up2)
+        uc1, _, ru1 = _conv_evo_fwd(cx, m.upconv1.conv, m.upconv1.evo, up2, uid=uid(m.upconv1))
         ops.upsample(uc1, 2, out=cat1[..., h0:])
         cat_amax(cat1, br1, uc1)
         # decoder1's output feeds only the output head: where the kernels for it are built the head recomputes it on load
         # (ops.evonorm_head) and the backward folds the head in (ops.evonorm_se_bwd(head=...)) -- up1 is never stored
         nk = m.out_conv.weight.shape[0]
-        fuse_top = m.fold_head_fwd and nk <= 4 and (not will_bwd or (m.fold_head_bwd and nk == 3))
+        fuse_top = m.fold_head_fwd and cx.drop is None and nk <= 4 and (not will_bwd or (m.fold_head_bwd and nk == 3))
         if fuse_top:
             logits, rd1 = _block_fwd(cx, m.decoder1, cat1, head=m.out_conv)
             up1 = None
@@ -369,7 +419,7 @@ class _AsspFn(torch.autograd.Function):
                 dout = torch.zeros((ctx.out_shape), dtype=torch.float32, device=douts_device(douts))
             if dout is None:
                 continue
-            if hd is m.out_conv and (ctx.top_fused or (m.fold_head_bwd and hd.weight.shape[0] == 3)):
+            if hd is m.out_conv and (ctx.top_fused or (m.fold_head_bwd and cx.drop is None and hd.weight.shape[0] == 3)):
                 top = (hd, dout)
                 continue
             dx, dw, db = ops.head_bwd(src, hd.weight, dout, sc)
@@ -393,7 +443,7 @@ class _AsspFn(torch.autograd.Function):
             """Backward of an encoder block: its output gradient = d_skip (bridge) + MaxAvgPool backward(d_pooled), composed
             inside the block's EvoNorm / SE backward where the pooling forward recorded its arg-max bytes."""
             idx = getattr(down, "_pool_argmax", None)
-            if idx is not None and m.fold_pool_bwd:
+            if idx is not None and m.fold_pool_bwd and cx.drop is None:
                 return _block_bwd(cx, rec, None, need_dx, pool=(d_skip, d_pooled, idx, True))
             return _block_bwd(cx, rec, ops.maxpool2_bwd(down, d_pooled, dx_skip=d_skip, with_avg=True), need_dx)
 
@@ -415,8 +465,6 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
                  refinement=False):
         super().__init__()
         warnings.warn("norm layer and activation specified will not be used ! only EVO !!")
-        if dropout:
-            raise NotImplementedError("dropout > 0 is not implemented (the published configs use 0)")
         if refinement:
             raise NotImplementedError("equiunet_assp_evo_ref raises AttributeError in the reference too (SURVEY App. B)")
         if inplanes != 4 or num_classes > 4 or any(c % 16 for c in features):
@@ -460,6 +508,16 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
             self.deep3 = nn.ModuleList([_ConvParams(f[2], num_classes, 1, bias=True)])
             self.deep2 = nn.ModuleList([_ConvParams(f[1], num_classes, 1, bias=True)])
         # (the reference leaves torch's default init here: init_weights is commented out, :287)
+        # --dropout p: nn.Dropout behind both EvoNorms of a block and behind every ConvEvo's but the ASPP's (networks/equiunet2021.py:
+        # 200,203,219; :178).  Dropout streams: a block owns ids (u, u + 1), a ConvEvo one id.
+        self._init_dropout(dropout)
+        ids, nxt = {}, 0
+        for mod in self.modules():
+            if isinstance(mod, ConvEvoBlockCorrected):
+                ids[mod], nxt = nxt, nxt + 2
+            elif isinstance(mod, ConvEvo):
+                ids[mod], nxt = nxt, nxt + 1
+        self._unit_ids = ids
 
     def _dtype(self):
         if self.precision == "bf16":

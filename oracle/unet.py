@@ -202,20 +202,26 @@ def residual_se(sd, pre, x):
     return x + x * y[:, :, None, None, None]
 
 
-def conv_evo_block(sd, pre, x):
-    """ConvEvoBlockCorrected, networks/equiunet2021.py:192-209 (Sequential indices 0,1,3,4,6)."""
+def conv_evo_block(sd, pre, x, drop=None):
+    """ConvEvoBlockCorrected, networks/equiunet2021.py:192-209 (Sequential indices 0,1,3,4,6; 2 and 5 = nn.Dropout(p)).
+    drop: {key: multiplier keep / (1 - p)} with keys pre + ".2" / pre + ".5" (the oracle is pure: the caller supplies the masks)."""
     p = pre + ".conv_conv_se"
     x = F.conv3d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], 1, 1)
     x = evonorm_s0(x, sd[p + ".1.gamma"], sd[p + ".1.beta"])
+    if drop is not None:
+        x = x * drop[pre + ".2"]
     x = F.conv3d(x, sd[p + ".3.weight"], sd[p + ".3.bias"], 1, 1)
     x = evonorm_s0(x, sd[p + ".4.gamma"], sd[p + ".4.beta"])
+    if drop is not None:
+        x = x * drop[pre + ".5"]
     return residual_se(sd, p + ".6", x)
 
 
-def conv_evo(sd, pre, x):
-    """ConvEvo (1x1x1 conv + bias -> EvoNorm), networks/equiunet2021.py:212-222."""
+def conv_evo(sd, pre, x, drop=None):
+    """ConvEvo (1x1x1 conv + bias -> EvoNorm -> nn.Dropout(p)), networks/equiunet2021.py:212-222; drop: {pre: multiplier}."""
     x = F.conv3d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"])
-    return evonorm_s0(x, sd[pre + ".evo.gamma"], sd[pre + ".evo.beta"])
+    x = evonorm_s0(x, sd[pre + ".evo.gamma"], sd[pre + ".evo.beta"])
+    return x if drop is None else x * drop[pre]
 
 
 def max_avg_pool(x):
@@ -232,19 +238,21 @@ def aspp(sd, pre, x, dilations=(1, 2, 4, 6), kernels=(1, 3, 3, 3)):
     return conv_evo(sd, pre + ".conv_k1", torch.cat(outs, 1))
 
 
-def assp_evo_forward(sd, x, deep_supervision=True):
-    """EquiUnetASSPEvo.forward, networks/equiunet2021.py:289-333. Returns (logits, [2 deeps])."""
-    down1 = conv_evo_block(sd, "encoder1", x)
-    down2 = conv_evo_block(sd, "encoder2", max_avg_pool(down1))
-    down3 = conv_evo_block(sd, "encoder3", max_avg_pool(down2))
-    down4 = conv_evo_block(sd, "encoder4", max_avg_pool(down3))
+def assp_evo_forward(sd, x, deep_supervision=True, drop=None):
+    """EquiUnetASSPEvo.forward, networks/equiunet2021.py:289-333. Returns (logits, [2 deeps]).
+    drop (training with --dropout p): the multipliers keep / (1 - p) of every nn.Dropout but the ASPP's, whose p is pinned to 0
+    (:178): {"<block>.2", "<block>.5", "<bridge | upconv>": tensor}."""
+    down1 = conv_evo_block(sd, "encoder1", x, drop)
+    down2 = conv_evo_block(sd, "encoder2", max_avg_pool(down1), drop)
+    down3 = conv_evo_block(sd, "encoder3", max_avg_pool(down2), drop)
+    down4 = conv_evo_block(sd, "encoder4", max_avg_pool(down3), drop)
     a = aspp(sd, "aspp", down4)
-    down1b = conv_evo(sd, "bridge1", down1)
-    down2b = conv_evo(sd, "bridge2", down2)
-    down3b = conv_evo(sd, "bridge3", down3)
-    up3 = conv_evo_block(sd, "decoder3", torch.cat([down3b, _up(conv_evo(sd, "upconv3", a), 2)], 1))
-    up2 = conv_evo_block(sd, "decoder2", torch.cat([down2b, _up(conv_evo(sd, "upconv2", up3), 2)], 1))
-    up1 = conv_evo_block(sd, "decoder1", torch.cat([down1b, _up(conv_evo(sd, "upconv1", up2), 2)], 1))
+    down1b = conv_evo(sd, "bridge1", down1, drop)
+    down2b = conv_evo(sd, "bridge2", down2, drop)
+    down3b = conv_evo(sd, "bridge3", down3, drop)
+    up3 = conv_evo_block(sd, "decoder3", torch.cat([down3b, _up(conv_evo(sd, "upconv3", a, drop), 2)], 1), drop)
+    up2 = conv_evo_block(sd, "decoder2", torch.cat([down2b, _up(conv_evo(sd, "upconv2", up3, drop), 2)], 1), drop)
+    up1 = conv_evo_block(sd, "decoder1", torch.cat([down1b, _up(conv_evo(sd, "upconv1", up2, drop), 2)], 1), drop)
     out = _c1(sd, "out_conv", up1)
     if not deep_supervision:
         return out

@@ -424,3 +424,69 @@ def test_conv_evo_block_matches_reference_golden(golden_dir):
     cx = ea._Ctx(_M(blk), torch.float32)
     y, _ = ea._block_fwd(cx, blk, _to_ndhwc(x))
     np.testing.assert_allclose(_from_ndhwc(y).numpy(), gold["block_y"], atol=1e-4)
+
+
+def test_dropout_network_matches_oracle_given_the_masks():
+    """--dropout p > 0 for EquiUnetASSPEvo (nn.Dropout behind both EvoNorms of every block -- the second one BEFORE the SE layer --
+    and behind every ConvEvo's but the ASPP's: networks/equiunet2021.py:200,203,219; :178): the masks of a training forward are
+    re-drawn from the model's (seed, step) state and handed to the CPU oracle; logits, loss and every parameter gradient agree
+    at the f32 bars.  The fused EvoNorm + SE forms (which would average UN-dropped values) are off; eval mode ignores p."""
+    import argparse, contextlib, io, os, warnings
+    from brats21_amd import get_model, ops
+    dev = torch.device("cuda:0")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    p, size, width = 0.2, (16, 16, 16), 16
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = get_model(argparse.Namespace(model="equiunet_assp_evo", width=width, norm="group", act="relu", num_classes=3, dropout=p))
+    m.precision = "fp32"
+    m = m.to(dev).train()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x, t = synth.random_image(2, 4, size, seed=3), synth.nested_spheres(2, size)
+    out, deeps = m(x.to(dev))
+    loss = unet.deep_supervision_loss((out, deeps), t.to(dev))
+    loss.backward()
+    state = m._dropout_state.clone()
+    names = {mod: k for k, mod in m.named_modules() if mod in m._unit_ids}
+    f = [width * 2 ** i for i in range(4)]
+    level = {"encoder1": (1, f[0]), "encoder2": (2, f[1]), "encoder3": (4, f[2]), "encoder4": (8, f[3]), "decoder3": (4, f[2]),
+             "decoder2": (2, f[1]), "decoder1": (1, f[0]), "bridge1": (1, f[0] // 2), "bridge2": (2, f[1] // 2), "bridge3": (4, f[2] // 2),
+             "upconv3": (8, f[3] // 4), "upconv2": (4, f[2] // 4), "upconv1": (2, f[1] // 4)}
+    drop = {}
+
+    def mask(name, uid):
+        sc, c = level[name]
+        ones = torch.ones(2, *(s // sc for s in size), c, device=dev)
+        return ops.dropout(ones, p, state, uid).permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+    for mod, uid in m._unit_ids.items():
+        name = names[mod]
+        if name.startswith("aspp"):
+            continue  # (its dropout probability is pinned to 0 in the reference)
+        if name in ("bridge1", "bridge2", "bridge3", "upconv1", "upconv2", "upconv3"):
+            drop[name] = mask(name, uid)
+        else:
+            drop[name + ".2"], drop[name + ".5"] = mask(name, uid), mask(name, uid + 1)
+    assert len(drop) == 7 * 2 + 6
+    sd_ref = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    out_ref = unet.assp_evo_forward(sd_ref, x, drop=drop)
+    loss_ref = unet.deep_supervision_loss(out_ref, t)
+    loss_ref.backward()
+    err = float((out.detach().cpu() - out_ref[0].detach()).abs().max())
+    worst = ("", 0.0)
+    for k, q in m.named_parameters():
+        if k.endswith(".v"):
+            assert q.grad is None
+            continue
+        rel = float((q.grad.cpu() - sd_ref[k].grad).norm() / (sd_ref[k].grad.norm() + 1e-12))
+        worst = max(worst, (k, rel), key=lambda e: e[1])
+    print(f"\nEquiUnetASSPEvo --dropout {p}: logits max abs err vs the oracle given the masks {err:.2e}, loss {loss.item():.6f} vs "
+          f"{loss_ref.item():.6f}, worst gradient rel err {worst[1]:.2e} ({worst[0]})")
+    assert err < 1e-3 and abs(loss.item() - loss_ref.item()) < 1e-4 and worst[1] < 5e-3
+    with torch.no_grad():
+        out2 = m(x.to(dev))[0]
+        assert int(m._dropout_state[1]) == 2 and not torch.equal(out2, out.detach())
+        m.eval()
+        e1, e2 = m(x.to(dev))[0], m(x.to(dev))[0]
+        assert torch.equal(e1, e2) and int(m._dropout_state[1]) == 2
