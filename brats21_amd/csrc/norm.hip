@@ -1791,6 +1791,179 @@ extern "C" int BRATS_API(brats_evonorm_bwd)(const void* dz, int dzpitch, const v
   return 0;
 }
 
+// ---- EvoNorm backward whose first pass was taken by the producer of dz (round 5; the EvoNorm analogue of brats_gn_act_bwd_tiles)
+// A block of EquiUnetASSPEvo is conv1 -> EvoNorm -> conv2 -> EvoNorm -> SE (networks/equiunet2021.py:197-206): dz, the gradient
+// of the first EvoNorm's output z, is produced by conv2's input-gradient launch and then read back twice (pass 1: sum dz,
+// sum dz * num(x), sum dz * num'(x); pass 2: dx).  num(x) = x * sigmoid(x) costs a transcendental per element -- nothing for a
+// convolution epilogue -- but z = num(x) * (rstd * gamma) + beta is LINEAR in it and z is in memory anyway (conv2's saved
+// input): the "backward statistics" form of the 16-bit convolutions (brats_conv3d_fwd_bstats with by = z, leakyrelu slope 1:
+// u = dz) leaves S1 = sum dz and S2 = sum dz * z per tile and channel, from which
+//     gamma_c * sum dz * num = (S2 - beta_c * S1) / rstd_g          (no division by gamma)
+// gives A_g, the only pass-1 quantity pass 2 needs.  The two sums that are NOT linear in z -- sum dz * num (for dgamma when
+// gamma_c = 0 exactly) and sum dz * num' (the convolution's bias gradient) -- are taken by pass 2 itself, which evaluates the
+// sigmoid per element anyway: two more FMAs per element and a block reduction.  dz and x are read once instead of twice.
+// red: brats_evonorm_bwd_tiles_ws_floats(N, C) floats.
+constexpr int EVO_SIDE_MAX_BLOCKS = 2048;
+extern "C" size_t BRATS_API(brats_evonorm_bwd_tiles_ws_floats)(int N, int C) {
+  // [N][C][2] (S1, gamma * sum dz * num) + side totals [N][C][2] + side partials [blocks][N][C][2] + f64 slab partials of the tiles
+  return (size_t)N * C * 4 + (size_t)EVO_SIDE_MAX_BLOCKS * N * C * 2 + (size_t)2 * GN_MAX_SPLITS * N * C * 2 + 8;
+}
+
+// s12[n][c] = { S1, (S2 - beta_c * S1) / rstd_g } from the f64 slab sums of the tile statistics (fixed order)
+__global__ void __launch_bounds__(256) evonorm_bwd_tiles_prep_kernel(const double* __restrict__ part, int splits, int N, int C, int groups,
+                                                                     const float* __restrict__ mean_rstd, const float* __restrict__ beta,
+                                                                     float* __restrict__ s12) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s1 = 0.0, s2 = 0.0;
+  const double* src = part + ((size_t)n * C + c) * 2;
+  const size_t zs = (size_t)N * C * 2;
+  for (int z = 0; z < splits; ++z) { s1 += src[z * zs]; s2 += src[z * zs + 1]; }
+  const double rstd = mean_rstd[(n * groups + c / (C / groups)) * 2 + 1];
+  s12[(size_t)i * 2] = (float)s1;
+  s12[(size_t)i * 2 + 1] = (float)((s2 - (double)beta[c] * s1) / rstd);
+}
+
+// pass 2 alone: dx = dz * gamma * r * num'(x) - r^3 * A_g * (x - mean_g) / (M - 1), A_g = sum_{c in g} s12[n][c][1];
+// side partials [block][n][c] = { sum dz * num, sum dz * num' } over the block's voxels
+template <typename T, bool NT>
+__global__ void __launch_bounds__(256) evonorm_bwd_apply_side_kernel(const T* __restrict__ dz, int dzpitch, const T* __restrict__ x, int xpitch,
+                                                                     const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ s12, T* __restrict__ dx, int dxpitch,
+                                                                     float* __restrict__ side_part, int voxels, int C, int groups,
+                                                                     uint32_t* __restrict__ amax) {
+  constexpr int VW = 16 / sizeof(T);
+  extern __shared__ float sm[];  // [3][C] constants, then the reduction scratch [vl_n][C]
+  float* gr = sm;          // gamma * r
+  float* mu = sm + C;      // group mean
+  float* kk = sm + 2 * C;  // r^3 * A_g / (M - 1)
+  const int n = blockIdx.y, cpg = C / groups;
+  const float Mm1 = (float)cpg * (float)voxels - 1.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float r = mean_rstd[(n * groups + g) * 2 + 1];
+    float A = 0.f;
+    for (int j = 0; j < cpg; ++j) A += s12[((size_t)n * C + g * cpg + j) * 2 + 1];
+    gr[c] = gamma[c] * r;
+    mu[c] = mean_rstd[(n * groups + g) * 2];
+    kk[c] = r * r * r * A / Mm1;
+  }
+  __syncthreads();
+  const int cv = C / VW, vl_n = blockDim.x / cv;
+  const int mycv = threadIdx.x % cv, myvl = threadIdx.x / cv, c0 = mycv * VW;
+  const bool live = myvl < vl_n;
+  float cg[VW], cm[VW], ck[VW], a2[VW], a3[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) { cg[j] = gr[c0 + j]; cm[j] = mu[c0 + j]; ck[j] = kk[c0 + j]; a2[j] = a3[j] = 0.f; }
+  const T* dzb = dz + (size_t)n * voxels * dzpitch + c0;
+  const T* xb = x + (size_t)n * voxels * xpitch + c0;
+  T* dxb = dx + (size_t)n * voxels * dxpitch + c0;
+  float mx = 0.f;
+  auto body = [&](const float* g, const float* xx, float* o) {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const float sg = sigmoidf_(xx[j]);
+      const float num = xx[j] * sg, dnum = sg * (1.f + xx[j] * (1.f - sg));
+      a2[j] += g[j] * num;
+      a3[j] += g[j] * dnum;
+      o[j] = g[j] * cg[j] * dnum - ck[j] * (xx[j] - cm[j]);
+    }
+    if (amax) {
+#pragma unroll
+      for (int j = 0; j < VW; j += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(o[j])), __builtin_fabsf(o[j + 1]));
+    }
+  };
+  const size_t stride = (size_t)gridDim.x * vl_n;
+  size_t vox = live ? (size_t)blockIdx.x * vl_n + myvl : (size_t)voxels;
+  for (; vox + stride < (size_t)voxels; vox += 2 * stride) {
+    float g0[VW], x0[VW], g1[VW], x1[VW], o0[VW], o1[VW];
+    vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+    vload<T, VW, NT>(xb + vox * xpitch, x0);
+    vload<T, VW, NT>(dzb + (vox + stride) * dzpitch, g1);
+    vload<T, VW, NT>(xb + (vox + stride) * xpitch, x1);
+    body(g0, x0, o0);
+    body(g1, x1, o1);
+    vstore<T, VW, NT>(dxb + vox * dxpitch, o0);
+    vstore<T, VW, NT>(dxb + (vox + stride) * dxpitch, o1);
+  }
+  if (vox < (size_t)voxels) {
+    float g0[VW], x0[VW], o0[VW];
+    vload<T, VW, NT>(dzb + vox * dzpitch, g0);
+    vload<T, VW, NT>(xb + vox * xpitch, x0);
+    body(g0, x0, o0);
+    vstore<T, VW, NT>(dxb + vox * dxpitch, o0);
+  }
+  float* scr = sm + 3 * C;
+  float* part = side_part + ((size_t)blockIdx.x * gridDim.y + n) * C * 2;
+  lane_reduce_plane<VW>(scr, a2, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * 2] = t; });
+  lane_reduce_plane<VW>(scr, a3, live, myvl, vl_n, C, c0, [&](int c, float t) { part[c * 2 + 1] = t; });
+  if (amax) record_absmax<T>(mx, amax);
+}
+
+// dgamma, dbeta and the bias gradient of the convolution that produced x, from S1, A_g and the side totals
+__global__ void __launch_bounds__(256) evonorm_bwd_tiles_finish_kernel(const float* __restrict__ s12, const float* __restrict__ side,
+                                                                       const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+                                                                       const double* __restrict__ chan, float* __restrict__ dgamma,
+                                                                       float* __restrict__ dbeta, float* __restrict__ dconvbias, int N,
+                                                                       int voxels, int C, int groups) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int cpg = C / groups, gg = c / cpg;
+  const float Mm1 = (float)cpg * (float)voxels - 1.f;
+  float b = 0.f, g = 0.f, dbc = 0.f;
+  for (int m = 0; m < N; ++m) {
+    const float r = mean_rstd[(m * groups + gg) * 2 + 1], mean = mean_rstd[(m * groups + gg) * 2];
+    float A = 0.f;
+    for (int j = 0; j < cpg; ++j) A += s12[((size_t)m * C + gg * cpg + j) * 2 + 1];
+    b += s12[((size_t)m * C + c) * 2];
+    g += side[((size_t)m * C + c) * 2] * r;
+    const float sumx = chan ? (float)chan[((size_t)m * C + c) * 2] : 0.f;
+    dbc += gamma[c] * r * side[((size_t)m * C + c) * 2 + 1] - r * r * r * A / Mm1 * (sumx - (float)voxels * mean);
+  }
+  dbeta[c] = b;
+  dgamma[c] = g;
+  if (dconvbias) dconvbias[c] = dbc;
+}
+
+extern "C" int BRATS_API(brats_evonorm_bwd_tiles)(const float* tile_stats, int tiles_per_sample, const void* dz, int dzpitch, const void* x,
+                                       int xpitch, const float* mean_rstd, const float* gamma, const float* beta, void* dx, int dxpitch,
+                                       float* red, float* dgamma, float* dbeta, const double* chan_sums, float* dconvbias, int dtype,
+                                       int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
+  if (!tile_stats || !dz || !x || !dx || !red || !mean_rstd || !gamma || !beta || !dgamma || !dbeta || tiles_per_sample <= 0)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: null pointer");
+  if (dtype != BRATS_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "evonorm_bwd_tiles: 16-bit activations only (the producing convolution form is)");
+  if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: dconvbias needs the forward per-channel sums");
+  if (C % 8 || C % groups || dzpitch % 8 || xpitch % 8 || dxpitch % 8 || C / 8 > 256)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: C=%d / pitches must be multiples of 8", C);
+  hipStream_t st = (hipStream_t)s;
+  float* s12 = red;
+  float* side = red + (size_t)N * C * 2;
+  float* side_part = side + (size_t)N * C * 2;  // (brats_ordered_sum: the partials directly behind the totals)
+  double* part = (double*)(side_part + (((size_t)EVO_SIDE_MAX_BLOCKS * N * C * 2 + 1) / 2) * 2);
+  const int splits = gn_splits(tiles_per_sample);
+  hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, splits), dim3(256), 0, st, tile_stats, tiles_per_sample, C, part);
+  hipLaunchKernelGGL(evonorm_bwd_tiles_prep_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, splits, N, C, groups, mean_rstd, beta, s12);
+  const int cv = C / 8, vl = 256 / cv;
+  size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
+  const bool big = stream_nt((size_t)N * voxels * C * 2);
+  const size_t cap = big ? EVO_SIDE_MAX_BLOCKS : 512;
+  dim3 g2((unsigned)(gx < 1 ? 1 : (gx > cap ? cap : gx)), N);
+  const size_t lds2 = (size_t)(3 * C + vl * C) * sizeof(float);
+  if (big)
+    hipLaunchKernelGGL((evonorm_bwd_apply_side_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x, xpitch,
+                       mean_rstd, gamma, s12, (bf16_t*)dx, dxpitch, side_part, voxels, C, groups, (uint32_t*)amax);
+  else
+    hipLaunchKernelGGL((evonorm_bwd_apply_side_kernel<bf16_t, false>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x, xpitch,
+                       mean_rstd, gamma, s12, (bf16_t*)dx, dxpitch, side_part, voxels, C, groups, (uint32_t*)amax);
+  BRATS_CHECK_LAUNCH();
+  if (int rc = brats_ordered_sum(side_part, side, (int)g2.x, N * C * 2, st)) return rc;
+  hipLaunchKernelGGL(evonorm_bwd_tiles_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, s12, side, mean_rstd, gamma, chan_sums, dgamma,
+                     dbeta, dconvbias, N, voxels, C, groups);
+  BRATS_CHECK_LAUNCH();
+  return 0;
+}
+
 // EvoNorm backward of the layer a ResidualSELayer sits on, with the SE backward in the middle (se.hpp): pass 1 over (dout, x)
 // with the five raw sums -> brats_se_bwd_launch (d loss / d gate from the sums; gadd, the SE parameter gradients, the three
 // sums for dz = dout * gate1p + gadd) -> pass 2.  Replaces brats_channel_dot + brats_se_bwd + brats_evonorm_bwd(gscale, gadd):

@@ -104,6 +104,17 @@ class _Ctx:
             self.slots = _AmaxSlots(64, device)
         return self.slots.take()
 
+    def identity_ss(self, n, c, device):
+        """{scale, shift} = {1, 0} per (sample, channel): ops.conv3d_bstats' activation argument when there is no activation."""
+        key = (n, c)
+        if getattr(self, "_ss", None) is None:
+            self._ss = {}
+        if key not in self._ss:
+            ss = torch.zeros((n, c, 2), dtype=torch.float32, device=device)
+            ss[..., 0] = 1.0
+            self._ss[key] = ss
+        return self._ss[key]
+
     def dest(self, param):
         """The parameter's slice of a DDP all-reduce bucket (ddp.GradientBuckets.dest) for kernels that can write there."""
         d = getattr(self.m, "_grad_dest", None)
@@ -131,7 +142,10 @@ def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
     return y, stats, (x, dil)
 
 
-def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
+def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None, bstats=False):
+    """bstats: this is the SECOND convolution of a block, whose input xin is the first EvoNorm's output z1 -- where the kernel form
+    is built, the input-gradient launch also leaves (sum dz1, sum dz1 * z1) per tile and channel (ops.conv3d_bstats with the
+    identity "activation": leakyrelu, slope 1) and (dz1, tile sums) is returned for ops.evonorm_bwd_tiles."""
     xin, dil = saved
     w = conv.weight
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
@@ -156,8 +170,13 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None):
     if cx.fp8 == "all" and k == 3 and ops.conv_f8_chunk(cout) > 0:
         dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil, amax=getattr(dy, "_amax", None))
         return dx
-    dx, _ = ops.conv3d(dy, ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil), cin, k, dil,
-                       amax=getattr(dy, "_amax", None) if (cx.x3s and k == 3) else None)
+    wpk = ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil)
+    if (bstats and k == 3 and not cx.x3s and xin.shape[-1] == cin and xin.dtype == dy.dtype
+            and ops.conv_bstats_ok(cx.dtype, dil, cout, cin, "leakyrelu")):
+        n = dy.shape[0]
+        ss = cx.identity_ss(n, cin, dy.device)
+        return ops.conv3d_bstats(dy, wpk, cin, dil, xin, ss, "leakyrelu", slope=1.0)  # (dz1, tile sums)
+    dx, _ = ops.conv3d(dy, wpk, cin, k, dil, amax=getattr(dy, "_amax", None) if (cx.x3s and k == 3) else None)
     return dx
 
 
@@ -219,6 +238,15 @@ def _conv_evo_fwd(cx, conv, evo, x, out=None, want_chansum=False, uid=None):
 
 def _conv_evo_bwd(cx, rec, dz, need_dx=True, gscale=None, gadd=None):
     conv, evo, saved, y, mr, chan, uid = rec
+    if isinstance(dz, tuple):  # (dz, tile sums of the pass-1 quantities): _conv_any_bwd(bstats=True)
+        dz, tiles = dz
+        amax = cx.slot(y.device, cx.x3s) if (cx.fp8 == "all" or cx.x3s) else None
+        dy, dgamma, dbeta, dcb = ops.evonorm_bwd_tiles(tiles, dz, y, mr, _flat(evo.gamma), _flat(evo.beta), 8, chan=chan, amax=amax)
+        if amax is not None:
+            dy._amax = amax
+        cx.put(evo.gamma, dgamma)
+        cx.put(evo.beta, dbeta)
+        return _conv_any_bwd(cx, conv, saved, dy, need_dx, db=dcb)
     dz = cx.dropped(dz, uid)
     amax = cx.slot(y.device, cx.x3s) if (cx.fp8 == "all" or cx.x3s) else None  # scale source of the e4m3 / fp16-pair gradients
     dy, dgamma, dbeta, dcb = ops.evonorm_bwd(dz, y, mr, _flat(evo.gamma), 8, chan=chan, amax=amax, gscale=gscale, gadd=gadd)
@@ -306,7 +334,8 @@ def _block_bwd(cx, rec, do, need_dx=True, head=None, pool=None):
         dy._amax = amax
     for prm, g in ((fc1.weight, dw1), (fc1.bias, db1), (fc2.weight, dw2), (fc2.bias, db2), (evo.gamma, dgamma), (evo.beta, dbeta)):
         cx.put(prm, g)
-    dz1 = _conv_any_bwd(cx, conv, saved, dy, True, db=dcb)
+    # the first EvoNorm's backward statistics ride in this input-gradient launch where that kernel form is built (model.fold_bwd_stats)
+    dz1 = _conv_any_bwd(cx, conv, saved, dy, True, db=dcb, bstats=cx.m.fold_bwd_stats)
     return _conv_evo_bwd(cx, r1, dz1, need_dx)
 
 
@@ -483,6 +512,9 @@ class EquiUnetASSPEvo(_PackedWeightsModule):
         self.fold_head_bwd = os.environ.get("BRATS_FOLD_HEAD", "1") != "0"
         # the pooling backward + bridge-gradient add inside the block's EvoNorm / SE backward (brats_evonorm_se_bwd_pool)
         self.fold_pool_bwd = os.environ.get("BRATS_FOLD_POOL", "1") != "0"
+        # EvoNorm backward's first pass of a block's first unit inside the input-gradient launch of its second convolution
+        # (ops.conv3d_bstats on the stored EvoNorm output + ops.evonorm_bwd_tiles): dz1 and y1 are read once instead of twice
+        self.fold_bwd_stats = os.environ.get("BRATS_FOLD_BWD_STATS", "1") != "0"
         # ... and its forward on the last block's raw convolution output (brats_evonorm_head_fwd): up1 is never stored
         self.fold_head_fwd = os.environ.get("BRATS_FOLD_HEAD_FWD", os.environ.get("BRATS_FOLD_HEAD", "1")) != "0"
         self.skip_deep_heads_in_eval = False

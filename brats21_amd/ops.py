@@ -1037,6 +1037,25 @@ def evonorm_bwd(dz, y, mean_rstd, gamma, groups=8, chan=None, amax=None, gscale=
     return dy, dgamma, dbeta, dcb
 
 
+def evonorm_bwd_tiles(tile_stats, dz, y, mean_rstd, gamma, beta, groups=8, chan=None, amax=None):
+    """evonorm_bwd whose first pass was taken by conv3d_bstats(..., fwd_y = z, act="leakyrelu", slope=1.0) -- tile_stats = per tile
+    and channel (sum dz, sum dz * z) with z the EvoNorm's stored output (include/brats_hip.h: brats_evonorm_bwd_tiles).
+    -> (dy, dgamma, dbeta, dconvbias|None)."""
+    dzp, c, dzpitch = _desc(dz)
+    yp, _, ypitch = _desc(y)
+    n, d, h, w, _ = y.shape
+    dy = new_act(n, d, h, w, c, y.dtype, y.device)
+    red = torch.empty(_lib.lib().brats_evonorm_bwd_tiles_ws_floats(n, c), dtype=torch.float32, device=y.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    dcb = torch.empty(c, dtype=torch.float32, device=y.device) if chan is not None else None
+    _lib.check(_lib.lib().brats_evonorm_bwd_tiles(tile_stats.data_ptr(), tile_stats.shape[1], dzp, dzpitch, yp, ypitch, mean_rstd.data_ptr(),
+                                                  _f32(gamma), _f32(beta), dy.data_ptr(), c, red.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                  chan.data_ptr() if chan is not None else None, dcb.data_ptr() if dcb is not None else None,
+                                                  _code(y.dtype), n, d * h * w, c, groups, _f32(amax), _stream()), "evonorm_bwd_tiles")
+    return dy, dgamma, dbeta, dcb
+
+
 def channel_dot(a, b=None):
     """[N, C] f32 = sum over voxels of a (* b)."""
     ap, c, apitch = _desc(a)

@@ -324,6 +324,19 @@ int brats_evonorm_bwd(const void* dz, int dzpitch, const void* x, int xpitch, co
                       const float* gscale, const float* gadd /* optional [N][C]: dz is read as dz * gscale + gadd -- the
                       ResidualSELayer backward (out = z + z * gate) folded in instead of a separate channel_scale pass */,
                       brats_stream_t s);
+/* EvoNorm backward whose first pass was taken by the producer of dz (the EvoNorm analogue of brats_gn_act_bwd_tiles): the
+ * gradient dz of the first EvoNorm of a ConvEvoBlockCorrected (networks/equiunet2021.py:197-206) comes out of the second
+ * convolution's input-gradient launch, run as brats_conv3d_fwd_bstats with by = z (that EvoNorm's stored output), act =
+ * leakyrelu, slope 1 -- tile_stats [N][tiles][C][2] then holds sum dz and sum dz * z per tile and channel.  z is linear in
+ * num(x) = x * sigmoid(x), so these give pass 2 everything pass 1 (brats_evonorm_bwd's first kernel: a read of dz and x and a
+ * sigmoid per element) computed for it; the two sums that are not linear in z (for dgamma and dconvbias) are taken by pass 2
+ * itself.  Same outputs as brats_evonorm_bwd (without gscale / gadd), 16-bit activations only.
+ * red: brats_evonorm_bwd_tiles_ws_floats(N, C) floats. */
+size_t brats_evonorm_bwd_tiles_ws_floats(int N, int C);
+int brats_evonorm_bwd_tiles(const float* tile_stats, int tiles_per_sample, const void* dz, int dzpitch, const void* x,
+                            int xpitch, const float* mean_rstd, const float* gamma, const float* beta, void* dx, int dxpitch,
+                            float* red, float* dgamma, float* dbeta, const double* chan_sums, float* dconvbias, int dtype,
+                            int N, int voxels, int C, int groups, float* amax, brats_stream_t s);
 /* ---- squeeze-excite (MONAI ResidualSELayer(3, C, r = 2, relu, sigmoid), equiunet2021.py:204-205): per-(n,channel)
  * reductions over voxels, per-(n,channel) scale(+add) passes, and the gate itself (round 3: ONE launch forward, ONE launch
  * backward instead of ~20 ATen launches per block; up to 16 workgroups of 1024 threads, csrc/se.hip):

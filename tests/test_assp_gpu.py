@@ -490,3 +490,91 @@ def test_dropout_network_matches_oracle_given_the_masks():
         m.eval()
         e1, e2 = m(x.to(dev))[0], m(x.to(dev))[0]
         assert torch.equal(e1, e2) and int(m._dropout_state[1]) == 2
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_evonorm_backward_statistics_fold(precision):
+    """model.fold_bwd_stats for EquiUnetASSPEvo (round 5): the first EvoNorm's backward pass 1 rides in the input-gradient launch of
+    the block's second convolution -- brats_conv3d_fwd_bstats on the STORED EvoNorm output z (linear in x * sigmoid(x)) with the
+    identity activation, then brats_evonorm_bwd_tiles.  (i) kernel level: ops.evonorm_bwd_tiles on the tile sums == ops.evonorm_bwd
+    on the same dz (a gamma with an exact zero and a negative entry included); (ii) network level, width 48: all seven blocks
+    take the form, the forward is untouched, the gradients equal the two-pass form's up to the rounding of dz."""
+    import argparse, contextlib, copy, io, warnings
+    from brats21_amd import get_model, ops
+    from brats21_amd import synth as psynth
+    from brats21_amd.losses import DiceLoss
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    # ---- (i) kernel level
+    g = torch.Generator().manual_seed(4)
+    n, size, c = 2, (8, 16, 32), 48
+    x1 = torch.randn(n, *size, c, generator=g).to(dev).to(dt)              # conv1's raw output
+    dy2 = (torch.randn(n, *size, c, generator=g) * 0.1).to(dev).to(dt)     # gradient of conv2's raw output
+    w2 = (torch.randn(c, c, 3, 3, 3, generator=g) * 0.05).to(dev)
+    gamma = (1.0 + 0.3 * torch.randn(c, generator=g)).to(dev)
+    gamma[3], gamma[7] = 0.0, -0.8
+    beta = (0.2 * torch.randn(c, generator=g)).to(dev)
+    vox = size[0] * size[1] * size[2]
+    # EvoNorm's group statistics of x1 (unbiased variance over C/8 x D x H x W, networks/equiunet2021.py:48-52) and its channel sums, in f64
+    xf = x1.double()
+    mean = xf.view(n, -1, 8, c // 8).mean((1, 3))
+    var = xf.view(n, -1, 8, c // 8).var((1, 3), unbiased=True)
+    mr = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], -1).float().contiguous()
+    chan = torch.stack([xf.sum((1, 2, 3)), (xf * xf).sum((1, 2, 3))], -1).contiguous()
+    z1, _ = ops.evonorm(x1, mr, gamma, beta, 8)
+    wpk = ops.pack_weights(w2, dt, ops.PACK_DGRAD)
+    ss = torch.zeros(n, c, 2, device=dev); ss[..., 0] = 1.0
+    assert ops.conv_bstats_ok(dt, 1, c, c, "leakyrelu")
+    dz, tiles = ops.conv3d_bstats(dy2, wpk, c, 1, z1, ss, "leakyrelu", slope=1.0)
+    dz_plain, _ = ops.conv3d(dy2, wpk, c, 3, 1)
+    assert torch.equal(dz, dz_plain)
+    a = ops.evonorm_bwd_tiles(tiles, dz, x1, mr, gamma, beta, 8, chan=chan)
+    b = ops.evonorm_bwd(dz, x1, mr, gamma, 8, chan=chan)
+    for name, u, v, tol in (("dx", a[0].float(), b[0].float(), 2e-2), ("dgamma", a[1], b[1], 1e-2), ("dbeta", a[2], b[2], 1e-2), ("dconvbias", a[3], b[3], 1e-2)):
+        e = float((u - v).abs().max() / (v.abs().max() + 1e-12))
+        print(f"evonorm_bwd_tiles vs evonorm_bwd ({precision}) {name}: rel-to-max {e:.2e}")
+        assert e < tol, (name, e)
+    assert bool(torch.isfinite(a[1]).all()) and abs(float(a[1][3] - b[1][3])) <= 1e-2 * float(b[1].abs().max())  # gamma = 0: no division by it
+    # ---- (ii) network level
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        base = get_model(argparse.Namespace(model="equiunet_assp_evo", width=48, norm="group", act="relu", num_classes=3, dropout=0)).to(dev).train()
+    base.precision = precision
+    x = psynth.random_image(2, 4, (32, 32, 32), seed=7, device=dev)
+    t = psynth.nested_spheres(2, (32, 32, 32), device=dev)
+    crit = DiceLoss().to(dev)
+    calls = []
+    real = ops.conv3d_bstats
+
+    def counted(*a_, **k_):
+        calls.append(1)
+        return real(*a_, **k_)
+
+    def run(fold):
+        model = copy.deepcopy(base)
+        model.fold_bwd_stats = fold
+        out, deep = model(x)
+        loss = crit(out.float(), t) + sum(crit(d.float(), t) for d in deep)
+        loss.backward()
+        return out.detach(), [q.grad.detach().clone() if q.grad is not None else None for q in model.parameters()]
+
+    ops.conv3d_bstats = counted
+    try:
+        o1, g1 = run(True)
+        n_fused = len(calls)
+        o0, g0 = run(False)
+    finally:
+        ops.conv3d_bstats = real
+    assert n_fused == 7 and len(calls) == 7 and torch.equal(o1, o0)
+    tol = 4e-2 if precision == "bf16" else 1e-2
+    worst = 0.0
+    for (name, _), u, v in zip(base.named_parameters(), g1, g0):
+        assert (u is None) == (v is None), name
+        if u is None:
+            continue
+        assert bool(torch.isfinite(u).all()), name
+        e = float((u - v).abs().max()) / (float(v.abs().max()) + 1e-12)
+        worst = max(worst, e)
+        assert e <= tol, (name, e)
+    print(f"EquiUnetASSPEvo-48 fold_bwd_stats on / off ({precision}): worst gradient difference rel-to-max {worst:.2e} (bar {tol})")
