@@ -49,8 +49,9 @@ enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_EL
 
 /* THE version: brats_abi_version() returns this define, the Python binding (brats21_amd/_lib.py) and tests/test_abi_cpu.py parse
  * it.  History: 2 since round 3 (a changed signature, brats_maxpool2_fwd); 3 in round 4 (additions only); 4 in round 4 (the block
- * table of brats_conv3d_pack_weights_multi changed meaning). */
-#define BRATS_ABI_VERSION 4
+ * table of brats_conv3d_pack_weights_multi changed meaning); 5 in round 5 (additions only: brats_conv3d_set_x3_wgrad_fused,
+ * brats_dropout, brats_evonorm_bwd_tiles + its workspace query). */
+#define BRATS_ABI_VERSION 5
 int brats_abi_version(void);
 const char* brats_last_error(void);
 
