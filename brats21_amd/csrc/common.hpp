@@ -163,6 +163,23 @@ DEVI float x3_scale_from_amax(float amax) {
   return __uint_as_float(se << 23);
 }
 DEVI float x3_inv_scale(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }  // scale = 2^k -> 2^-k
+// x3 split of two f32 values: h = the packed 16-bit pair {rn16(x0), rn16(x1)}, l = {rn16(x0 - h.lo), rn16(x1 - h.hi)}.  x - rn16(x) is
+// exact in f32 (|x - h| <= ulp16 / 2), so  fma(h, -1, x)  IS the difference: in the fp16 build v_fma_mix_f32 takes the half straight
+// out of the packed register (one instruction instead of v_cvt_f32_f16 + v_sub_f32; 12 instead of 16 VALU instructions per four
+// values in the staging paths of conv_igemm_x3.hpp / conv_wgrad_x3.hpp, bit-identical results).
+DEVI void x3_split2(float x0, float x1, uint32_t& h, uint32_t& l) {
+  h = pack2(x0, x1);
+#if defined(BRATS_FP16) && defined(__HIP_DEVICE_COMPILE__)
+  float d0, d1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(h), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(h), "v"(x1));
+  l = pack2(d0, d1);
+#else
+  float h0, h1;
+  unpack2(h, h0, h1);
+  l = pack2(x0 - h0, x1 - h1);
+#endif
+}
 
 // ---- LDS-DMA (buffer_load ... lds) helpers shared by the weight-gradient and the loader-wave convolution kernels ----
 // a VGPR value the optimiser must treat as new: keeps per-tile address arithmetic from being hoisted out of the tile loop

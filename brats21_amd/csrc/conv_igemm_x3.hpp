@@ -27,10 +27,7 @@ DEVI void x3_split8(const u32x4 a, const u32x4 b, float sc, u32x4& hi, u32x4& lo
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float x0 = __uint_as_float(w[2 * i]) * sc, x1 = __uint_as_float(w[2 * i + 1]) * sc;
-    h[i] = pack2(x0, x1);
-    float h0, h1;
-    unpack2(h[i], h0, h1);
-    l[i] = pack2(x0 - h0, x1 - h1);
+    x3_split2(x0, x1, h[i], l[i]);
   }
   hi = u32x4{h[0], h[1], h[2], h[3]};
   lo = u32x4{l[0], l[1], l[2], l[3]};

@@ -1237,10 +1237,7 @@ __global__ void __launch_bounds__(256) x3_split_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float x0 = __uint_as_float(w[2 * e]) * sc, x1 = __uint_as_float(w[2 * e + 1]) * sc;
-      h[e] = pack2(x0, x1);
-      float h0, h1;
-      unpack2(h[e], h0, h1);
-      l[e] = pack2(x0 - h0, x1 - h1);
+      x3_split2(x0, x1, h[e], l[e]);
     }
     const size_t o = (i / cv) * C + (i % cv) * 8;
     __builtin_nontemporal_store(u32x4{h[0], h[1], h[2], h[3]}, (u32x4*)(hi + o));

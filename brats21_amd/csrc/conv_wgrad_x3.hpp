@@ -63,10 +63,7 @@ DEVI void x3_split4(const u32x4 a, float sc, u32x2& hi, u32x2& lo) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const float x0 = __uint_as_float(w[2 * i]) * sc, x1 = __uint_as_float(w[2 * i + 1]) * sc;
-    h[i] = pack2(x0, x1);
-    float h0, h1;
-    unpack2(h[i], h0, h1);
-    l[i] = pack2(x0 - h0, x1 - h1);
+    x3_split2(x0, x1, h[i], l[i]);
   }
   hi = u32x2{h[0], h[1]};
   lo = u32x2{l[0], l[1]};

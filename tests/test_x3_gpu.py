@@ -105,6 +105,7 @@ def test_conv3d_x3_fwd_dgrad_wgrad_vs_f64(cin, cin2, cout, dil, size):
     (48, 48, 48, (6, 8, 16)),     # decoder: two sources, each its own 48-channel ci block
     (96, 0, 96, (5, 6, 19)),      # ragged volume (every face cuts a half tile), 2 x 2 channel blocks
     (8, 0, 48, (8, 8, 16)),       # first layer: one 16-channel ci block of which 8 are real
+    (48, 0, 48, (20, 8, 16)),     # columns cut into two z-segments of 5 half tiles: the second one starts on an ODD tile (ring parity 1)
     (48, 0, 48, (32, 64, 64)),    # enough half tiles (2048) for the default switch: persistent workgroups walking 8 tiles each
 ])
 def test_conv3d_x3_wgrad_fused_vs_f64_and_vs_three_launch_form(cin, cin2, cout, size):
