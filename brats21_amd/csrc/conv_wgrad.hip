@@ -311,19 +311,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
 // the next tile's 87 KB are prefetched into registers (11 x 16 B per lane) during the MFMA phase.
 // CIF = ci fragments of the channel block: 3 (48 input channels) or 1 (the first layer: <= 16 input channels, 16-channel
 // LDS rows of which only the real ones are fetched)
-template <int CIF> struct Wg3 {
+// COF = co fragments of the block: 3 (48 output channels), or 4 for the FIRST layer of the width-64 networks (8 -> 64: round 5; the
+// dY voxel stride is then padded from 128 to 160 bytes, the next conflict-free value for the transposing reads)
+template <int CIF, int COF = 3> struct Wg3 {
   static constexpr int HZ = WG_TZ + 2, HY = WG_TY + 2, HX = WG_TX + 2, HVOX = HZ * HY * HX;
-  static constexpr int SX = CIF == 3 ? 96 : 32, SY = 96, XPPV = 2 * CIF, YPPV = 6;
+  static constexpr int CO = 16 * COF;
+  static constexpr int SX = CIF == 3 ? 96 : 32, SY = COF == 3 ? 96 : 160, XPPV = 2 * CIF, YPPV = 2 * COF;
   static constexpr int XPIECES = HVOX * XPPV, YPIECES = WG_VOX * YPPV;     // 3888 (1296), 1536 sixteen-byte pieces
-  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;     // 8 (3), 3 per thread
+  static constexpr int XI = (XPIECES + 511) / 512, YI = YPIECES / 512;     // 8 (3), 3 (4) per thread
   static constexpr int LDS_X = HVOX * SX, LDS = LDS_X + WG_VOX * SY;       // 62208 (20736) + 24576
   static constexpr int PAIRS = 27 * CIF, PPW = (PAIRS + 7) / 8;             // pair p -> wave p % 8
 };
 
-template <int CIF>
+template <int CIF, int COF = 3>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradParams p) {
   typedef bf16_t T;
-  using G = Wg3<CIF>;
+  using G = Wg3<CIF, COF>;
+  static_assert(COF == 3 || CIF == 1, "four co fragments: the first-layer form only");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldx = lds;
   char* ldy = lds + G::LDS_X;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
   const int split = blockIdx.x;
   const int tpx = (p.ntiles + p.nlane - 1) / p.nlane;
   const int tile_end = min(p.ntiles, (lane8 + 1) * tpx);
-  const int co0 = blockIdx.y * 48, ci0 = blockIdx.z * 16 * CIF;
+  const int co0 = blockIdx.y * G::CO, ci0 = blockIdx.z * 16 * CIF;
   const int ci_lim = (ci0 < p.c1 ? p.c1 : p.c1 + p.c2) - ci0;  // valid channels of this source in the block
   const T* xsrc;
   int xpitch;
@@ -366,11 +370,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     const int t = pid / CIF, nn = pid % CIF;
     poff[jj] = pid < G::PAIRS ? (((t / 9) * G::HY + (t / 3) % 3) * G::HX + t % 3) * G::SX + nn * 32 : 0;
   }
-  f32x4 acc[G::PPW][3];
+  f32x4 acc[G::PPW][COF];
 #pragma unroll
   for (int jj = 0; jj < G::PPW; ++jj)
 #pragma unroll
-    for (int m = 0; m < 3; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < COF; ++m) acc[jj][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 rx[G::XI], ry[G::YI];
   auto issue_loads = [&](int tile) {
@@ -423,7 +427,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     for (int i = 0; i < G::XI; ++i)
       if (tid + 512 * i < G::XPIECES) *(u32x4*)(ldx + (tid + 512 * i) * 16) = rx[i];
 #pragma unroll
-    for (int i = 0; i < G::YI; ++i) *(u32x4*)(ldy + (tid + 512 * i) * 16) = ry[i];
+    for (int i = 0; i < G::YI; ++i) {  // (piece P = (voxel, part): a padded voxel stride when COF = 4)
+      const int P = tid + 512 * i;
+      *(u32x4*)(ldy + (P / G::YPPV) * G::SY + (P % G::YPPV) * 16) = ry[i];
+    }
     __syncthreads();
     if (tile + g8 < tile_end) issue_loads(tile + g8);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch in front of the MFMA phase
@@ -432,12 +439,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
     const int ybase = (4 * q + qq) * G::SY + pp * 8;
     const int xbase = (4 * q + qq) * G::SX + pp * 8;
     constexpr int PD = 2;  // (3 in the tap-plane kernel; here the 256-register budget is full)
-    bf16x8 a[2][3], b[PD + 1];
+    bf16x8 a[2][COF], b[PD + 1];
     auto read_a = [&](auto s_) {
       constexpr int s = s_;
       const int yoff = ybase + (32 * s) * G::SY;
 #pragma unroll
-      for (int m = 0; m < 3; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
+      for (int m = 0; m < COF; ++m) a[s & 1][m] = tr_pair(ldy + yoff + m * 32, ldy + yoff + 16 * G::SY + m * 32);
     };
     auto read_b = [&](auto u_) {
       constexpr int u = u_;
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
       if constexpr (jj == 0 && s + 1 < 8) read_a(std::integral_constant<int, s + 1>{});
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+      for (int m = 0; m < COF; ++m)
         acc[jj][m] = MFMA16_16x16x32(a[s & 1][m], b[u % (PD + 1)], acc[jj][m]);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps_kernel(const WgradP
       const int ci = ci0 + nn * 16 + v;
       if (nn * 16 + v < ci_lim) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < COF; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
       }
@@ -1089,10 +1096,10 @@ static bool wgrad_alltaps_ok(int dtype, int dil, int c1, int c2, int cout, int n
   // block shape: 48 co x 48 ci, or 64 co x 32 ci for widths that are multiples of 64 but not of 48 (LDS-DMA form only)
   bool wide = false;
   if (cout % 48 || (!narrow && (c1 % 48 || (c2 > 0 && c2 % 48)))) {
-    if (narrow || cout % 64 || c1 % 32 || (c2 > 0 && c2 % 32)) return false;
-    wide = true;
+    if (cout % 64 || (!narrow && (c1 % 32 || (c2 > 0 && c2 % 32)))) return false;
+    wide = true;  // (narrow + wide: the first layer of a width-64 network, 64 co x 16 ci blocks)
   }
-  const int blocks = wide ? (cout / 64) * (cin / 32) : (cout / 48) * (narrow ? 1 : cin / 48);
+  const int blocks = wide ? (cout / 64) * (narrow ? 1 : cin / 32) : (cout / 48) * (narrow ? 1 : cin / 48);
   const int nl = wgrad_nlane(ntiles);
   int g8 = ceil_div(ncu, nl * blocks);
   if (g8 < 1) g8 = 1;
@@ -1184,6 +1191,8 @@ static int wgrad_mfma(const void* x1, int c1, int pitch1, const void* x2, int c2
     static std::atomic<uint64_t> attr_a{0}, attr_b{0}, attr_c{0}, attr_d{0};
     BRATS_ENSURE_LDS_ATTR(conv_wgrad_alltaps_kernel<3>, Wg3<3>::LDS, attr_a);
     BRATS_ENSURE_LDS_ATTR(conv_wgrad_alltaps_kernel<1>, Wg3<1>::LDS, attr_b);
+    static std::atomic<uint64_t> attr_e{0};
+    BRATS_ENSURE_LDS_ATTR((conv_wgrad_alltaps_kernel<1, 4>), (Wg3<1, 4>::LDS), attr_e);
     BRATS_ENSURE_LDS_ATTR((conv_wgrad_alltaps2_kernel<3, 3>), lds_48, attr_c);
     BRATS_ENSURE_LDS_ATTR((conv_wgrad_alltaps2_kernel<4, 2>), lds_wide, attr_d);
     static int form = -1;  // BRATS_WGRAD_ALLTAPS=1: the round-1 form (register staging, one X buffer) for same-box A/B runs
@@ -1191,7 +1200,9 @@ static int wgrad_mfma(const void* x1, int c1, int pitch1, const void* x2, int c2
       const char* e = getenv("BRATS_WGRAD_ALLTAPS");
       form = (e && atoi(e) == 1) ? 1 : 2;
     }
-    if (wide) {
+    if (wide && c2 <= 0 && c1 <= 16) {
+      hipLaunchKernelGGL((conv_wgrad_alltaps_kernel<1, 4>), dim3(p.nsplit, cout / 64, 1), dim3(512), (Wg3<1, 4>::LDS), st, p);
+    } else if (wide) {
       hipLaunchKernelGGL((conv_wgrad_alltaps2_kernel<4, 2>), dim3(p.nsplit, cout / 64, p.cin / 32), dim3(512), lds_wide, st, p);
     } else if (c2 <= 0 && c1 <= 16) {
       // the slab columns of the padded ci lanes (c1 < 16) are never written and never read (cin = c1)

@@ -380,6 +380,8 @@ def test_fused_dice_matches_torch_dice(jaccard):
     (8, 0, 48, 2, (64, 64, 64)),       # the first layer: one 16-channel ci block, 8 real channels
     (64, 0, 64, 2, (32, 32, 64)),      # width 64: 64 co x 32 ci blocks (LDS-DMA form only)
     (32, 32, 128, 3, (18, 30, 66)),    # ... over a 32 | 32 concat, ragged in z / y / x
+    (8, 0, 64, 2, (64, 64, 64)),       # the first layer of a width-64 network: 64 co x 16 ci blocks (round 5; 160-byte dY voxel stride)
+    (8, 0, 128, 3, (18, 30, 66)),      # ... two co blocks, ragged in z / y / x
 ])
 def test_conv3d_wgrad_alltaps_kernel_matches_tapplane_kernel(cin, cin2, cout, n, size):
     """The all-taps wgrad kernel (one 8-wave workgroup per CU, X tile with z halo staged once) against the tap-plane
