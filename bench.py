@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--fp8", default=None, choices=["fwd", "all"],
                     help="NOT the headline configuration: run the 3x3x3 convolutions forward (fwd) or forward + input "
                          "gradients (all) on the e4m3 MFMA kernel (BASELINE.json configs[4]); weight gradients stay bf16")
+    ap.add_argument("--dropout", type=float, default=0.0, help="NOT the headline configuration: --dropout p of the reference's CLI")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: every rank joins the process group (gloo on CPU), one all-reduce, rank 0 "
@@ -396,7 +397,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)  # identical random-init weights on every rank
-    ns = argparse.Namespace(model=args.model, width=args.width, norm="group", act="relu", num_classes=3, dropout=0)
+    ns = argparse.Namespace(model=args.model, width=args.width, norm="group", act="relu", num_classes=3, dropout=args.dropout)
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         model = get_model(ns).to(dev).train()
@@ -565,7 +566,8 @@ def main():
         "dtype": args.precision + (f"+e4m3 conv ({args.fp8})" if args.fp8 else ""), "data": "synthetic",
         "config": {"workload": f"{args.model} width={args.width}, batch={args.batch}/GPU of 4x{args.patch}^3 synthetic patches, "
                                f"fwd + deep-supervision Dice + bwd + {args.optimizer}" + (" as one hipGraph" if args.graph else "") +
-                               (" (BASELINE.json configs[1])" if (args.model, args.width, args.fp8) == ("equiunet", 48, None) else
+                               (f", dropout {args.dropout}" if args.dropout else "") +
+                               (" (BASELINE.json configs[1])" if (args.model, args.width, args.fp8, args.dropout) == ("equiunet", 48, None, 0.0) else
                                 " (BASELINE.json configs[2], per-GPU share)" if (args.model, args.width, args.fp8) == ("equiunet_assp_evo", 48, None) else
                                 f" (BASELINE.json configs[4], per-GPU share at {args.batch} patches, {args.precision} storage)" if (args.model, args.width) == ("equiunet_assp_evo", 64) and args.fp8 else ""),
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "loss": round(float(loss.item()), 5)},
@@ -582,7 +584,7 @@ def main():
                              "(tests/test_trained_gpu.py: networks trained on the GPU until the oracle's own Dice is ~0.98 -- bf16 |dDice| "
                              "<= 4.3e-4 on a fresh 128^3 patch, 3.4e-5 stitched over a configs[3] volume, fp16 <= 8.7e-5 / 6.8e-6; "
                              "profiles/r05_final_trained_weights_parity.txt) and at initialisation (tests/test_headline_gpu.py)")
-    if world == 1 and not args.no_other_configs and (args.model, args.width, args.precision, args.fp8, args.batch) == ("equiunet", 48, "bf16", None, 2) \
+    if world == 1 and not args.no_other_configs and (args.model, args.width, args.precision, args.fp8, args.batch, args.dropout) == ("equiunet", 48, "bf16", None, 2, 0.0) \
             and (args.patch == 128 or args.other_configs_patch):
         del train_step, opt
         model.zero_grad(set_to_none=True)

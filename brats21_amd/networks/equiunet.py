@@ -183,7 +183,9 @@ class _PackedWeightsModule(nn.Module):
         if not 0.0 <= float(p) < 1.0:
             raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
         self.dropout_p = float(p)
-        self.register_buffer("_dropout_state", torch.tensor([int(torch.randint(0, 2 ** 62, (1,))), 0], dtype=torch.int64), persistent=False)
+        # (data-parallel ranks build identical replicas under one torch seed: the rank is mixed in so that they draw different masks)
+        seed = (int(torch.randint(0, 2 ** 62, (1,))) + 0x9E3779B97F4A7C15 * int(os.environ.get("RANK", "0"))) % (2 ** 63)
+        self.register_buffer("_dropout_state", torch.tensor([seed, 0], dtype=torch.int64), persistent=False)
 
     def _advance_dropout(self, device):
         """Next step's dropout state: the counter moves ON THE DEVICE (a captured step draws fresh masks at every replay); the

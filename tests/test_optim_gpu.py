@@ -149,3 +149,30 @@ def test_graphed_train_step_follows_a_learning_rate_schedule():
     assert worst < 1e-5, worst
     # and the schedule mattered: a constant-lr run ends elsewhere
     assert lrs[0] != lrs[-1]
+
+
+def test_graphed_train_step_draws_fresh_dropout_masks_at_every_replay():
+    """--dropout p under GraphedTrainStep: the step counter of the mask generator lives on the device and is advanced INSIDE the
+    captured step, so every replay of the one hipGraph draws new masks.  With a vanishing learning rate the
+    weights do not move: the loss of consecutive replays on the same batch differs only through the masks."""
+    import argparse, contextlib, io
+    from brats21_amd import get_model, synth
+    from brats21_amd.engine import GraphedTrainStep, TrainStep
+    from brats21_amd.optim import Ranger2020
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = get_model(argparse.Namespace(model="equiunet", width=16, norm="group", act="relu", num_classes=3, dropout=0.3)).to(dev).train()
+        opt = Ranger2020(m.parameters(), lr=1e-12, capturable=True)
+    x = synth.random_image(2, 4, (32, 32, 32), seed=5, device=dev)
+    t = synth.nested_spheres(2, (32, 32, 32), device=dev)
+    step = GraphedTrainStep(TrainStep(m, opt, criterion=None, amp=True), warmup=2)
+    losses = [float(step(x, t)) for _ in range(6)]
+    c0 = int(m._dropout_state[1])
+    losses += [float(step(x, t)) for _ in range(3)]
+    assert int(m._dropout_state[1]) == c0 + 3          # the counter moves with the replays
+    assert len({round(v, 7) for v in losses[1:]}) >= 6  # ... and so do the masks
+    m.eval()
+    with torch.no_grad():
+        a, b = m(x)[0], m(x)[0]
+    assert torch.equal(a, b)
