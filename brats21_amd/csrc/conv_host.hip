@@ -284,7 +284,7 @@ static int conv_fwd_impl(const void* x1, int c1, int pitch1, const void* x2, int
   hipStream_t st = (hipStream_t)s;
   if (ksize == 1) dil = 1;
   if (pre.on) return conv_pre_launch(p, ck, dil, st);
-  if (bst.on) return conv_bst_launch(p, ck, dil, st);
+  if (bst.on) return dtype == BRATS_X3_BF16 ? conv_x3_bst_launch(p, ck, dil, st) : conv_bst_launch(p, ck, dil, st);
 #define GO(T) \
   if (ksize == 3 && dil == 1) return conv_launch<T, 3, 1>(p, ck, st); \
   if (ksize == 3 && dil == 2) return conv_launch<T, 3, 2>(p, ck, st); \
@@ -331,9 +331,10 @@ extern "C" int BRATS_API(brats_conv3d_fwd_pre)(const void* x1, int c1, int pitch
 }
 
 extern "C" int BRATS_API(brats_conv3d_bstats_ok)(int dtype, int ksize, int dil, int c1, int cout) {
-  if (dtype != BRATS_BF16 || ksize != 3 || cout <= 0) return 0;
+  if ((dtype != BRATS_BF16 && dtype != BRATS_X3_BF16) || ksize != 3 || cout <= 0) return 0;
   const int ck = BRATS_API(brats_conv3d_chunk)(dtype, ksize, dil, c1, 0, cout);
-  return ck > 0 && conv_bst_supported(ck, dil, ceil_div(cout, 16)) ? 1 : 0;
+  if (ck <= 0) return 0;
+  return (dtype == BRATS_X3_BF16 ? conv_x3_bst_supported(ck, dil, ceil_div(cout, 16)) : conv_bst_supported(ck, dil, ceil_div(cout, 16))) ? 1 : 0;
 }
 
 extern "C" int BRATS_API(brats_conv3d_fwd_bstats)(const void* x1, int c1, int pitch1, const void* packed_w, void* y, int ypitch,
@@ -357,5 +358,19 @@ extern "C" int BRATS_API(brats_conv3d_x3_fwd)(const void* x1, int c1, int pitch1
   if (dtype != BRATS_X3_BF16) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_fwd: dtype must be BRATS_X3_F16 or BRATS_X3_BF16");
   return conv_fwd_impl(x1, c1, pitch1, x2, c2, pitch2, xamax, packed_w, bias, y, ypitch, y2, y2pitch, ysplit, stats, dtype, 3, dil,
                        N, D, H, W, cout, s);
+}
+
+extern "C" int BRATS_API(brats_conv3d_x3_fwd_bstats)(const void* x1, int c1, int pitch1, const float* xamax, const void* packed_w, void* y,
+                                          int ypitch, const void* fwd_y, int fwd_pitch, const float* scale_shift, int act,
+                                          float slope, float* tile_stats, int dtype, int dil, int N, int D, int H, int W, int cout,
+                                          brats_stream_t s) {
+  if (dtype != BRATS_X3_BF16) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_fwd_bstats: dtype must be BRATS_X3_F16 or BRATS_X3_BF16");
+  if (act != BRATS_ACT_RELU && act != BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "conv3d_x3_fwd_bstats: relu / leakyrelu only (act %d)", act);
+  if (!fwd_y || !scale_shift || !tile_stats) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_fwd_bstats: null pointer");
+  if (fwd_pitch % 4 || ((size_t)fwd_y & 15)) BRATS_FAIL(BRATS_E_ARG, "conv3d_x3_fwd_bstats: the forward tensor must keep 16-byte loads aligned");
+  ConvBst bst;
+  bst.by = fwd_y; bst.bypitch = fwd_pitch; bst.bss = scale_shift; bst.slope = act == BRATS_ACT_RELU ? 0.f : slope; bst.on = true;
+  return conv_fwd_impl(x1, c1, pitch1, nullptr, 0, 0, xamax, packed_w, nullptr, y, ypitch, nullptr, 0, 0, tile_stats, dtype, 3, dil, N, D,
+                       H, W, cout, s, ConvPre{}, bst);
 }
 #include "twin_end.hpp"

@@ -110,8 +110,11 @@ constexpr int conv_x3_lds_bytes() {
 // TY = tile rows in y: 4, or -- VS only -- 8 (the 4x8x16 tile of conv_igemm_vs8.hpp: a wave owns 4 y-rows in each of its two
 // z-slices = 8 voxel fragments, so a weight fragment pair fetched from L2 feeds 24 x 3 MFMAs instead of 12 x 3, the halo
 // amplification drops 2.53x -> 2.11x, and the per-tile costs are paid half as often; statistics stay per 4x4x16 sub-tile)
-template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY>
-__global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY) ? 3 : 2) void conv_igemm_x3_kernel(const ConvParams p, int ty4) {
+// BST: the "backward statistics" form (ConvParams::by / bss, conv_igemm.hpp): this launch is the input gradient of a block's
+// SECOND convolution; the tile statistics become sum u, sum u * by with u = dz * act'(by * scale + shift), by = the first
+// unit's f32 forward tensor -- GroupNorm / EvoNorm backward's first pass without reading dz and by back (2 x 4 bytes per element)
+template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY, bool BST = false>
+__global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY && !BST) ? 3 : 2) void conv_igemm_x3_kernel(const ConvParams p, int ty4) {
   static_assert(TY == CONV_TY || (TY == 8 && VS), "the 8-row tile exists for the y-split roles");
   using G = ConvGeom<bf16_t, KS, CK, DIL, TY>;
   using TL = ConvTile<NF, false, VS>;
@@ -232,27 +235,75 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY) ? 3 : 2) voi
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
+    // BST: the forward values under this lane's outputs (4 f32 channels per fragment and x-row = 16 bytes), requested one x-row
+    // ahead of their use, and the lane's channels' {scale, shift}
+    u32x4 byv[BST ? NF : 1][2];
+    float bsc[BST ? NF : 1][4], bsh[BST ? NF : 1][4];
+    auto load_y = [&](int i, auto checked) {
+      if constexpr (BST) {
+        const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
+        const float* rowp = (const float*)p.by + (sample_vox + (size_t)(z * p.H + y) * p.W + (x0 + v)) * p.bypitch + 4 * q;
+        const bool ok = !decltype(checked)::value || (z < p.D && y < p.H && x_ok);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const bool cok = !decltype(checked)::value || (f0 + f) * 16 + 4 * q < p.cout;
+          byv[f][i & 1] = ok && cok ? *(const u32x4*)(rowp + (f0 + f) * 16) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    };
+    if constexpr (BST) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int c = (f0 + f) * 16 + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool cok = c + r < p.cout;
+          bsc[f][r] = cok ? p.bss[((size_t)n * p.cout + c + r) * 2] : 0.f;
+          bsh[f][r] = cok ? p.bss[((size_t)n * p.cout + c + r) * 2 + 1] : 0.f;
+        }
+      }
+    }
+    // tile sums of one output piece: sum x, sum x^2 -- or, BST, sum u, sum u * (forward value); m = 0 / 1 mask of an edge tile
+    auto tally = [&](int f, int i, const float (&o)[4], float m) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (BST) {
+          const float yy = __uint_as_float(byv[f][i & 1][r]);
+          const float pre = __builtin_fmaf(yy, bsc[f][r], bsh[f][r]);
+          const float u = (pre > 0.f ? o[r] : o[r] * p.bslope) * m;
+          s1[f][r] += u;
+          s2[f][r] = __builtin_fmaf(u, yy, s2[f][r]);
+        } else {
+          const float om = o[r] * m;
+          s1[f][r] += om;
+          s2[f][r] = __builtin_fmaf(om, o[r], s2[f][r]);
+        }
+      }
+    };
     const bool full = z0 + CONV_TZ <= p.D && y0 + TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * TL::NFW * 16 <= p.cout;
     if (full) {
+      load_y(0, std::false_type{});
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
+        if (i + 1 < NB) load_y(i + 1, std::false_type{});
+        if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (keep the loads one row ahead, not all at the top)
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
         float* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            o[r] = acc[f][i][r] * isc;
-            s1[f][r] += o[r];
-            s2[f][r] = __builtin_fmaf(o[r], o[r], s2[f][r]);
-          }
+          for (int r = 0; r < 4; ++r) o[r] = acc[f][i][r] * isc;
+          tally(f, i, o, 1.f);
           Vec<float, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
       }
     } else {
+      load_y(0, std::true_type{});
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
+        if (i + 1 < NB) load_y(i + 1, std::true_type{});
+        if constexpr (BST) __builtin_amdgcn_sched_barrier(0);
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
         const bool ok = z < p.D && y < p.H && x_ok;
         const float mk = ok ? 1.f : 0.f;
@@ -260,15 +311,10 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY) ? 3 : 2) voi
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const bool cok = (f0 + f) * 16 + 4 * q < p.cout;
-          const float mf = cok ? mk : 0.f;
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            o[r] = acc[f][i][r] * isc;
-            const float om = o[r] * mf;
-            s1[f][r] += om;
-            s2[f][r] = __builtin_fmaf(om, o[r], s2[f][r]);
-          }
+          for (int r = 0; r < 4; ++r) o[r] = acc[f][i][r] * isc;
+          tally(f, i, o, cok ? mk : 0.f);
           if (ok && cok) Vec<float, 4>::store(rowp + lane_o + (f0 + f) * 16, o);
         }
       }
@@ -317,11 +363,11 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY) ? 3 : 2) voi
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------------
-template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY>
+template <int KS, int CK, int DIL, int NF, bool VS, int TY = CONV_TY, bool BST = false>
 int conv_x3_launch_one(const ConvParams& p0, hipStream_t st) {
   constexpr int lds = conv_x3_lds_bytes<KS, CK, DIL, NF, VS, TY>();
   static_assert(lds <= 160 * 1024, "x3 LDS tile too large");
-  auto kern = conv_igemm_x3_kernel<KS, CK, DIL, NF, VS, TY>;
+  auto kern = conv_igemm_x3_kernel<KS, CK, DIL, NF, VS, TY, BST>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   ConvParams p = p0;
@@ -333,6 +379,12 @@ int conv_x3_launch_one(const ConvParams& p0, hipStream_t st) {
   return 0;
 }
 
+inline int conv_x3_ty8_enabled() {
+  static int ty8 = -1;
+  if (ty8 < 0) { const char* e = getenv("BRATS_X3_TY8"); ty8 = e ? atoi(e) : 1; }
+  return ty8;
+}
+
 // tile choice: the cout-half roles where the layer has an even number of NF-fragment groups, the y-split roles otherwise
 // (and for small grids, as conv_launch_ck does); conv_choose_tile()'s nf, so brats_conv3d_split_granule() holds here too
 template <int KS, int CK, int DIL>
@@ -341,14 +393,27 @@ int conv_x3_launch_ck(const ConvParams& p, hipStream_t st) {
   const bool small = (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / (2 * t.nf) > 0 ? p.rows16 / (2 * t.nf) : 1) < conv_small_grid_threshold();
   if constexpr (CK == 16 && DIL == 1) {
     // Cout = 48 (mod 96), big volumes: the y-split roles on the 4x8x16 tile (BRATS_X3_TY8=0: the 4x4x16 tile, for A/B runs)
-    static int ty8 = -1;
-    if (ty8 < 0) { const char* e = getenv("BRATS_X3_TY8"); ty8 = e ? atoi(e) : 1; }
+    const int ty8 = conv_x3_ty8_enabled();
     if (ty8 && t.nf == 3 && t.ksplit && (long)p.N * p.tz * p.ty * p.tx >= 2048) return conv_x3_launch_one<KS, CK, DIL, 3, true, 8>(p, st);
   }
   if (t.nf == 3) return (t.ksplit || small) ? conv_x3_launch_one<KS, CK, DIL, 3, true>(p, st) : conv_x3_launch_one<KS, CK, DIL, 3, false>(p, st);
   if (t.nf == 2) return (t.ksplit || small) ? conv_x3_launch_one<KS, CK, DIL, 2, true>(p, st) : conv_x3_launch_one<KS, CK, DIL, 2, false>(p, st);
   return conv_x3_launch_one<KS, CK, DIL, 1, true>(p, st);
 }
+
+// the backward-statistics forms (conv_x3_k3_bst.hip): the channel roles of a block's second convolution in the width-48 / 96 / ...
+// networks -- rows a multiple of 48; 16-channel chunks where rows = 48 (mod 96), 24-channel chunks where rows = 0 (mod 96)
+inline bool conv_x3_bst_supported(int ck, int dil, int rows16) {
+  if (rows16 % 3 || (dil != 1 && dil != 2)) return false;
+  if (ck == 16) return dil == 1 && rows16 % 6 != 0;
+  return ck == 24 && rows16 % 6 == 0;
+}
+template <int DIL>
+int conv_x3_bst_launch_ck24(const ConvParams& p, hipStream_t st) {  // conv_x3_launch_ck's choice among the NF = 3 roles
+  const bool small = (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 6) < conv_small_grid_threshold();
+  return small ? conv_x3_launch_one<3, 24, DIL, 3, true, CONV_TY, true>(p, st) : conv_x3_launch_one<3, 24, DIL, 3, false, CONV_TY, true>(p, st);
+}
+int conv_x3_bst_launch(const ConvParams& p, int ck, int dil, hipStream_t st);  // conv_x3_k3_bst.hip
 
 // implemented in conv_x3_k3_d<DIL>.hip
 template <int DIL> int conv_x3_launch(const ConvParams& p, int ck, hipStream_t st);

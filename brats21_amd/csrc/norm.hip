@@ -1088,23 +1088,27 @@ extern "C" int BRATS_API(brats_gn_act_bwd_tiles)(const float* tile_stats, int ti
                                       int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
   if (!tile_stats || !dz || !y || !dy || !red || !scale_shift || !mean_rstd || !gamma || tiles_per_sample <= 0)
     BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_tiles: null pointer");
-  if (dtype != BRATS_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_tiles: 16-bit activations only");
+  if (dtype != BRATS_BF16 && dtype != BRATS_F32) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_tiles: 16-bit or f32 (split-precision mode) activations");
   if (act != BRATS_ACT_RELU && act != BRATS_ACT_LEAKY) BRATS_FAIL(BRATS_E_UNSUPPORTED, "gn_act_bwd_tiles: relu / leakyrelu only (act %d)", act);
-  if (C % 8 || C % groups || dzpitch % 8 || ypitch % 8 || dypitch % 8 || C / 8 > 256)
-    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_tiles: C=%d / pitches must be multiples of 8", C);
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (C % vw || C % groups || dzpitch % vw || ypitch % vw || dypitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd_tiles: C=%d / pitches must be multiples of %d", C, vw);
   hipStream_t st = (hipStream_t)s;
   // f64 slab partials behind the [N][C][2] totals, inside the workspace brats_gn_bwd_ws_floats() sizes (64 x N x C x 2 doubles)
   double* part = (double*)(red + (((size_t)N * C * 2 + 1) / 2) * 2);
   const int splits = gn_splits(tiles_per_sample);
   hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, splits), dim3(256), 0, st, tile_stats, tiles_per_sample, C, part);
   hipLaunchKernelGGL(gn_bwd_tiles_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, splits, N, C, groups, mean_rstd, red);
-  const int cv = C / 8, vl = 256 / cv;
+  const int cv = C / vw, vl = 256 / cv;
   const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
-  const bool big = stream_nt((size_t)N * voxels * C * 2);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
   dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
   const SlopeArg sl{slope, nullptr};
-  if (big)
+  if (dtype == BRATS_F32)
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false, false, 0>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y, ypitch,
+                       scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, sl, N, voxels, C, groups, (uint32_t*)amax, HeadFold{});
+  else if (big)
     hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t, false, true, 0>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)y, ypitch,
                        scale_shift, mean_rstd, gamma, red, (bf16_t*)dy, dypitch, dgamma, dbeta, act, sl, N, voxels, C, groups, (uint32_t*)amax, HeadFold{});
   else
@@ -1932,10 +1936,11 @@ extern "C" int BRATS_API(brats_evonorm_bwd_tiles)(const float* tile_stats, int t
                                        int N, int voxels, int C, int groups, float* amax, brats_stream_t s) {
   if (!tile_stats || !dz || !x || !dx || !red || !mean_rstd || !gamma || !beta || !dgamma || !dbeta || tiles_per_sample <= 0)
     BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: null pointer");
-  if (dtype != BRATS_BF16) BRATS_FAIL(BRATS_E_UNSUPPORTED, "evonorm_bwd_tiles: 16-bit activations only (the producing convolution form is)");
+  if (dtype != BRATS_BF16 && dtype != BRATS_F32) BRATS_FAIL(BRATS_E_UNSUPPORTED, "evonorm_bwd_tiles: 16-bit or f32 (split-precision mode) activations");
   if (dconvbias && !chan_sums) BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: dconvbias needs the forward per-channel sums");
-  if (C % 8 || C % groups || dzpitch % 8 || xpitch % 8 || dxpitch % 8 || C / 8 > 256)
-    BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: C=%d / pitches must be multiples of 8", C);
+  const int vw = dtype == BRATS_BF16 ? 8 : 4;
+  if (C % vw || C % groups || dzpitch % vw || xpitch % vw || dxpitch % vw || C / vw > 256)
+    BRATS_FAIL(BRATS_E_ARG, "evonorm_bwd_tiles: C=%d / pitches must be multiples of %d", C, vw);
   hipStream_t st = (hipStream_t)s;
   float* s12 = red;
   float* side = red + (size_t)N * C * 2;
@@ -1944,13 +1949,16 @@ extern "C" int BRATS_API(brats_evonorm_bwd_tiles)(const float* tile_stats, int t
   const int splits = gn_splits(tiles_per_sample);
   hipLaunchKernelGGL(gn_chan_reduce_kernel, dim3((C + 15) / 16, N, splits), dim3(256), 0, st, tile_stats, tiles_per_sample, C, part);
   hipLaunchKernelGGL(evonorm_bwd_tiles_prep_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, splits, N, C, groups, mean_rstd, beta, s12);
-  const int cv = C / 8, vl = 256 / cv;
+  const int cv = C / vw, vl = 256 / cv;
   size_t gx = ((size_t)voxels + (size_t)vl * 8 - 1) / ((size_t)vl * 8);
-  const bool big = stream_nt((size_t)N * voxels * C * 2);
+  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
   const size_t cap = big ? EVO_SIDE_MAX_BLOCKS : 512;
   dim3 g2((unsigned)(gx < 1 ? 1 : (gx > cap ? cap : gx)), N);
   const size_t lds2 = (size_t)(3 * C + vl * C) * sizeof(float);
-  if (big)
+  if (dtype == BRATS_F32)
+    hipLaunchKernelGGL((evonorm_bwd_apply_side_kernel<float, false>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)x, xpitch,
+                       mean_rstd, gamma, s12, (float*)dx, dxpitch, side_part, voxels, C, groups, (uint32_t*)amax);
+  else if (big)
     hipLaunchKernelGGL((evonorm_bwd_apply_side_kernel<bf16_t, true>), g2, dim3(256), lds2, st, (const bf16_t*)dz, dzpitch, (const bf16_t*)x, xpitch,
                        mean_rstd, gamma, s12, (bf16_t*)dx, dxpitch, side_part, voxels, C, groups, (uint32_t*)amax);
   else

@@ -438,12 +438,13 @@ def _cgr_bwd(rec, dz, dtype, act, grads, names, need_dx=True, sink=None, fp8=Non
         def dgrad(**kw):
             return ops.conv3d(dy, wpk, cin, 3, unit.dilation, amax=amax if x3s else None, **kw)
     if x2 is None:
-        if bst is not None and not f8 and not x3s:
+        if bst is not None and not f8:
             u1, _, _, y1, mr1, ss1 = bst
             kact1, slope1 = _unit_act(u1, act)
             if (not u1.batch_norm and not u1.bcn and not unit.bcn and mr1 is not None and y1.shape[-1] == cin and y1.dtype == dy.dtype
                     and ops.conv_bstats_ok(dtype, unit.dilation, dy.shape[-1], cin, kact1, slope1)):
-                return ops.conv3d_bstats(dy, wpk, cin, unit.dilation, y1, ss1, kact1)  # (dx, tile sums of u1's GroupNorm backward)
+                # (dx, tile sums of u1's GroupNorm backward)
+                return ops.conv3d_bstats(dy, wpk, cin, unit.dilation, y1, ss1, kact1, amax=amax if x3s else None)
         dx, _ = dgrad()
         return dx
     c1 = x.shape[-1]

@@ -171,11 +171,12 @@ def _conv_any_bwd(cx, conv, saved, dy, need_dx=True, db=None, bstats=False):
         dx, _ = ops.conv3d_f8(dy, ops.pack_weights_f8(w, PACK_DGRAD), cin, dil, amax=getattr(dy, "_amax", None))
         return dx
     wpk = ops.pack_weights(w, cx.dtype, PACK_DGRAD, dil=dil)
-    if (bstats and k == 3 and not cx.x3s and xin.shape[-1] == cin and xin.dtype == dy.dtype
+    if (bstats and k == 3 and xin.shape[-1] == cin and xin.dtype == dy.dtype
             and ops.conv_bstats_ok(cx.dtype, dil, cout, cin, "leakyrelu")):
         n = dy.shape[0]
         ss = cx.identity_ss(n, cin, dy.device)
-        return ops.conv3d_bstats(dy, wpk, cin, dil, xin, ss, "leakyrelu", slope=1.0)  # (dz1, tile sums)
+        return ops.conv3d_bstats(dy, wpk, cin, dil, xin, ss, "leakyrelu", slope=1.0,  # (dz1, tile sums)
+                                 amax=getattr(dy, "_amax", None) if cx.x3s else None)
     dx, _ = ops.conv3d(dy, wpk, cin, k, dil, amax=getattr(dy, "_amax", None) if (cx.x3s and k == 3) else None)
     return dx
 

@@ -787,15 +787,17 @@ def gn_act_bwd(dz, y, scale_shift, mean_rstd, gamma, groups=8, act="relu", slope
 
 def conv_bstats_ok(dtype, dil, c1, cout, act="relu", slope_t=None):
     """Is the "backward statistics" form of the 3x3x3 convolution (conv3d_bstats) built for this layer?"""
-    if not is16(dtype) or slope_t is not None or act not in ("relu", "leakyrelu"):
+    dtype = _conv_dtype(dtype, 3)  # (f32 tensors inside a split_precision() block: the x3 kernels have the form too)
+    if not (is16(dtype) or dtype in (X3F, X3B)) or slope_t is not None or act not in ("relu", "leakyrelu"):
         return False
     return bool(_lib.lib().brats_conv3d_bstats_ok(_code(dtype), 3, dil, c1, cout))
 
 
-def conv3d_bstats(x, packed_w, cout, dil, fwd_y, scale_shift, act="relu", slope=0.01):
+def conv3d_bstats(x, packed_w, cout, dil, fwd_y, scale_shift, act="relu", slope=0.01, amax=None):
     """The input gradient dz = conv(x = dy of a block's second unit, weights packed with PACK_DGRAD) that also leaves
     GroupNorm backward's first pass for the block's FIRST unit (include/brats_hip.h: brats_conv3d_fwd_bstats): per tile and
-    channel sum u and sum u * fwd_y, u = dz * act'(fwd_y * scale + shift).  -> (dz, tile_stats) for gn_act_bwd_tiles()."""
+    channel sum u and sum u * fwd_y, u = dz * act'(fwd_y * scale + shift).  -> (dz, tile_stats) for gn_act_bwd_tiles().
+    f32 tensors inside a split_precision() block run brats_conv3d_x3_fwd_bstats; amax = max|x| as for conv3d (fp16 pairs)."""
     ptr, c, p = _desc(x)
     n, d, h, w, _ = x.shape
     fp, fc, fpitch = _desc(fwd_y)
@@ -805,6 +807,13 @@ def conv3d_bstats(x, packed_w, cout, dil, fwd_y, scale_shift, act="relu", slope=
     stats = torch.empty((n, tiles_per_sample(d, h, w), cout, 2), dtype=torch.float32, device=x.device)
     # (a family of its own in the bench's kernel table: these launches carry a GroupNorm-backward pass in their epilogue and
     #  are not the plain implicit GEMM the roofline line is about)
+    kd = _conv_dtype(x.dtype, 3)
+    if kd in (X3F, X3B):
+        with _span("conv_igemm_bst", c, cout, 3, dil, n, d, h, w, str(kd)):
+            _lib.check(_lib.lib().brats_conv3d_x3_fwd_bstats(ptr, c, p, _f32(amax), packed_w.data_ptr(), out.data_ptr(), cout, fp, fpitch,
+                                                             scale_shift.data_ptr(), ACTS[act], float(slope), stats.data_ptr(),
+                                                             _code(kd), dil, n, d, h, w, cout, _stream()), "conv3d_x3_fwd_bstats")
+        return out, stats
     with _span("conv_igemm_bst", c, cout, 3, dil, n, d, h, w, str(x.dtype)):
         _lib.check(_lib.lib().brats_conv3d_fwd_bstats(ptr, c, p, packed_w.data_ptr(), out.data_ptr(), cout, fp, fpitch,
                                                       scale_shift.data_ptr(), ACTS[act], float(slope), stats.data_ptr(),

@@ -158,6 +158,14 @@ int brats_conv3d_fwd_bstats(const void* x1, int c1, int pitch1, const void* pack
 int brats_conv3d_x3_fwd(const void* x1, int c1, int pitch1, const void* x2, int c2, int pitch2, const float* xamax,
                         const void* packed_w, const float* bias, void* y, int ypitch, void* y2, int y2pitch, int ysplit,
                         float* stats, int dtype, int dil, int N, int D, int H, int W, int cout, brats_stream_t s);
+/* brats_conv3d_fwd_bstats for the split-precision kernels (dtype BRATS_X3_F16 / BRATS_X3_BF16; f32 tensors, fwd_y f32 and
+ * 16-byte aligned): the input gradient of a block's second convolution in the parity mode, scaled through `xamax` like
+ * brats_conv3d_x3_fwd, leaving the first-pass sums of the first unit's GroupNorm / EvoNorm backward per tile -- there the pass
+ * it replaces reads 2 x 4 bytes per element.  brats_conv3d_bstats_ok(dtype = BRATS_X3_*) = 1 where the form is built (cout a
+ * multiple of 48).  Autograd of networks/equiunet2020.py:105-123 / equiunet2021.py:197-206 under model.precision = "x3". */
+int brats_conv3d_x3_fwd_bstats(const void* x1, int c1, int pitch1, const float* xamax, const void* packed_w, void* y, int ypitch,
+                               const void* fwd_y, int fwd_pitch, const float* scale_shift, int act, float slope,
+                               float* tile_stats, int dtype, int dil, int N, int D, int H, int W, int cout, brats_stream_t s);
 /* ---- fp8 (OCP e4m3) variant of the 3x3x3 convolution (BASELINE.json configs[4], "fp8 MFMA conv path"): bf16 NDHWC
  * activations in and out; the input is quantised to e4m3 while it is staged (x / 2^e, round-to-nearest-even, e chosen
  * from the tensor's |max| so that it lands in [128, 256)), the weights are packed as e4m3 with one power-of-two scale

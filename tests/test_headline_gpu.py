@@ -65,7 +65,9 @@ def test_equiunet48_vs_oracle_f32_and_bf16(size):
     flips = float(((out_b.cpu() > 0) != (ref > 0)).float().mean())
     print(f"EquiUnet-48 @{size}^3 bf16: max {float(dev.max()):.3e} mean {float(dev.mean()):.3e} p99.9 {p999:.3e}; "
           f"thresholded voxels that differ {flips:.3e}; hard Dice oracle {d_ref.flatten().tolist()} bf16 {d_b.flatten().tolist()}")
-    assert float(dev.mean()) < 0.05 and float(dev.max()) < 1.0
+    # bf16 against the f32 oracle on |logits| <= 28: measured mean 1.9e-2, p99.9 0.13, max 0.23 at both sizes (deterministic
+    # arithmetic: the same on every box) -- bars at ~1.5x, so that a 2x loss of bf16 accuracy fails ("weak" 3)
+    assert float(dev.mean()) < 0.03 and p999 < 0.2 and float(dev.max()) < 0.35, (float(dev.mean()), p999, float(dev.max()))
     assert float((d_ref - d_b).abs().max()) <= DICE_ATOL, (d_ref, d_b)
 
 

@@ -292,6 +292,70 @@ def test_x3_backward_arithmetic_matches_exact_f32_backward(name, width, size):
     assert rel[0][0] < 1e-4, rel[:5]
 
 
+@pytest.mark.parametrize("c,dil,size,mode", [(48, 1, (8, 16, 32), "x3_f16"), (48, 1, (9, 7, 21), "x3_bf16"), (96, 1, (8, 8, 16), "x3_f16"),
+                                             (96, 2, (8, 8, 16), "x3_f16"), (48, 1, (16, 64, 64), "x3_f16")])
+def test_conv3d_x3_backward_statistics_form(c, dil, size, mode):
+    """brats_conv3d_x3_fwd_bstats: the split-precision input gradient that also leaves per tile and channel sum u, sum u * y
+    (u = dz * relu'(y * scale + shift)) -- dz bit-identical to the plain x3 launch, the sums against float64 sums over the
+    stored dz (f32 storage: the fused form sees exactly the stored values, only the order of the additions differs).
+    The last case is large enough for the 4x8x16 tile (>= 2048 tiles)."""
+    from brats21_amd import ops
+    n = 2
+    dy = _nd(_rand((n, c, *size), 1, 1e-4))            # a gradient: small values, scaled through its |max|
+    y1 = _nd(_rand((n, c, *size), 2))                  # the first unit's raw convolution output
+    w = _rand((c, c, 3, 3, 3), 3, (2.0 / (c * 27)) ** 0.5).to(DEV)
+    ss = torch.stack([1.0 + 0.2 * _rand((n, c), 4), 0.3 * _rand((n, c), 5)], -1).contiguous().to(DEV)
+    amax = dy.abs().max().reshape(1).float() if mode == "x3_f16" else None
+    with ops.split_precision(mode):
+        assert ops.conv_bstats_ok(torch.float32, dil, c, c, "relu")
+        wpk = ops.pack_weights(w, torch.float32, ops.PACK_DGRAD, dil=dil)
+        dz, tiles = ops.conv3d_bstats(dy, wpk, c, dil, y1, ss, "relu", amax=amax)
+        dz0, _ = ops.conv3d(dy, wpk, c, 3, dil, amax=amax)
+        dzl, tl = ops.conv3d_bstats(dy, wpk, c, dil, y1, ss, "leakyrelu", slope=0.25, amax=amax)
+    assert torch.equal(dz, dz0) and torch.equal(dzl, dz0)
+    pre = y1.double() * ss[:, None, None, None, :, 0].double() + ss[:, None, None, None, :, 1].double()
+    for name, t_, slope in (("relu", tiles, 0.0), ("leakyrelu 0.25", tl, 0.25)):
+        u = torch.where(pre > 0, dz0.double(), dz0.double() * slope)
+        s1, s2 = u.sum((1, 2, 3)), (u * y1.double()).sum((1, 2, 3))
+        got = t_.double().sum(1)  # [n, c, 2]
+        scale1, scale2 = float(u.abs().sum((1, 2, 3)).max()), float((u * y1.double()).abs().sum((1, 2, 3)).max())
+        e1, e2 = float((got[..., 0] - s1).abs().max()) / scale1, float((got[..., 1] - s2).abs().max()) / scale2
+        print(f"x3 bstats {mode} c={c} d={dil} {size} {name}: sum u {e1:.2e}, sum u*y {e2:.2e} (of the sums of magnitudes)")
+        assert e1 < 2e-6 and e2 < 2e-6, (name, e1, e2)
+
+
+@pytest.mark.parametrize("name,nblocks", [("equiunet", 8), ("equiunet_assp_evo", 7)])
+def test_x3_backward_statistics_fold_in_the_networks(name, nblocks):
+    """model.fold_bwd_stats in the parity mode: every block's second input-gradient launch takes the first pass of the first
+    unit's GroupNorm / EvoNorm backward; the forward is untouched and -- f32 storage -- the gradients equal the two-pass form's to
+    summation order (1e-5 of each tensor's norm; the arithmetic itself is pinned against the exact-f32 backward by
+    test_x3_backward_arithmetic_matches_exact_f32_backward, which runs with the fold on)."""
+    from brats21_amd import ops
+    m, _ = _perturbed(name, 48)
+    x, t = synth.random_image(2, 4, (32, 32, 32), seed=5).to(DEV), synth.nested_spheres(2, (32, 32, 32)).to(DEV)
+    calls, real = [], ops.conv3d_bstats
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    ops.conv3d_bstats = counted
+    try:
+        m.fold_bwd_stats = True
+        o1, g1 = _step_grads(m, "x3", x, t)
+        n1 = len(calls)
+        m.fold_bwd_stats = False
+        o0, g0 = _step_grads(m, "x3", x, t)
+    finally:
+        ops.conv3d_bstats = real
+        m.fold_bwd_stats = True
+    assert n1 == nblocks and len(calls) == nblocks, (n1, len(calls))
+    assert torch.equal(o1, o0)
+    rel = sorted(((float((g1[k] - g0[k]).norm() / (g0[k].norm() + 1e-30)), k) for k in g0), reverse=True)
+    print(f"\n{name}-48 x3: fold_bwd_stats on vs off, worst per-parameter rel diff {rel[:3]}")
+    assert rel[0][0] < 1e-5, rel[:5]
+
+
 @pytest.mark.parametrize("name,width,size", [("equiunet", 48, 32), ("equiunet_assp_evo", 48, 32)])
 def test_x3_gradients_vs_f64_oracle(name, width, size):
     """Per-parameter gradients of the whole split-precision training step against the oracle in float64, beside the exact-f32
