@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         s2[f][r] = 0.f;
       }
     }
-    // BST: the forward values under this lane's outputs (4 channels per fragment and x-row, 8 bytes), requested one pair of
-    // x-rows ahead of their use (all of them up front spill), and the lane's channels' {scale, shift}; the tile sums become
+    // BST: the forward values under this lane's outputs (4 channels per fragment and x-row, 8 bytes), requested
+    // BRATS_BST_AHEAD x-rows ahead of their use (round 5: all of them at once), and the lane's channels' {scale, shift}; the tile sums become
     // sum u, sum u * (forward value) with u = dz * act'(forward * scale + shift)  (GroupNorm backward's first pass)
     u32x2 byv[BST ? NF : 1][BST ? NB : 1];
     float bsc[BST ? NF : 1][4], bsh[BST ? NF : 1][4];
@@ -509,15 +509,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
       // rows of the first operand <-> even rows of the second) gives every lane 8 consecutive channels of ONE voxel:
       // rows 0 / 2 keep x-row i, rows 1 / 3 take x-row i + 1.
       const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
-      load_y(0, std::false_type{});
-      load_y(1, std::false_type{});
+#ifndef BRATS_BST_AHEAD
+#define BRATS_BST_AHEAD 8
+#endif
+      constexpr int AH = BRATS_BST_AHEAD < NB ? BRATS_BST_AHEAD : NB;  // x-rows requested ahead of their use (even)
+#pragma unroll
+      for (int k = 0; k < AH; ++k) load_y(k, std::false_type{});
 #pragma unroll
       for (int i = 0; i < NB; i += 2) {
-        if (i + 2 < NB) {
-          load_y(i + 2, std::false_type{});
-          load_y(i + 3, std::false_type{});
+        if (i + AH < NB) {
+          load_y(i + AH, std::false_type{});
+          load_y(i + AH + 1, std::false_type{});
         }
-        if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every load to the top: 48 live registers, spills)
+        if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (the loads stay where they are written)
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? 2 * wn : 0) + (i % YB);
         T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll

@@ -62,8 +62,8 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
       s2[f][rr] = 0.f;
     }
   }
-  // BST: the forward values under this lane's outputs (4 channels per fragment and x-row, 8 bytes), requested one pair of
-  // x-rows ahead of their use (all 24 pieces up front cost 48 registers and spilled), and the lane's channels' {scale, shift}
+  // BST: the forward values under this lane's outputs (4 channels per fragment and x-row, 8 bytes), requested
+  // BRATS_BST_AHEAD x-rows ahead of their use, and the lane's channels' {scale, shift}
   u32x2 byv[BST ? NF : 1][BST ? NB : 1];
   float bsc[BST ? NF : 1][4], bsh[BST ? NF : 1][4];
   auto load_y = [&](int i, auto checked) {
@@ -103,15 +103,19 @@ DEVI void vs8_epilogue_store(const ConvParams& p, f32x4 (&acc)[NF][8], float* sr
     // the second) gives every lane 8 consecutive channels of ONE voxel: rows 0 / 2 keep x-row i, rows 1 / 3 take x-row
     // i + 1.  Half the store instructions; worth ~1 % (the epilogue waits on the CU's ~10 B/clk store path, not on issue).
     const int lane_w = (x0 + v) * ypit + 8 * (q >> 1) - csub + (q & 1) * p.W * ypit;
-    load_y(0, std::false_type{});
-    load_y(1, std::false_type{});
+#ifndef BRATS_BST_AHEAD
+#define BRATS_BST_AHEAD 8  // all of a wave's x-rows at once (48 registers, no spill: 230 VGPRs either way); 2 -> 8: bst launches -2 %, same box
+#endif
+    constexpr int AH = BRATS_BST_AHEAD;  // x-rows requested ahead of their use
+#pragma unroll
+    for (int k = 0; k < AH; ++k) load_y(k, std::false_type{});
 #pragma unroll
     for (int i = 0; i < NB; i += 2) {
-      if (i + 2 < NB) {
-        load_y(i + 2, std::false_type{});
-        load_y(i + 3, std::false_type{});
+      if (i + AH < NB) {
+        load_y(i + AH, std::false_type{});
+        load_y(i + AH + 1, std::false_type{});
       }
-      if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every load to the top: 48 live registers, spills)
+      if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (the loads stay where they are written)
       const int z = z0 + 2 * wm + (i / YB), y = y0 + YB * wn + (i % YB);
       T* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
 #pragma unroll

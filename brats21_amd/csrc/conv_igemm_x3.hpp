@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY && !BST) ? 3 
       for (int r = 0; r < 4; ++r) { s1[f][r] = 0.f; s2[f][r] = 0.f; }
     // BST: the forward values under this lane's outputs (4 f32 channels per fragment and x-row = 16 bytes), requested one x-row
     // ahead of their use, and the lane's channels' {scale, shift}
-    u32x4 byv[BST ? NF : 1][2];
+#ifndef BRATS_X3_BST_AHEAD
+#define BRATS_X3_BST_AHEAD 8  // all rows at once (96 registers in the 4x8x16 kernel, 249 VGPRs, no spill); 1 -> 8: bst launches -2.5 %
+#endif
+    constexpr int AH = BRATS_X3_BST_AHEAD < NB ? BRATS_X3_BST_AHEAD : NB;  // x-rows requested ahead of their use
+    u32x4 byv[BST ? NF : 1][BST ? AH + 1 : 1];
     float bsc[BST ? NF : 1][4], bsh[BST ? NF : 1][4];
     auto load_y = [&](int i, auto checked) {
       if constexpr (BST) {
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY && !BST) ? 3 
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const bool cok = !decltype(checked)::value || (f0 + f) * 16 + 4 * q < p.cout;
-          byv[f][i & 1] = ok && cok ? *(const u32x4*)(rowp + (f0 + f) * 16) : u32x4{0u, 0u, 0u, 0u};
+          byv[f][i % (AH + 1)] = ok && cok ? *(const u32x4*)(rowp + (f0 + f) * 16) : u32x4{0u, 0u, 0u, 0u};
         }
       }
     };
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY && !BST) ? 3 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if constexpr (BST) {
-          const float yy = __uint_as_float(byv[f][i & 1][r]);
+          const float yy = __uint_as_float(byv[f][i % (AH + 1)][r]);
           const float pre = __builtin_fmaf(yy, bsc[f][r], bsh[f][r]);
           const float u = (pre > 0.f ? o[r] : o[r] * p.bslope) * m;
           s1[f][r] += u;
@@ -282,10 +286,11 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY && !BST) ? 3 
     };
     const bool full = z0 + CONV_TZ <= p.D && y0 + TY <= p.H && x0 + CONV_TX <= p.W && (ct + 1) * TL::NFW * 16 <= p.cout;
     if (full) {
-      load_y(0, std::false_type{});
+#pragma unroll
+      for (int k = 0; k < AH; ++k) load_y(k, std::false_type{});
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        if (i + 1 < NB) load_y(i + 1, std::false_type{});
+        if (i + AH < NB) load_y(i + AH, std::false_type{});
         if constexpr (BST) __builtin_amdgcn_sched_barrier(0);  // (keep the loads one row ahead, not all at the top)
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
         float* rowp = ydst + (sample_vox + (size_t)(z * p.H + y) * p.W) * ypit;
@@ -299,10 +304,11 @@ __global__ __launch_bounds__(256, (CK == 16 && VS && TY == CONV_TY && !BST) ? 3 
         }
       }
     } else {
-      load_y(0, std::true_type{});
+#pragma unroll
+      for (int k = 0; k < AH; ++k) load_y(k, std::true_type{});
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        if (i + 1 < NB) load_y(i + 1, std::true_type{});
+        if (i + AH < NB) load_y(i + AH, std::true_type{});
         if constexpr (BST) __builtin_amdgcn_sched_barrier(0);
         const int z = z0 + 2 * wm + (i / YB), y = y0 + (VS ? YB * wn : 0) + (i % YB);
         const bool ok = z < p.D && y < p.H && x_ok;
