@@ -32,6 +32,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 LOGIT_ATOL = 1e-3
 DICE_ATOL = 1e-3
+F8_DICE_ATOL = 1e-2  # the opt-in e4m3 convolution path (3 significand bits): its own, wider bar; the margin is printed
 PATCH = (128, 128, 128)
 VOL = (240, 240, 155)
 STEPS = {"equiunet": 320, "equiunet_assp_evo": 320}
@@ -117,8 +118,16 @@ def test_trained_patch_logits_and_dice_vs_oracle(model):
                 out = m(xd)
                 out = (out[0] if isinstance(out, (tuple, list)) else out).float().cpu()
                 res[prec] = _report(prec, out, ref, t, d_ref) + (float((out - ref).abs().max()),)
+            # BASELINE.json configs[4]'s arithmetic: fp16 storage, every 3x3x3 convolution on the e4m3 MFMA kernels (scales
+            # from the recorded |max| of each tensor)
+            m.precision, m.conv_fp8 = "fp16", "fwd"
+            out = m(xd)
+            out = (out[0] if isinstance(out, (tuple, list)) else out).float().cpu()
+            m.conv_fp8 = None
+            res["fp16+e4m3"] = _report("fp16 + e4m3 convolutions", out, ref, t, d_ref) + (float((out - ref).abs().max()),)
         m.precision = "x3"
         assert res["fp32"][2] < LOGIT_ATOL and res["x3"][2] < LOGIT_ATOL, res
+        assert res["fp16+e4m3"][0] <= F8_DICE_ATOL, (contrast, res["fp16+e4m3"])
         for prec in ("fp32", "x3", "bf16", "fp16"):
             assert res[prec][0] <= DICE_ATOL, (contrast, prec, res[prec])
 
