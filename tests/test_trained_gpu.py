@@ -15,7 +15,9 @@ those weights and on volumes the training never saw:
     the oracle's, with the margin and the fraction of thresholded voxels that flipped printed;
   * the benchmarked chain (sliding window + 8-flip TTA, Evaluator: learning/engine.py:236-259, src/definer.py:696-697) in
     bf16 / fp16 against the same chain in f32, whose network arithmetic the stitched-logit check has just pinned.
-The numbers land in profiles/ through scripts/gpu_suite.sh (pytest -s)."""
+The 320-step training runs reproduce BIT FOR BIT across runs and boxes (every reduction of the step is ordered; checked: two
+runs on one box and a third on another print identical loss curves and Dice values), so the margins below are properties of the tree,
+not of the lease.  The numbers land in profiles/ through scripts/r5_final.sh (pytest -s)."""
 import argparse
 import contextlib
 import io
