@@ -130,7 +130,7 @@ def side_train_leg(dev, rank, model_name, width, batch, precision, warmup, steps
     with contextlib.redirect_stdout(io.StringIO()):
         m = get_model(ns).to(dev).train()
         opt = Ranger2020(m.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5,
-                         capturable=graph)
+                         capturable=graph or precision == "fp16")  # (fp16: the GradScaler's skip decided on the device, no host round trip)
     if fp8:
         m.conv_fp8 = fp8
     size = (patch,) * 3
@@ -411,7 +411,7 @@ def main():
     if args.optimizer == "ranger":  # src/definer.py:316-331 + the CLI defaults lr 1e-4, weight_decay 1e-5
         with contextlib.redirect_stdout(io.StringIO()):
             opt = Ranger2020(model.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5,
-                             weight_decay=1e-5, use_gc=args.use_gc, capturable=args.graph)
+                             weight_decay=1e-5, use_gc=args.use_gc, capturable=args.graph or args.precision == "fp16")
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
     buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None  # BRATS_DDP_BF16=1: bf16 transport
@@ -422,7 +422,6 @@ def main():
     if args.precision == "x3":
         model.precision = "x3"
     amp_dtype = torch.float16 if args.precision == "fp16" else torch.bfloat16
-    assert not (args.graph and args.precision == "fp16"), "--graph: the GradScaler's inf check reads the device every step; use bf16"
     train_step = TrainStep(model, opt, criterion=None if args.fused_dice else crit, amp=use_amp, buckets=buckets, amp_dtype=amp_dtype)
 
     if args.graph:  # (with N > 1 the bucketed RCCL all-reduces are captured into the graph too)

@@ -86,10 +86,16 @@ class GraphedTrainStep:
 
     def __init__(self, step, warmup=2, multi_rank_capture=None):
         if getattr(step, "scaler", None) is not None and step.amp:
-            # torch.amp.GradScaler.step() / update() read found_inf on the HOST: a capture would either fail obscurely or bake
-            # one step's decision into the graph.  fp16 training runs eagerly (TrainStep), bf16 / x3 / fp32 graph.
-            raise NotImplementedError("GraphedTrainStep: a TrainStep with a GradScaler (amp_dtype=torch.float16) cannot be captured; "
-                                      "use the eager TrainStep for fp16, or bf16 / model.precision='x3' for graph replay")
+            # torch.amp.GradScaler.step() reads found_inf on the HOST for an ordinary optimizer: a capture would bake one step's
+            # decision into the graph.  With an optimizer that takes the scale and the flag as device tensors
+            # (_step_supports_amp_scaling: brats21_amd.optim.Ranger2020(capturable=True), torch's fused Adam) nothing of the loop
+            # touches the host -- scale(), the inf check, the skipped-or-not step and update() are all kernels -- and it captures.
+            if not (getattr(step.optimizer, "_step_supports_amp_scaling", False) and getattr(step.optimizer, "capturable", False)) \
+                    or step.max_grad_norm is not None:
+                raise NotImplementedError("GraphedTrainStep: a TrainStep with a GradScaler (amp_dtype=torch.float16) captures only with "
+                                          "an optimizer that implements the GradScaler protocol on the device "
+                                          "(brats21_amd.optim.Ranger2020(capturable=True)) and without gradient clipping; otherwise use "
+                                          "the eager TrainStep for fp16, or bf16 / model.precision='x3' for graph replay")
         if step.buckets is not None:
             import os
             import torch.distributed as dist

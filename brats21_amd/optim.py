@@ -6,6 +6,7 @@ two HIP launches over all parameters (csrc/ranger.hip) instead of the reference'
 ``exp_avg_sq``, ``slow_buffer`` -- so Engine.resume (learning/engine.py:511-525) restores either way.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -60,6 +61,11 @@ class Ranger2020(Optimizer):
         # it when an LR scheduler changed group["lr"]: no re-capture).
         self.capturable = capturable
         self._plans = {}
+        # torch.amp.GradScaler protocol (as torch's fused Adam): GradScaler.step() then hands the loss scale and the overflow flag
+        # over as DEVICE tensors (self.grad_scale / self.found_inf) instead of reading the flag on the host and unscaling in a
+        # pass of its own.  capturable=True: the skip is decided on the device too (no host round trip per step); otherwise the
+        # flag is read here -- the reference loop's own synchronisation (learning/engine.py:117-122), no more
+        self._step_supports_amp_scaling = os.environ.get("BRATS_RANGER_AMP", "1") != "0"  # (0: GradScaler's own unscale pass + host check, for A/B runs)
 
     # ------------------------------------------------------------------------------------------ static plan
     def _plan(self, gi, active, dev):
@@ -176,6 +182,14 @@ class Ranger2020(Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         lib = _lib.lib()
+        grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        if found_inf is not None and not self.capturable:
+            if float(found_inf.item()) != 0.0:  # GradScaler's skipped step: nothing moves, the step counts stay
+                return None
+            found_inf = None
+        for t_ in (grad_scale, found_inf):
+            if t_ is not None and (t_.dtype != torch.float32 or t_.numel() != 1 or not t_.is_cuda):
+                raise _lib.BratsHipError("Ranger2020: grad_scale / found_inf must be one-element f32 device tensors (torch.amp.GradScaler's)")
         for gi, group in enumerate(self.param_groups):
             active = [p for p in group["params"] if p.grad is not None]
             if not active:
@@ -225,8 +239,9 @@ class Ranger2020(Optimizer):
                     self.sync_lr()
                 elif plan.get("lr_dev") != float(lr):
                     raise _lib.BratsHipError("Ranger2020: the learning rate changed between the warm-up steps and the capture")
-                _lib.check(lib.brats_ranger_advance(dyn.data_ptr(), -1.0, float(beta1), float(beta2), int(k),
-                                                    float(self.N_sma_threshhold), stream), "ranger_advance")
+                _lib.check(lib.brats_ranger_advance_amp(dyn.data_ptr(), -1.0, float(beta1), float(beta2), int(k),
+                                                        float(self.N_sma_threshhold),
+                                                        found_inf.data_ptr() if found_inf is not None else None, stream), "ranger_advance")
             elif capturing:
                 raise _lib.BratsHipError("Ranger2020.step() inside a hipGraph capture needs capturable=True")
             table = plan["dev_table"]
@@ -247,11 +262,12 @@ class Ranger2020(Optimizer):
                 ev = torch.cuda.Event()
                 ev.record()
                 plan["events"][slot] = ev
-            _lib.check(lib.brats_ranger_step(
+            _lib.check(lib.brats_ranger_step_amp(
                 table.data_ptr(), len(active), plan["chunks"].data_ptr(), plan["chunks"].shape[0],
                 plan["rows"].data_ptr() if plan["rows"] is not None else None, plan["nrows"], plan["means"].data_ptr(),
                 plan["chunk_stats"].data_ptr() if self.use_gcnorm else None, plan["grad_std"].data_ptr() if self.use_gcnorm else None,
                 dyn.data_ptr() if dyn is not None else None, beta1, beta2, 1 - beta1, 1 - beta2, group["eps"], self.alpha,
+                grad_scale.data_ptr() if grad_scale is not None else None, found_inf.data_ptr() if found_inf is not None else None,
                 stream), "ranger_step")
             for p in active:  # the kernel wrote through raw pointers: tell autograd / the packed-weight cache
                 torch.autograd.graph.increment_version(p)

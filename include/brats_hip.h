@@ -568,6 +568,18 @@ int brats_ranger_step(const brats_ranger_tensor* table, int ntensors, const int*
                       const int* rows, int nrows, float* row_means, float* chunk_stats, float* grad_std,
                       const brats_ranger_dyn* dyn, float beta1, float beta2, float one_minus_beta1,
                       float one_minus_beta2, float eps, float alpha, brats_stream_t s);
+/* The same step under torch.amp.GradScaler WITHOUT its host round trip (the reference's AMP loop, learning/engine.py:117-122, with
+ * an optimizer that declares _step_supports_amp_scaling as torch's fused Adam does): grad_scale = device scalar holding the loss
+ * scale the gradients still carry (a power of two; NULL = already unscaled) -- every gradient is read as g / grad_scale;
+ * found_inf = device scalar, non-zero when a gradient overflowed (NULL = not checked) -- then every kernel of the step returns
+ * at once and brats_ranger_advance_amp leaves the counter alone: the skipped step of GradScaler.step(), decided on the device. */
+int brats_ranger_advance_amp(brats_ranger_dyn* dyn, double lr, double beta1, double beta2, int k,
+                             double nsma_threshold, const float* found_inf, brats_stream_t s);
+int brats_ranger_step_amp(const brats_ranger_tensor* table, int ntensors, const int* chunks, int nchunks,
+                          const int* rows, int nrows, float* row_means, float* chunk_stats, float* grad_std,
+                          const brats_ranger_dyn* dyn, float beta1, float beta2, float one_minus_beta1,
+                          float one_minus_beta2, float eps, float alpha, const float* grad_scale,
+                          const float* found_inf, brats_stream_t s);
 
 /* ---- input pipeline on the GPU (the reference's CPU transform chain,
  * src/definer.py:449-467).  NCDHW f32.

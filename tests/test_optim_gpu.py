@@ -73,10 +73,13 @@ def test_ranger_full_model_vs_oracle_and_state_dict_roundtrip():
         Ranger2020(params, alpha=1.5)
 
 
-def test_graphed_train_step_matches_eager():
+@pytest.mark.parametrize("amp_dtype", [torch.bfloat16, torch.float16])
+def test_graphed_train_step_matches_eager(amp_dtype):
     """The whole step (fwd + fused Dice + bwd + capturable Ranger) captured into one hipGraph replays to the same
     parameters as the eager TrainStep (bf16 kernels are deterministic), across the step-5 -> 6 RAdam switch and the
-    lookahead sync at step 6."""
+    lookahead sync at step 6.  float16: the reference's autocast + GradScaler loop captured too -- Ranger2020(capturable=True) takes
+    the loss scale and the overflow flag as device tensors, so scale(), the inf check, the step and update() are all kernels;
+    the eager twin (capturable=False) reads the flag on the host as the reference's loop does."""
     from brats21_amd import get_model
     from brats21_amd.engine import GraphedTrainStep, TrainStep
     from brats21_amd.optim import Ranger2020
@@ -90,7 +93,7 @@ def test_graphed_train_step_matches_eager():
         with contextlib.redirect_stdout(io.StringIO()):
             m = get_model(ns).to(DEV).train()
         opt = Ranger2020(m.parameters(), lr=1e-2, weight_decay=1e-5, use_gc=True, capturable=graphed)
-        step = TrainStep(m, opt, amp=True)
+        step = TrainStep(m, opt, amp=True, amp_dtype=amp_dtype)
         if graphed:
             step = GraphedTrainStep(step, warmup=2)
             # the two warm-up steps run on the first batch: replay the same schedule eagerly below
@@ -176,3 +179,62 @@ def test_graphed_train_step_draws_fresh_dropout_masks_at_every_replay():
     with torch.no_grad():
         a, b = m(x)[0], m(x)[0]
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("capturable", [False, True])
+@pytest.mark.parametrize("use_gcnorm", [False, True])
+def test_ranger_under_gradscaler_without_the_unscale_pass(capturable, use_gcnorm):
+    """torch.amp.GradScaler with an optimizer that declares _step_supports_amp_scaling (as torch's fused Adam): the scaler hands
+    the loss scale and the overflow flag over as device tensors.  (i) Steps on gradients that still carry the scale 2^16 equal --
+    bit for bit -- the steps of a twin optimizer fed the unscaled gradients (the scale is a power of two), both RAdam branches
+    and a lookahead step included; (ii) an overflowed step (inf in one gradient) moves nothing: parameters, moments, and -- in
+    capturable mode, where the skip is decided on the device -- the device-side step counter; the scale halves; (iii) the next
+    clean step continues as if the skipped one had never happened (learning/engine.py:117-122 semantics)."""
+    from brats21_amd.optim import Ranger2020
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(12, 5, 3, 3, 3), (12,), (7, 12, 1, 1, 1), (3000,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=gen).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    kw = dict(lr=3e-3, alpha=0.5, k=3, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5, use_gcnorm=use_gcnorm, capturable=capturable)
+    with contextlib.redirect_stdout(io.StringIO()):
+        oa, ob = Ranger2020(pa, **kw), Ranger2020(pb, **kw)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 16, growth_interval=10 ** 6)
+    assert oa._step_supports_amp_scaling
+    scaler.scale(torch.zeros(1, device=DEV))  # (the scaler allocates its device scalars at the first scale() call)
+
+    def grads(overflow=False):
+        gs = [torch.randn(s, generator=gen) * 0.05 for s in shapes]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad = (g * 2.0 ** 16).to(DEV)   # what a backward of scaler.scale(loss) leaves
+            q.grad = g.to(DEV)
+        if overflow:
+            pa[2].grad[3, 4] = float("inf")
+
+    def scaled_step():
+        scaler.step(oa)   # no scaler.unscale_(): the optimizer reads g / scale itself
+        scaler.update()
+
+    for _ in range(7):   # k = 3: lookahead at steps 3 and 6; N_sma crosses its threshold at step 6
+        grads()
+        scaled_step()
+        ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p.detach(), q.detach())
+    before = [p.detach().clone() for p in pa]
+    mom = [oa.state[p]["exp_avg"].clone() for p in pa]
+    grads(overflow=True)
+    scaled_step()
+    assert float(scaler.get_scale()) == 2.0 ** 15
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, pa))
+    assert all(torch.equal(a, oa.state[p]["exp_avg"]) for a, p in zip(mom, pa))
+    if capturable:
+        oa.sync_steps()
+    assert oa.state[pa[0]]["step"] == 7, oa.state[pa[0]]["step"]
+    # the clean step after the skipped one: the twin simply takes its 8th step (scale now 2^15)
+    gs = [torch.randn(s, generator=gen) * 0.05 for s in shapes]
+    for p, q, g in zip(pa, pb, gs):
+        p.grad, q.grad = (g * 2.0 ** 15).to(DEV), g.to(DEV)
+    scaled_step()
+    ob.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p.detach(), q.detach())
