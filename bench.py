@@ -66,7 +66,7 @@ def cpu_baseline(width, cores):
 
 
 def parity_mode_leg(args, dev, x, t):
-    """The 1e-3-logit-parity configurations of the SAME workload, 2 warm-up + 5 timed training steps each, plus the logit
+    """The 1e-3-logit-parity configurations of the SAME workload, 4 warm-up + 8 timed training steps (exact f32: 2 + 4), plus the logit
     error of each mode against the CPU oracle on one patch of the bench's own image with the bench's own initial weights
     (the oracle is only the checker here):
       * model.precision = "x3": f32 tensors, the 3x3x3 convolutions as three fp16-pair MFMA products with f32 accumulation
@@ -98,21 +98,22 @@ def parity_mode_leg(args, dev, x, t):
         with contextlib.redirect_stdout(io.StringIO()):
             opt = Ranger2020(m.parameters(), lr=1e-4, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5)
         step = TrainStep(m, opt, criterion=None, amp=False)
-        for _ in range(2):
+        nw, nt = (4, 8) if prec == "x3" else (2, 4)  # (x3: a 2 + 5 leg read 0.3 ms high beside 10 + 30, 4 + 8 does not; f32: 145 ms / step)
+        for _ in range(nw):
             step(x, t)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(nt):
             step(x, t)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
+        ms = (time.perf_counter() - t0) / nt * 1e3
         legs[prec] = {"dtype": prec, "ms_per_step": round(ms, 2), "patches_per_s": round(x.shape[0] / ms * 1e3, 2),
                       "logit_err": float(f"{err:.3e}")}
     out = dict(legs["x3"])
     out.update({"dtype": "x3 (f32 storage; 3x3x3 convolutions = 3 fp16-pair MFMA products, f32 accumulate)", "logit_bar": 1e-3,
                 "logit_absmax": round(float(ref.abs().max()), 2), "fp32_exact": legs["fp32"],
-                "note": "model.precision='x3' (csrc/conv_igemm_x3.hpp) beside 'fp32' (exact-f32 MFMA): same batch / optimizer, 2 warm-up "
-                        "+ 5 timed steps; logit_err = max abs difference of the main head to the CPU oracle (oracle/unet.py) on "
+                "note": "model.precision='x3' (csrc/conv_igemm_x3.hpp) beside 'fp32' (exact-f32 MFMA): same batch / optimizer, 4 warm-up "
+                        "+ 8 timed steps (f32: 2 + 4); logit_err = max abs difference of the main head to the CPU oracle (oracle/unet.py) on "
                         "patch 0 with the initial weights"})
     return out
 
