@@ -171,7 +171,8 @@ def other_configs_legs(dev, rank, patch=128):
     legs["fp16_mode"] = side_train_leg(
         dev, rank, "equiunet", 48, 2, "fp16", 5, 10,
         "the headline workload (equiunet width=48, 2 x 4x128^3) in the REFERENCE's own arithmetic: torch.autocast(float16) + "
-        "GradScaler loop (learning/engine.py:304,117-122), fp16 MFMA kernels", patch=patch)
+        "GradScaler loop (learning/engine.py:304,117-122), fp16 MFMA kernels; Ranger2020(capturable=True) takes the scaler's loss scale / "
+        "overflow flag as device tensors (the _step_supports_amp_scaling protocol): no unscale pass, no host read per step", patch=patch)
     legs["configs4_per_gpu"] = side_train_leg(
         dev, rank, "equiunet_assp_evo", 64, 4, "fp16", 3, 6,
         "equiunet_assp_evo width=64, 4 patches of 4x128^3 per GPU, fp16 storage + e4m3 MFMA convolutions forward / input gradient / "
