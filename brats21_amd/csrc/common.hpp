@@ -70,6 +70,9 @@ template <typename T, int N> struct Vec;
 template <> struct Vec<float, 4> {
   static DEVI void load(const float* p, float* o) { f32x4 v = *(const f32x4*)p; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
   static DEVI void store(float* p, const float* o) { f32x4 v = {o[0], o[1], o[2], o[3]}; *(f32x4*)p = v; }
+  // (non-temporal forms: the f32 tensors of the split-precision mode at the 128^3 level are 805 MB each)
+  static DEVI void load_nt(const float* p, float* o) { f32x4 v = __builtin_nontemporal_load((const f32x4*)p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+  static DEVI void store_nt(float* p, const float* o) { f32x4 v = {o[0], o[1], o[2], o[3]}; __builtin_nontemporal_store(v, (f32x4*)p); }
 };
 template <> struct Vec<bf16_t, 4> {
   static DEVI void load(const bf16_t* p, float* o) {
@@ -110,12 +113,14 @@ template <> struct Vec<bf16_t, 8> {
     __builtin_nontemporal_store(v, (u32x4*)p);
   }
 };
-// streaming access with a compile-time policy (NT only exists for the bf16 x 8 vectors of the hot kernels)
+// streaming access with a compile-time policy (NT exists for the 16-byte vectors: bf16 x 8, f32 x 4)
 template <typename T, int N, bool NT> DEVI void vload(const T* p, float* o) {
-  if constexpr (NT && std::is_same<T, bf16_t>::value && N == 8) Vec<bf16_t, 8>::load_nt(p, o); else Vec<T, N>::load(p, o);
+  if constexpr (NT && ((std::is_same<T, bf16_t>::value && N == 8) || (std::is_same<T, float>::value && N == 4))) Vec<T, N>::load_nt(p, o);
+  else Vec<T, N>::load(p, o);
 }
 template <typename T, int N, bool NT> DEVI void vstore(T* p, const float* o) {
-  if constexpr (NT && std::is_same<T, bf16_t>::value && N == 8) Vec<bf16_t, 8>::store_nt(p, o); else Vec<T, N>::store(p, o);
+  if constexpr (NT && ((std::is_same<T, bf16_t>::value && N == 8) || (std::is_same<T, float>::value && N == 4))) Vec<T, N>::store_nt(p, o);
+  else Vec<T, N>::store(p, o);
 }
 // tensors from this size on are streamed with the non-temporal hints: they cannot stay in the 256 MB Infinity Cache
 // anyway.  Smaller ones must NOT be: a 100 MB tensor that the producer kernel has just written is served from the cache

@@ -5,6 +5,15 @@
 // group variance, x*sigmoid(x) numerator).
 #include "twin_begin.hpp"
 #include "common.hpp"
+
+// beyond the Infinity Cache (256 MB): non-temporal streaming on more, shorter-lived blocks (common.hpp stream_nt); f32 tensors are
+// the split-precision mode's (2 x 128^3 x 48 x 4 B = 805 MB)
+static inline bool big_tensor(int dtype, size_t elems) {
+#ifdef BRATS_NO_F32_NT  // (A/B builds)
+  if (dtype != BRATS_BF16) return false;
+#endif
+  return stream_nt(elems * (dtype == BRATS_BF16 ? 2 : 4));
+}
 #include "se.hpp"
 
 // ---- statistics finalize ---------------------------------------------------------------------------
@@ -334,12 +343,16 @@ extern "C" int BRATS_API(brats_affine_act_fwd)(const void* y, int ypitch, const 
     BRATS_FAIL(BRATS_E_ARG, "affine_act_fwd: C and pitches must be multiples of %d (C <= %d)", vw, 256 * vw);
   const int vl = 256 / (C / vw);
   const int gx = (voxels + vl * 8 - 1) / (vl * 8);
-  const int cap = (dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2)) ? 8192 : 2048;
+  const bool big = big_tensor(dtype, (size_t)N * voxels * C);
+  const int cap = big ? 8192 : 2048;
   dim3 grid(gx < 1 ? 1 : (gx > cap ? cap : gx), N);  // large tensors: many short-lived blocks stream faster (scripts/probes/stream_rw.hip)
   hipStream_t st = (hipStream_t)s;
   uint32_t* am = (uint32_t*)amax;
-  if (dtype == BRATS_BF16 && act <= BRATS_ACT_LEAKY && stream_nt((size_t)N * voxels * C * 2)) {
+  if (dtype == BRATS_BF16 && act <= BRATS_ACT_LEAKY && big) {
     hipLaunchKernelGGL((affine_act_kernel<bf16_t, false, true>), grid, dim3(256), 0, st, (const bf16_t*)y, ypitch, scale_shift, (bf16_t*)z,
+                       zpitch, act, slope, voxels, C, am);
+  } else if (dtype != BRATS_BF16 && act <= BRATS_ACT_LEAKY && big) {  // (split-precision mode: f32 tensors of 805 MB at the 128^3 level)
+    hipLaunchKernelGGL((affine_act_kernel<float, false, true>), grid, dim3(256), 0, st, (const float*)y, ypitch, scale_shift, (float*)z,
                        zpitch, act, slope, voxels, C, am);
   } else if (act > BRATS_ACT_LEAKY) {
     if (dtype == BRATS_BF16)
@@ -1015,7 +1028,7 @@ static int gn_act_bwd_impl(const void* dz, int dzpitch, const void* y, int ypitc
     BRATS_FAIL(BRATS_E_ARG, "gn_act_bwd: C=%d / pitches must be multiples of %d", C, vw);
   const int cv = C / vw, vl = 256 / cv;
   const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
-  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const bool big = big_tensor(dtype, (size_t)N * voxels * C);
   const int cap1 = big ? GN_BWD_MAX_BLOCKS : 512;
   dim3 g1(gx < 1 ? 1 : (gx > cap1 ? cap1 : gx), N);
   const size_t lds1 = (size_t)(vl * C * 2 + (K > 0 ? vl * K : 0)) * sizeof(float);
@@ -1024,14 +1037,17 @@ static int gn_act_bwd_impl(const void* dz, int dzpitch, const void* y, int ypitc
 #define GN_BWD_GO(T, HEAVY, NT, HK) gn_bwd_launch<T, HEAVY, NT, HK>(g1, g2, lds1, lds2, st, dz, dzpitch, y, ypitch, scale_shift, mean_rstd, \
                                                                   gamma, dy, dypitch, red, dgamma, dbeta, act, slope, N, voxels, C, groups, amax, hf)
   if (K < 0) {  // the pool-source form (relu / leakyrelu: checked by the caller)
-    if (big) GN_BWD_GO(bf16_t, false, true, -1);
+    if (big && dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, true, -1);
+    else if (big) GN_BWD_GO(float, false, true, -1);
     else if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, -1);
     else GN_BWD_GO(float, false, false, -1);
   } else if (K) {  // (relu / leakyrelu, three logit planes: checked by the caller)
-    if (big) GN_BWD_GO(bf16_t, false, true, 3);
+    if (big && dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, true, 3);
+    else if (big) GN_BWD_GO(float, false, true, 3);
     else if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, false, 3);
     else GN_BWD_GO(float, false, false, 3);
-  } else if (big && act <= BRATS_ACT_LEAKY) GN_BWD_GO(bf16_t, false, true, 0);
+  } else if (big && act <= BRATS_ACT_LEAKY && dtype == BRATS_BF16) GN_BWD_GO(bf16_t, false, true, 0);
+  else if (big && act <= BRATS_ACT_LEAKY) GN_BWD_GO(float, false, true, 0);
   else if (act > BRATS_ACT_LEAKY) {
     if (dtype == BRATS_BF16) GN_BWD_GO(bf16_t, true, false, 0);
     else GN_BWD_GO(float, true, false, 0);
@@ -1101,11 +1117,14 @@ extern "C" int BRATS_API(brats_gn_act_bwd_tiles)(const float* tile_stats, int ti
   hipLaunchKernelGGL(gn_bwd_tiles_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, splits, N, C, groups, mean_rstd, red);
   const int cv = C / vw, vl = 256 / cv;
   const int gx = (int)(((size_t)voxels + vl * 8 - 1) / (vl * 8));
-  const bool big = dtype == BRATS_BF16 && stream_nt((size_t)N * voxels * C * 2);
+  const bool big = big_tensor(dtype, (size_t)N * voxels * C);
   dim3 g2(gx < 1 ? 1 : (gx > (big ? 8192 : 2048) ? (big ? 8192 : 2048) : gx), N);
   const size_t lds2 = (size_t)2 * groups * sizeof(float);
   const SlopeArg sl{slope, nullptr};
-  if (dtype == BRATS_F32)
+  if (dtype == BRATS_F32 && big)
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false, true, 0>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y, ypitch,
+                       scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, sl, N, voxels, C, groups, (uint32_t*)amax, HeadFold{});
+  else if (dtype == BRATS_F32)
     hipLaunchKernelGGL((gn_bwd_apply_kernel<float, false, false, 0>), g2, dim3(256), lds2, st, (const float*)dz, dzpitch, (const float*)y, ypitch,
                        scale_shift, mean_rstd, gamma, red, (float*)dy, dypitch, dgamma, dbeta, act, sl, N, voxels, C, groups, (uint32_t*)amax, HeadFold{});
   else if (big)
