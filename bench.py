@@ -172,7 +172,7 @@ def other_configs_legs(dev, rank, patch=128):
         dev, rank, "equiunet", 48, 2, "fp16", 5, 10,
         "the headline workload (equiunet width=48, 2 x 4x128^3) in the REFERENCE's own arithmetic: torch.autocast(float16) + "
         "GradScaler loop (learning/engine.py:304,117-122), fp16 MFMA kernels; Ranger2020(capturable=True) takes the scaler's loss scale / "
-        "overflow flag as device tensors (the _step_supports_amp_scaling protocol): no unscale pass, no host read per step", patch=patch)
+        "overflow flag as device tensors (the _step_supports_amp_scaling protocol): no unscale WRITE pass and no host read per step (the scaler's inf check still reads every gradient once)", patch=patch)
     legs["configs4_per_gpu"] = side_train_leg(
         dev, rank, "equiunet_assp_evo", 64, 4, "fp16", 3, 6,
         "equiunet_assp_evo width=64, 4 patches of 4x128^3 per GPU, fp16 storage + e4m3 MFMA convolutions forward / input gradient / "
@@ -184,8 +184,9 @@ def other_configs_legs(dev, rank, patch=128):
 
 
 def gpu_count_without_hip():
-    """GPUs of this node read from the KFD topology in sysfs -- no HIP / HSA call, so the launcher process stays a process that
-    never initialised the GPU (torch.cuda.device_count() may fall through to hipGetDeviceCount).  None = unknown."""
+    """GPUs this process may use, read from the KFD topology in sysfs and the *_VISIBLE_DEVICES masks -- no HIP / HSA call, so
+    the launcher process stays a process that never initialised the GPU (torch.cuda.device_count() may fall through
+    to hipGetDeviceCount; ADVICE r5: a device mask narrower than the node must narrow the count).  None = unknown."""
     import glob
     nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
     if not nodes:
@@ -198,6 +199,22 @@ def gpu_count_without_hip():
             return None
         if int(props.get("simd_count", "0")) > 0:
             n += 1
+    # ROCR_VISIBLE_DEVICES filters what the runtime enumerates, HIP_ / CUDA_VISIBLE_DEVICES what HIP shows of that: each is a
+    # comma list of indices (or GPU-<uuid> names); an entry that cannot be an index of the narrower list ends the list
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        mask = os.environ.get(var)
+        if mask is None:
+            continue
+        seen = 0
+        for item in mask.split(","):
+            item = item.strip()
+            if item.isdigit():
+                if int(item) >= n:
+                    break
+            elif not item.startswith("GPU-"):
+                break
+            seen += 1
+        n = min(n, seen)
     return n
 
 
@@ -297,29 +314,187 @@ def inference_bench(model, dev, args):
     return legs
 
 
-def launch_ranks(n, argv, dry_run=False):
-    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv> as a child process; its stdout (rank
-    0's one JSON line) and stderr are relayed, its exit code returned.  Called before any HIP call of this process."""
+def rank_cpu_sets(n):
+    """Disjoint CPU sets for the n ranks of this node: the CPUs this process may run on (sched_getaffinity), dealt out in
+    n contiguous slices (contiguous ids share a core complex / NUMA node on the EPYC hosts of MI355X nodes).  A rank whose
+    enqueue thread migrates between sockets, or eight ranks' OpenMP pools each spawning one thread per core, is the classic
+    way a launch-bound eager step loses its scaling.  None when there are fewer CPUs than ranks."""
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // n
+    if per < 1:
+        return None
+    return [cpus[r * per:(r + 1) * per] for r in range(n)]
+
+
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        elif part:
+            out.append(int(part))
+    return out
+
+
+def gpu_local_cpus():
+    """Per GPU of this node (KFD node order = HIP device order when no *_VISIBLE_DEVICES mask reorders it): the CPUs of the NUMA
+    node its PCIe root hangs off, from /sys/bus/pci/devices/<domain:bus:dev.fn>/local_cpulist.  sysfs only, no HIP call.
+    None when the topology cannot be read."""
+    import glob
+    out = []
+    nodes = sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda p: int(p.split("/")[-2]))
+    for p in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(p) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            out.append(_cpulist(open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read()))
+        except (OSError, KeyError, ValueError):
+            return None
+    return out or None
+
+
+def pin_rank_to_cpus():
+    """Called by every rank BEFORE its first GPU call: give this rank its own CPU set (process affinity + torch thread count).
+    Source, in order: BRATS_RANK_CPUS from launch_ranks; else (started by somebody else's torch.distributed.run) the slice is
+    computed here from LOCAL_RANK / LOCAL_WORLD_SIZE -- among the CPUs next to this rank's GPU when sysfs tells (and no device
+    mask is in force), else a contiguous slice of the affinity set.  Nothing is pinned when a rank would get fewer than 2 CPUs.
+    Returns {"cpus": "a-b", "n": count, "source": ...} or None."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    nloc = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if os.environ.get("BRATS_NO_PIN") or nloc <= 1:
+        return None
+    mine, source = None, None
+    spec = os.environ.get("BRATS_RANK_CPUS")
+    if spec:
+        sets = spec.split(";")
+        if local < len(sets) and sets[local]:
+            mine, source = [int(c) for c in sets[local].split(",")], "launcher (BRATS_RANK_CPUS)"
+    if mine is None:
+        allowed = sorted(os.sched_getaffinity(0))
+        masked = any(os.environ.get(v) is not None for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        near = None if masked else gpu_local_cpus()
+        if near is not None and len(near) == nloc:
+            # the ranks whose GPUs share a NUMA node split that node's CPUs between them, in rank order
+            key = tuple(near[local])
+            peers = [r for r in range(nloc) if tuple(near[r]) == key]
+            pool = [c for c in near[local] if c in set(allowed)]
+            per = len(pool) // len(peers)
+            if per >= 2:
+                i = peers.index(local)
+                mine, source = pool[i * per:(i + 1) * per], "CPUs of the GPU's NUMA node (sysfs local_cpulist), split between its ranks"
+        if mine is None:
+            sets = rank_cpu_sets(nloc)
+            if sets is not None:
+                mine, source = sets[local], "contiguous slice of the affinity set"
+    if not mine or len(mine) < 2:
+        return None
+    try:
+        os.sched_setaffinity(0, set(mine))
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(8, len(mine))))
+    return {"cpus": f"{min(mine)}-{max(mine)}" if mine == list(range(min(mine), max(mine) + 1)) else ",".join(map(str, mine)),
+            "n": len(mine), "source": source}
+
+
+_RANK_ENV = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_NAME",
+             "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+             "TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+             "BRATS_RANK_CPUS")
+
+
+def run_ranks(n, argv, env, timeout_s):
+    """One `python -m torch.distributed.run` child over n ranks, in its own process group (on a timeout exactly that group is
+    killed -- the agent AND its rank processes); returns (rc, [JSON lines of rank 0], other stdout lines).  rc 124 = timed out."""
+    import signal
     import socket
     import subprocess
-    if not dry_run and os.environ.get("BRATS_DIST_BACKEND") != "gloo":  # (gloo: the debugging set-up with ranks sharing a GPU)
-        have = gpu_count_without_hip()  # (sysfs; unknown -> the ranks' own device / WORLD_SIZE checks fail loudly instead)
-        if have is not None and have < n:
-            print(f"bench.py: --gpus {n} but this node has {have} GPU(s)", file=sys.stderr)
-            return 2
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # (start_new_session: the child's pid is its process-group id)
+        except ProcessLookupError:
+            pass
+        out, _ = proc.communicate()
+        rc = 124
+    out = out or ""
+    js = [l for l in out.splitlines() if l.lstrip().startswith("{")]
+    other = [l for l in out.splitlines() if not l.lstrip().startswith("{")]
+    return rc, js, other
+
+
+def graph_ddp_leg(n, argv, base_env):
+    """The second leg of an N > 1 run, in FRESH rank processes (a child torch.distributed.run of the caller): the same workload
+    with the whole step -- forward, fused Dice, the backward program pushing into the gradient buckets, the buckets' RCCL
+    all-reduces, Ranger2020 -- captured once and replayed as ONE hipGraph per rank (--graph, BRATS_GRAPH_DDP=1).  One launch per
+    step takes the ~400 kernel enqueues per step off every rank's host thread, which is what decides the scaling when the
+    eager step is enqueue-bound (compare host_enqueue_ms with ms_per_step).  This path has never run on more than one GPU (this
+    pool has 1-GPU boxes): it can only ADD information.  Returns the "graph_ddp" record: rc 0 + its numbers, or the exit code
+    (124 = timed out and killed) + the tail of what it said; it is never retried and cannot change the eager headline."""
+    env = {k: v for k, v in base_env.items() if k not in _RANK_ENV}
+    env["BRATS_GRAPH_DDP"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    drop = {"--graph", "--no-graph-leg", "--kernel-table"}
+    leg_argv = [a for a in argv if a not in drop] + ["--graph", "--no-graph-leg", "--no-cpu-baseline"]
+    t0 = time.perf_counter()
+    try:
+        rc, js, other = run_ranks(n, leg_argv, env, float(base_env.get("BRATS_GRAPH_LEG_TIMEOUT", "300")))
+    except Exception as e:
+        return {"rc": -1, "error": repr(e)[:300]}
+    leg = {"rc": rc, "wall_s": round(time.perf_counter() - t0, 1),
+           "what": "same workload, whole step incl. the bucketed RCCL all-reduces replayed as ONE hipGraph per rank (--graph, "
+                   "BRATS_GRAPH_DDP=1) in fresh rank processes after the eager headline; rc != 0: the capture / replay failed "
+                   "(124: hung, killed) and was not retried"}
+    if rc == 0 and js:
+        g = json.loads(js[-1])
+        leg.update({"ms_per_step": g.get("ms_per_step"), "value": g.get("value"), "unit": g.get("unit"), "n_gpus": g.get("n_gpus"),
+                    "host_enqueue_ms": g.get("host_enqueue_ms"), "loss": g.get("config", {}).get("loss"), "ddp": g.get("ddp")})
+    else:
+        leg["stdout_tail"] = " | ".join(other[-6:])[-800:]
+    return leg
+
+
+def launch_ranks(n, argv, dry_run=False):
+    """Started bare with --gpus N: run the N ranks as CHILD processes of this one, which never touches the GPU.
+    Leg 1 (the headline) is the eager data-parallel step; its JSON line is the line of this run.  Leg 2 (graph_ddp_leg) runs only
+    after leg 1 succeeded and only for the default eager headline, and lands on the line as "graph_ddp"."""
+    if not dry_run and os.environ.get("BRATS_DIST_BACKEND") != "gloo":  # (gloo: the debugging set-up with ranks sharing a GPU)
+        have = gpu_count_without_hip()  # (sysfs; unknown -> the ranks' own device / WORLD_SIZE checks fail loudly instead)
+        if have is not None and have < n:
+            print(f"bench.py: --gpus {n} but this node has {have} GPU(s)", file=sys.stderr)
+            return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout.splitlines():  # stdout carries the JSON line only; library chatter of the ranks goes to stderr
-        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
+    env.setdefault("OMP_NUM_THREADS", "8")  # (each rank narrows its own torch pool to its CPU slice: pin_rank_to_cpus)
+    want_graph_leg = not dry_run and "--graph" not in argv and "--no-graph-leg" not in argv and env.get("BRATS_DIST_BACKEND") != "gloo"
+    rc, js, other = run_ranks(n, list(argv) + (["--no-graph-leg"] if want_graph_leg else []), env,
+                              float(env.get("BRATS_LEG_TIMEOUT", "1800")))
+    for line in other:
+        print(line, file=sys.stderr)
+    line = js[-1] if js else None
+    if rc == 0 and line is not None and want_graph_leg:
+        try:
+            rec = json.loads(line)
+            rec["graph_ddp"] = graph_ddp_leg(n, argv, env)
+            line = json.dumps(rec)
+        except Exception as e:  # the headline line must get out whatever the extra leg did
+            print(f"bench.py: graph leg bookkeeping failed: {e!r}", file=sys.stderr)
+    if line is not None:
+        print(line)
     sys.stdout.flush()
-    return proc.returncode
+    return rc
 
 
 def dry_run(args):
@@ -375,6 +550,8 @@ def main():
                          "gradients (all) on the e4m3 MFMA kernel (BASELINE.json configs[4]); weight gradients stay bf16")
     ap.add_argument("--dropout", type=float, default=0.0, help="NOT the headline configuration: --dropout p of the reference's CLI")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
+    ap.add_argument("--no-graph-leg", action="store_true",
+                    help="bare --gpus N > 1: do not run the second leg (the step incl. its RCCL all-reduces as one hipGraph, fresh ranks)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: every rank joins the process group (gloo on CPU), one all-reduce, rank 0 "
                          "prints {n_gpus, dry_run}; no GPU is touched (tests/test_bench_launch_cpu.py)")
@@ -395,11 +572,25 @@ def main():
     from brats21_amd.optim import Ranger2020
 
     assert os.path.exists(LIB_PATH), "HIP extension missing"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL's peer buffers need it on these hosts)
+    pin = pin_rank_to_cpus()  # before the first GPU call of this rank
     rank, world, local = init_process_group_from_env()
     if world != args.gpus:  # never measure world 1 under an n_gpus = N label
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has WORLD_SIZE={world}")
     local = local % max(torch.cuda.device_count(), 1)  # (two ranks may share one GPU under BRATS_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
+    # BRATS_FORCE_DDP=rccl at world 1: the REHEARSAL of an N > 1 run on a 1-GPU box -- a real RCCL communicator over one rank,
+    # every bucket's all-reduce a real asynchronous RCCL launch, the whole `ddp` block and the graph leg of the line exercised
+    rehearsal = world == 1 and os.environ.get("BRATS_FORCE_DDP") == "rccl"
+    if rehearsal and not dist.is_initialized():
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    live = dist.is_initialized()  # collectives of the accounting below run whenever there is a process group
     dev = torch.device("cuda", local)
     torch.manual_seed(0)  # identical random-init weights on every rank
     ns = argparse.Namespace(model=args.model, width=args.width, norm="group", act="relu", num_classes=3, dropout=args.dropout)
@@ -417,6 +608,8 @@ def main():
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-5, foreach=True)
     buckets = GradientBuckets(model) if (world > 1 or os.environ.get("BRATS_FORCE_DDP")) else None  # BRATS_DDP_BF16=1: bf16 transport
+    if rehearsal:
+        buckets.force_collectives = True
     size = (args.patch,) * 3
     x = synth.random_image(args.batch, 4, size, seed=1234 + rank, device=dev)
     t = synth.nested_spheres(args.batch, size, device=dev)
@@ -451,7 +644,7 @@ def main():
         else:
             dist.barrier()
 
-    if world > 1:
+    if live:
         barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -460,8 +653,11 @@ def main():
         if buckets is not None and not args.graph:
             buckets.measure = i in sample_at  # two HIP events around the collective waits of the sampled steps
         loss = step()
+    # host side of the timed steps: the enqueue thread is done here, the GPU is not.  host_enqueue_ms close to ms_per_step = the
+    # step is bound by this rank's Python / launch path, not by the GPU (an upper bound: a full HIP queue blocks the enqueue)
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3
     torch.cuda.synchronize()
-    if world > 1:
+    if live:
         barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
@@ -472,8 +668,12 @@ def main():
         # (nothing is sampled under --graph: timing events cannot be recorded into a replayed graph -> exposed / overlap
         #  are reported as null, never as a made-up 0.0 / 1.0)
         exp_mine = buckets.exposed_ms()
-        mine = torch.tensor([elapsed / args.steps * 1e3, float("nan") if exp_mine is None else exp_mine], device=dev, dtype=torch.float64)
-        if world > 1:
+        mine = torch.tensor([elapsed / args.steps * 1e3, float("nan") if exp_mine is None else exp_mine, host_enqueue_ms,
+                             float(pin["n"]) if pin else 0.0], device=dev, dtype=torch.float64)
+        # ranks_seen: a 1 from every rank summed by the collective library itself (what the job's RCCL communicator spans)
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        if live:
+            dist.all_reduce(ones)
             both = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(both, mine)
         else:
@@ -481,20 +681,24 @@ def main():
         ar = buckets.allreduce_ms()
         exps = [float(b[1]) for b in both]
         exposed = None if any(e != e for e in exps) else max(exps)  # NaN = not measured on that rank
-        ddp_info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+        ddp_info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "ranks_seen": int(round(float(ones.item()))),
                     "backend": dist.get_backend() if dist.is_initialized() else None,
                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-                    "ms_per_step_by_rank": [round(float(b[0]), 3) for b in both], "buckets": len(buckets._plan),
+                    "ms_per_step_by_rank": [round(float(b[0]), 3) for b in both],
+                    "host_enqueue_ms_by_rank": [round(float(b[2]), 3) for b in both],
+                    "host_enqueue_ms": round(max(float(b[2]) for b in both), 3),
+                    "cpus_per_rank": [int(b[3]) for b in both], "cpu_pinning_rank0": pin,
+                    "buckets": len(buckets._plan),
                     "payload_MB": round(buckets.payload_bytes() / 1e6, 1), "comm_dtype": str(buckets.comm_dtype).replace("torch.", ""),
                     "allreduce_ms": round(ar, 3), "exposed_ms": None if exposed is None else round(exposed, 3),
                     "overlap_frac": round(max(0.0, 1.0 - exposed / ar), 3) if (ar > 0 and exposed is not None) else None,
                     "graph_captured_collectives": bool(args.graph)}
-    if world > 1:
+    if live:
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
     if rank != 0:
-        if world > 1:
+        if live:
             dist.destroy_process_group()
         return
 
@@ -566,7 +770,7 @@ def main():
     res = {
         "metric": f"train patches/sec (4x{args.patch}^3, width-{args.width})", "value": round(patches / elapsed, 4), "unit": "patches/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "host_enqueue_ms": round(host_enqueue_ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision + (f"+e4m3 conv ({args.fp8})" if args.fp8 else ""), "data": "synthetic",
         "config": {"workload": f"{args.model} width={args.width}, batch={args.batch}/GPU of 4x{args.patch}^3 synthetic patches, "
                                f"fwd + deep-supervision Dice + bwd + {args.optimizer}" + (" as one hipGraph" if args.graph else "") +
@@ -598,9 +802,19 @@ def main():
         res.update(other_configs_legs(dev, rank, args.other_configs_patch or 128))
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.width, os.cpu_count() or 1)
+    if live:
+        backend = dist.get_backend()
+        dist.destroy_process_group()  # (the other ranks have returned already; nothing below is collective)
+        if backend == "nccl" and not args.graph and not args.no_graph_leg and not os.environ.get("BRATS_NO_GRAPH_LEG"):
+            # started as a rank of somebody else's torch.distributed.run (the driver's launch form): the graph + RCCL leg runs as a
+            # CHILD torch.distributed.run of rank 0 -- fresh rank processes -- after this rank gave its memory back
+            train_step = opt = model = buckets = x = t = loss = crit = None  # noqa: F841 (drop every reference to device memory)
+            torch.cuda.empty_cache()
+            try:
+                res["graph_ddp"] = graph_ddp_leg(world, sys.argv[1:], dict(os.environ))
+            except Exception as e:
+                res["graph_ddp"] = {"rc": -1, "error": repr(e)[:300]}
     print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -147,7 +147,7 @@ class GradientBuckets:
             buf = self._flat[b]
             if self._wire is not None:
                 buf = self._wire[b]
-                buf.copy_(self._flat[b])
+                buf.copy_(self._flat[b])  # f32 -> bf16, one pass over the bucket on the compute stream
             self._handles[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- producer side ----------------------------------------------------------------------------
@@ -227,11 +227,11 @@ class GradientBuckets:
         if ev is not None:
             ev[1].record()
             self.exposed.append(ev)
-        if self.world > 1:
-            if self._wire is not None:
-                for f, w in zip(self._flat, self._wire):
-                    f.copy_(w)
-            torch._foreach_mul_(self._flat, 1.0 / self.world)  # one multi-tensor launch instead of one mul per parameter
+        if self.world > 1 or (self.force_collectives and dist.is_initialized()):
+            if self._wire is not None:  # (what came back over the wire is the gradient, rounding included)
+                torch._foreach_copy_(self._flat, self._wire)
+            if self.world > 1:
+                torch._foreach_mul_(self._flat, 1.0 / self.world)  # one multi-tensor launch instead of one mul per parameter
         for b, bucket in enumerate(self._plan):
             for idx, off, n in bucket:
                 p = self.params[idx]
@@ -256,7 +256,7 @@ class GradientBuckets:
     def allreduce_ms(self, reps=5):
         """Blocking time of one step's collectives on scratch copies of the buckets (no compute beside them): the cost
         that overlap has to hide.  Call outside the timed region; every rank must call it."""
-        if self.world <= 1 or not self._flat:
+        if (self.world <= 1 and not (self.force_collectives and dist.is_initialized())) or not self._flat:
             return 0.0
         scratch = [torch.zeros_like(w) for w in (self._wire or self._flat)]
         on_gpu = scratch[0].is_cuda

@@ -183,8 +183,14 @@ class _PackedWeightsModule(nn.Module):
         if not 0.0 <= float(p) < 1.0:
             raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
         self.dropout_p = float(p)
-        # (data-parallel ranks build identical replicas under one torch seed: the rank is mixed in so that they draw different masks)
-        seed = (int(torch.randint(0, 2 ** 62, (1,))) + 0x9E3779B97F4A7C15 * int(os.environ.get("RANK", "0"))) % (2 ** 63)
+        # The seed comes from a PRIVATE generator seeded with torch.initial_seed(): constructing a model never advances the global
+        # CPU generator (the initial weights under a given torch.manual_seed do not depend on --dropout), and p = 0 draws
+        # nothing.  Data-parallel ranks build identical replicas under one torch seed: the rank is mixed in at the first forward
+        # (RANK of the launcher, else torch.distributed's rank) so that they draw different masks.
+        seed = 0
+        if self.dropout_p > 0.0:
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=torch.Generator().manual_seed(torch.initial_seed())))
+        self._dropout_seed_base, self._dropout_rank_mixed = seed, self.dropout_p == 0.0
         self.register_buffer("_dropout_state", torch.tensor([seed, 0], dtype=torch.int64), persistent=False)
 
     def _advance_dropout(self, device):
@@ -192,6 +198,13 @@ class _PackedWeightsModule(nn.Module):
         returned copy belongs to this forward / backward pair."""
         if self._dropout_state.device != device:
             raise BratsHipError("brats21_amd: module and input are on different devices")
+        if not self._dropout_rank_mixed:
+            rank = os.environ.get("RANK")
+            if rank is None:
+                import torch.distributed as dist
+                rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            self._dropout_state[0] = (self._dropout_seed_base + 0x9E3779B97F4A7C15 * int(rank)) % (2 ** 63)
+            self._dropout_rank_mixed = True
         self._dropout_state[1] += 1
         return self._dropout_state.clone()
 
@@ -282,8 +295,21 @@ def _cgr_fwd(unit, x, dtype, act, out=None, x2=None, fp8=None, slots=None, no_ac
     if unit.bcn:
         # BCNorm (see _BCNormParams): EstBN's per-channel affine map rides in the convolution (weights a_c * W, bias b_c), the
         # rest is GroupNorm(8) with the group's weight / bias as per-channel gamma / beta
-        a_c, cbias, gamma_c, beta_c = unit.bn.tables()
-        w = w.detach() * a_c.view(-1, 1, 1, 1, 1)
+        if torch.is_grad_enabled():
+            a_c, cbias, gamma_c, beta_c = unit.bn.tables()
+            w = w.detach() * a_c.view(-1, 1, 1, 1, 1)
+        else:
+            # inference (~144 forwards of the same weights per volume): fold ONCE per unit -- the folded tensor stays the same
+            # object, so ops.pack_weights' cache hits and no dead entry piles up in it.  Valid while none of the
+            # tensors it was made from changed: version counters, addresses and the pack generation (writes through p.data)
+            srcs = (unit.conv.weight, unit.bn.weight, unit.bn.bias, unit.bn.bn.weight, unit.bn.bn.bias, unit.bn.bn.running_var,
+                    unit.bn.bn.running_mean)
+            key = (ops.pack_generation(),) + tuple((t._version, t.data_ptr()) for t in srcs)
+            hit = getattr(unit, "_bcn_fold", None)
+            if hit is None or hit[0] != key:
+                a_c, cbias, gamma_c, beta_c = unit.bn.tables()
+                hit = unit._bcn_fold = (key, (w.detach() * a_c.view(-1, 1, 1, 1, 1), cbias, gamma_c, beta_c))
+            w, cbias, gamma_c, beta_c = hit[1]
         fp8, lazy = None, False
     cout = w.shape[0]
     cin_pad = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)

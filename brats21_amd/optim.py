@@ -200,6 +200,10 @@ class Ranger2020(Optimizer):
             beta1, beta2 = group["betas"]
             lr, wd, k = group["lr"], group["weight_decay"], group["k"]
             plan = self._plan(gi, active, dev)
+            if self.capturable and plan.get("dyn") is None and not torch.cuda.is_current_stream_capturing():
+                # a plan about to get its device-side step counter: the host-side state['step'] runs AHEAD of the device after
+                # overflow-skipped steps (the skip is decided on the device) -- seed it from the device's truth
+                self.sync_steps()
             rec = self._table(plan, active, dev)
             keep = []
             grads = rec["grad"]

@@ -47,8 +47,8 @@ def pytest_collection_modifyitems(config, items):
     if not wanted or (deselect and not any(deselect_match(it, config) for it in wanted)):
         return
     import subprocess
-    import torch
-    if torch.cuda.device_count() < 1:  # (counting devices does not initialise the GPU)
+    from bench import gpu_count_without_hip  # sysfs + *_VISIBLE_DEVICES only: this process must not have touched HIP yet
+    if not gpu_count_without_hip():
         return
     os.makedirs(os.path.dirname(DDP_GPU_RESULT), exist_ok=True)
     for f in (DDP_GPU_RESULT, DDP_GPU_RESULT + ".err0", DDP_GPU_RESULT + ".err1"):

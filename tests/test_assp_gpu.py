@@ -580,3 +580,42 @@ def test_evonorm_backward_statistics_fold(precision):
         worst = max(worst, e)
         assert e <= tol, (name, e)
     print(f"EquiUnetASSPEvo-48 fold_bwd_stats on / off ({precision}): worst gradient difference rel-to-max {worst:.2e} (bar {tol})")
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+@pytest.mark.parametrize("beta_scale,gamma_scale", [(1.0, 1.0), (3.0, 1.0), (3.0, 0.1)])
+def test_evonorm_backward_statistics_fold_with_large_beta(precision, beta_scale, gamma_scale):
+    """brats_evonorm_bwd_tiles recovers A_g = (S2 - beta * S1) / rstd from sums over the STORED 16-bit z, so the rounding
+    of z (2^-9 relative for bf16, 2^-11 for fp16) is amplified by the cancellation when |beta| is large against gamma * num.  The
+    reference initialises beta = 0 / gamma = 1 (networks/equiunet2021.py:70-71) and trained ASSP weights stay at |beta| < 0.5; this
+    case prices |beta| up to ~3 x randn and a small gamma against the two-pass kernel (which reads x, not z) and holds the measured
+    degradation to a stated bound -- the caveat in csrc/norm.hip's header and DESIGN.md quotes these numbers."""
+    from brats21_amd import ops
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16 if precision == "bf16" else torch.float16
+    g = torch.Generator().manual_seed(9)
+    n, size, c = 2, (8, 16, 32), 48
+    x1 = torch.randn(n, *size, c, generator=g).to(dev).to(dt)
+    dy2 = (torch.randn(n, *size, c, generator=g) * 0.1).to(dev).to(dt)
+    w2 = (torch.randn(c, c, 3, 3, 3, generator=g) * 0.05).to(dev)
+    gamma = (gamma_scale * (1.0 + 0.3 * torch.randn(c, generator=g))).to(dev)
+    beta = (beta_scale * torch.randn(c, generator=g)).to(dev)
+    xf = x1.double()
+    mean = xf.view(n, -1, 8, c // 8).mean((1, 3))
+    var = xf.view(n, -1, 8, c // 8).var((1, 3), unbiased=True)
+    mr = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-5)], -1).float().contiguous()
+    chan = torch.stack([xf.sum((1, 2, 3)), (xf * xf).sum((1, 2, 3))], -1).contiguous()
+    z1, _ = ops.evonorm(x1, mr, gamma, beta, 8)
+    wpk = ops.pack_weights(w2, dt, ops.PACK_DGRAD)
+    ss = torch.zeros(n, c, 2, device=dev); ss[..., 0] = 1.0
+    dz, tiles = ops.conv3d_bstats(dy2, wpk, c, 1, z1, ss, "leakyrelu", slope=1.0)
+    a = ops.evonorm_bwd_tiles(tiles, dz, x1, mr, gamma, beta, 8, chan=chan)
+    b = ops.evonorm_bwd(dz, x1, mr, gamma, 8, chan=chan)
+    # bf16 keeps 8 mantissa bits of z, fp16 11: the bound scales with the storage's rounding and with |beta| / |gamma|
+    unit = (2.0 ** -8 if precision == "bf16" else 2.0 ** -11) * max(1.0, beta_scale / gamma_scale)
+    errs = {}
+    for name, u, v in (("dx", a[0].float(), b[0].float()), ("dgamma", a[1], b[1]), ("dbeta", a[2], b[2])):
+        errs[name] = float((u - v).abs().max() / (v.abs().max() + 1e-12))
+    print(f"\nevonorm_bwd_tiles, {precision}, |beta| ~ {beta_scale}, |gamma| ~ {gamma_scale}: " +
+          ", ".join(f"{k} rel-to-max {e:.2e}" for k, e in errs.items()) + f" (unit {unit:.2e})")
+    assert errs["dx"] < 2e-2 + 4 * unit and errs["dgamma"] < 1e-2 + 4 * unit and errs["dbeta"] < 1e-2

@@ -91,3 +91,21 @@ def test_bench_two_ranks_on_one_gpu_exercise_the_ddp_block():
     assert d["payload_MB"] > 0 and d["allreduce_ms"] > 0 and d["comm_dtype"] == "float32" and d["graph_captured_collectives"] is False
     assert d["exposed_ms"] is not None and d["exposed_ms"] >= 0 and 0.0 <= d["overlap_frac"] <= 1.0
     assert max(d["ms_per_step_by_rank"]) <= r["ms_per_step"] * 1.05  # the line reports the MAX over ranks
+
+
+def test_bench_rccl_rehearsal_eager_headline_then_graph_leg_in_fresh_ranks():
+    """The shape of the driver's N > 1 line, rehearsed on this box's one GPU over the REAL RCCL backend (BRATS_FORCE_DDP=rccl: a
+    world-1 communicator, every bucket's all-reduce a real asynchronous RCCL launch): the eager step is the headline and carries
+    the host-enqueue budget and ranks_seen in its `ddp` block; the whole step incl. the collectives as one hipGraph runs afterwards
+    in a FRESH rank process started by rank 0 and lands as `graph_ddp` with its exit code (VERDICT r5 item 1 a, b, e)."""
+    r = _bench("--width", "8", "--patch", "32", "--steps", "6", "--warmup", "3", "--no-infer", "--no-cpu-baseline", "--no-parity-leg",
+               "--no-other-configs", env={"BRATS_FORCE_DDP": "rccl"})
+    d = r["ddp"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["ranks_seen"] == 1 and d["graph_captured_collectives"] is False
+    assert d["buckets"] >= 1 and d["allreduce_ms"] > 0 and d["exposed_ms"] is not None
+    assert 0 < d["host_enqueue_ms"] <= r["ms_per_step"] * 1.05 and r["host_enqueue_ms"] > 0
+    g = r["graph_ddp"]
+    assert g["rc"] == 0, g
+    assert g["ms_per_step"] > 0 and g["n_gpus"] == 1 and g["ddp"]["graph_captured_collectives"] is True and g["ddp"]["backend"] == "nccl"
+    assert g["host_enqueue_ms"] < r["host_enqueue_ms"]  # one graph launch per step instead of a few hundred enqueues
+    assert abs(g["loss"] - r["config"]["loss"]) < 2e-2  # same workload and seed (the capture adds two eager warm-up steps)

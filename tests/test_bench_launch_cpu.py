@@ -56,3 +56,66 @@ def test_world_size_mismatch_fails_loudly():
 def test_bare_gpus_1_runs_in_process():
     p = _run(["--gpus", "1", "--dry-run"])
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_visible_devices_mask_narrows_the_gpu_count(tmp_path, monkeypatch):
+    """the launcher's GPU count is the KFD topology INTERSECTED with the *_VISIBLE_DEVICES masks (pure env parsing)."""
+    sys.path.insert(0, ROOT)
+    import glob
+    import bench
+    files = []
+    for i, simd in enumerate((0, 1024, 1024, 1024, 1024)):  # node 0 = the CPU
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\n")
+        files.append(str(d / "properties"))
+    monkeypatch.setattr(glob, "glob", lambda pat: files if "kfd" in pat else [])
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.gpu_count_without_hip() == 4
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.gpu_count_without_hip() == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.gpu_count_without_hip() == 1  # HIP's "0,2" now indexes a list of one: only entry 0 survives
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "")
+    assert bench.gpu_count_without_hip() == 0
+
+
+def test_ranks_pin_themselves_to_disjoint_cpu_sets():
+    """every rank takes its own CPU slice before its first GPU call -- from LOCAL_RANK / LOCAL_WORLD_SIZE
+    alone when somebody else's torch.distributed.run started it (the driver's launch form)."""
+    code = ("import sys, os, json; sys.path.insert(0, %r); import bench; r = bench.pin_rank_to_cpus(); "
+            "print(json.dumps({'pin': r, 'aff': sorted(os.sched_getaffinity(0))}))" % ROOT)
+    n_cpu = len(os.sched_getaffinity(0))
+    if n_cpu < 4:
+        import pytest
+        pytest.skip("needs >= 4 CPUs")
+    seen = []
+    for local in range(2):
+        env = {k: v for k, v in os.environ.items() if k not in ("BRATS_RANK_CPUS", "BRATS_NO_PIN")}
+        env.update({"LOCAL_RANK": str(local), "LOCAL_WORLD_SIZE": "2", "WORLD_SIZE": "2", "RANK": str(local)})
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rec = json.loads(p.stdout.strip().splitlines()[-1])
+        assert rec["pin"] is not None and rec["pin"]["n"] == len(rec["aff"]) == n_cpu // 2
+        seen.append(set(rec["aff"]))
+    assert not (seen[0] & seen[1])
+    # world 1: nothing to pin
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "RANK", "BRATS_RANK_CPUS")}
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert json.loads(p.stdout.strip().splitlines()[-1])["pin"] is None
+
+
+def test_graph_leg_runs_in_fresh_ranks_and_reports_a_failure_as_its_exit_code():
+    """the graph + RCCL leg is a child torch.distributed.run (fresh rank processes, rank environment of the
+    caller scrubbed); success carries its numbers, a failed child its exit code -- never an exception, never a retry.  Exercised
+    here through --dry-run (gloo, no GPU)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_PORT="1", OMP_NUM_THREADS="1")  # a rank's own environment
+    ok = bench.graph_ddp_leg(2, ["--gpus", "2", "--dry-run"], env)
+    assert ok["rc"] == 0 and ok["n_gpus"] == 2 and "stdout_tail" not in ok
+    bad = bench.graph_ddp_leg(2, ["--gpus", "3", "--dry-run"], env)  # (WORLD_SIZE 2 under a --gpus 3 label: the ranks refuse)
+    assert bad["rc"] not in (0, None) and "ms_per_step" not in bad
+    hung = bench.graph_ddp_leg(2, ["--gpus", "2", "--dry-run"], dict(env, BRATS_GRAPH_LEG_TIMEOUT="0.05"))
+    assert hung["rc"] == 124

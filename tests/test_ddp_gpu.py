@@ -121,3 +121,69 @@ def test_graphed_step_with_captured_rccl_allreduce():
         assert torch.equal(results[0][1], results[1][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_eager_step_over_rccl_world1_forced_collectives_bf16_wire_and_no_sync():
+    """The EAGER data-parallel step -- the headline path of `bench.py --gpus N` -- through the real RCCL backend (VERDICT r5 item
+    1d): world size 1 on the one GPU of the test box with the collectives forced, so that every bucket's all-reduce is a real
+    asynchronous RCCL launch behind the backward program's pushes and finish() waits on real work handles.
+      A. f32 wire, TrainStep + Ranger2020, 4 steps: parameters bit-equal to the bucket-less run (all-reduce over one rank = identity);
+      B. bf16 wire: p.grad == bf16-rounded gradient of the bucket-less run, bit for bit, pushed steps and the first (gathered) one;
+      C. bf16 wire + no_sync accumulation over two micro-batches: p.grad == bf16(2 g)."""
+    import torch.distributed as dist
+    from brats21_amd.ddp import GradientBuckets
+    from brats21_amd.engine import TrainStep
+    from brats21_amd.optim import Ranger2020
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = "29547"
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        size = (16, 16, 16)
+        x = synth.random_image(2, 4, size, seed=3).to(DEV)
+        t = synth.nested_spheres(2, size).to(DEV)
+        for name, width in (("equiunet", 8), ("equiunet_assp_evo", 16)):
+            # A
+            finals = []
+            for with_buckets in (False, True):
+                m = _make(name, width, "bf16")
+                with contextlib.redirect_stdout(io.StringIO()):
+                    opt = Ranger2020(m.parameters(), lr=1e-3, use_gc=False)
+                buckets = None
+                if with_buckets:
+                    buckets = GradientBuckets(m, bucket_bytes=1 << 18)
+                    buckets.force_collectives = True
+                    buckets.measure = True
+                step = TrainStep(m, opt, amp=True, buckets=buckets)
+                losses = [float(step(x, t).detach()) for _ in range(4)]
+                torch.cuda.synchronize()
+                finals.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).clone()))
+                if with_buckets:
+                    assert len(buckets._plan) > 1 and buckets.exposed_ms() is not None and buckets.exposed_ms() >= 0.0
+            assert finals[0][0] == finals[1][0], (name, finals[0][0], finals[1][0])
+            assert torch.equal(finals[0][1], finals[1][1]), name
+            # B, C
+            ref, m = _make(name, width, "bf16"), _make(name, width, "bf16")
+            ref.zero_grad(set_to_none=True)
+            unet.deep_supervision_loss(ref(x), t).backward()
+            buckets = GradientBuckets(m, bucket_bytes=1 << 18, comm_dtype=torch.bfloat16)
+            buckets.force_collectives = True
+            assert buckets.comm_dtype == torch.bfloat16
+            for step_no in range(3):
+                m.zero_grad(set_to_none=True)
+                unet.deep_supervision_loss(m(x), t).backward()
+                buckets.finish()
+                for (k, p), q in zip(m.named_parameters(), ref.parameters()):
+                    if q.grad is not None:
+                        assert torch.equal(p.grad, q.grad.bfloat16().float()), (name, step_no, k)
+            assert buckets.payload_bytes() == 2 * sum(p.numel() for p in ref.parameters() if p.grad is not None)
+            m.zero_grad(set_to_none=True)
+            with buckets.no_sync():
+                unet.deep_supervision_loss(m(x), t).backward()
+            unet.deep_supervision_loss(m(x), t).backward()
+            buckets.finish()
+            for (k, p), q in zip(m.named_parameters(), ref.parameters()):
+                if q.grad is not None:
+                    assert torch.equal(p.grad, (2 * q.grad).bfloat16().float()), (name, "accumulated", k)
+    finally:
+        dist.destroy_process_group()

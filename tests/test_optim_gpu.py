@@ -238,3 +238,40 @@ def test_ranger_under_gradscaler_without_the_unscale_pass(capturable, use_gcnorm
     ob.step()
     for p, q in zip(pa, pb):
         assert torch.equal(p.detach(), q.detach())
+
+
+def test_capturable_ranger_new_plan_after_a_skipped_step_starts_from_the_device_step_count():
+    """in capturable mode an overflow-skipped step advances state['step'] on the host but not the device counter.  A
+    plan built afterwards (the set of parameters with a gradient changed) must be seeded from the device's count -- otherwise
+    RAdam's rectification and the lookahead phase shift by one.  The twin never saw the skipped step."""
+    from brats21_amd.optim import Ranger2020
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(12, 5, 3, 3, 3), (12,), (7, 12, 1, 1, 1), (3000,)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=gen).to(DEV)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    kw = dict(lr=3e-3, alpha=0.5, k=3, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5, capturable=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        oa, ob = Ranger2020(pa, **kw), Ranger2020(pb, **kw)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=10 ** 6)
+    scaler.scale(torch.zeros(1, device=DEV))
+
+    def grads(scale, skip_last=False, overflow=False):
+        gs = [torch.randn(s, generator=gen) * 0.05 for s in shapes]
+        for i, (p, q, g) in enumerate(zip(pa, pb, gs)):
+            p.grad, q.grad = ((g * scale).to(DEV), g.to(DEV)) if not (skip_last and i == 3) else (None, None)
+        if overflow:
+            pa[0].grad[0, 0, 0, 0, 0] = float("inf")
+
+    for _ in range(4):
+        grads(2.0 ** 10)
+        scaler.step(oa); scaler.update(); ob.step()
+    grads(2.0 ** 10, overflow=True)
+    scaler.step(oa); scaler.update()          # skipped on the device; the host count of `oa` is now 5, the device's 4
+    assert float(scaler.get_scale()) == 2.0 ** 9
+    for _ in range(3):                        # a NEW plan (3 of the 4 parameters): steps 5, 6 (lookahead at 6: k = 3), 7
+        grads(2.0 ** 9, skip_last=True)
+        scaler.step(oa); scaler.update(); ob.step()
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        assert torch.equal(p.detach(), q.detach()), i
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert [sa[i]["step"] for i in range(3)] == [7, 7, 7] == [sb[i]["step"] for i in range(3)]
