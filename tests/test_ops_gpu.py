@@ -537,6 +537,36 @@ def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size, mode):
     assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-3)  # and each 4x4x16 entry holds the same voxels
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,size,with_bias", [(2, (32, 64, 64), True), (1, (64, 64, 128), False), (1, (36, 52, 240), True)])
+def test_conv3d_first_layer_kernel(dtype, n, size, with_bias):
+    """The first layer (4 modalities padded to 8 channels -> 48, networks/equiunet2020.py:424) on the persistent kernel of
+    csrc/conv_igemm_first.hpp (weights in registers for the whole launch, output tile through LDS into 1 KB contiguous stores):
+    (i) bit-identical outputs to the 4x8x16-tile kernel, which the same call takes when the output is a channel slice of a wider
+    buffer (same packed weights, same K order, f32 accumulation from the bias), tile statistics equal to 1e-5; every face of
+    the volume is a boundary tile, the third case has 13 and 15 tiles per row (odd counts for the persistent walk);
+    (ii) against torch's CPU f32 convolution."""
+    from brats21_amd import ops
+    dev = _dev()
+    x = _q(_rand((n, 4) + size, 61), dtype)
+    w = _q(_rand((48, 4, 3, 3, 3), 62, (2.0 / (4 * 27)) ** 0.5), dtype)
+    b = _rand((48,), 63, 0.1) if with_bias else None
+    xin = torch.zeros(n, *size, 8, dtype=dtype, device=dev)      # channels 4..7 are the zero padding the networks add
+    xin[..., :4] = _to_ndhwc(x, dtype, dev)
+    w8 = torch.zeros(48, 8, 3, 3, 3)
+    w8[:, :4] = w
+    wpk = ops.pack_weights(w8.to(dev), dtype, ops.PACK_FWD)
+    bd = b.to(dev) if with_bias else None
+    y_new, s_new = ops.conv3d(xin, wpk, 48, 3, 1, bias=bd, want_stats=True)              # dense output: the new kernel
+    wide = torch.zeros(n, *size, 96, dtype=dtype, device=dev)
+    y_old, s_old = ops.conv3d(xin, wpk, 48, 3, 1, bias=bd, want_stats=True, out=wide[..., 16:64])  # slice: the tile kernel
+    assert torch.equal(y_new, y_old.contiguous())
+    assert torch.allclose(s_new, s_old, rtol=1e-5, atol=1e-4)
+    torch.set_num_threads(16)
+    ref = F.conv3d(x, w, b, 1, 1)
+    torch.testing.assert_close(_from_ndhwc(y_new), ref, atol=_tol(dtype, 2e-5, 3e-2), rtol=_tol(dtype, 1e-5, 2e-2))
+
+
 @pytest.mark.parametrize("mode", [1])
 @pytest.mark.parametrize("cin,cin2,cout,n,size,pitch", [
     (48, 48, 48, 1, (9, 21, 37), None),   # two-source, ragged in z, y and x (every boundary mask of the halo staging)
