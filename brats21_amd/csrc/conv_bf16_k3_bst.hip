@@ -18,7 +18,7 @@ static int conv_bst_launch_ck48(const ConvParams& p, hipStream_t st) {
   // conv_launch_ck's choice among the NF = 3 roles
   if (p.rows16 % 6 == 0 && !(conv_vsplit_enabled() && (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 6) < conv_small_grid_threshold()))
     return conv_launch_one<bf16_t, 3, 48, DIL, 3, false, false, false, true>(p, st);
-  return conv_launch_one<bf16_t, 3, 48, DIL, 3, false, true, false, true>(p, st);
+  return conv_launch_nf3<bf16_t, 3, 48, DIL, true, false, true>(p, st);
 }
 
 int conv_bst_launch(const ConvParams& p, int ck, int dil, hipStream_t st) {

@@ -10,6 +10,12 @@ extern "C" int BRATS_API(brats_conv3d_set_vs8)(int mode) {
   g_conv_vs8_mode = mode < 0 ? -1 : (mode ? 1 : 0);  // 0 the 4x4x16-tile kernels, 1 conv_igemm_vs8 (4x8x16 tile)
   return old;
 }
+int g_conv_kp_mode = -1;  // -1 = BRATS_CONV_KP (default on), 0 / 1 = brats_conv3d_set_kp (conv_igemm.hpp: conv_kp_enabled)
+extern "C" int BRATS_API(brats_conv3d_set_kp)(int mode) {
+  const int old = g_conv_kp_mode;
+  g_conv_kp_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  return old;
+}
 static int conv_vs8_enabled() {
   if (g_conv_vs8_mode >= 0) return g_conv_vs8_mode;
   static int v = -1;

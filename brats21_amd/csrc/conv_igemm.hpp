@@ -85,18 +85,27 @@ struct ConvGeom {
 //   KSPLIT         : the parity of the K macro-steps (same couts and voxels, reduced through LDS)
 //   VS             : the y half (same couts, 4 voxel fragments per wave, all K: no reduction, all four waves share
 //                    the epilogue; the weight fragments are fetched twice as often)
-template <int NF, bool KSPLIT, bool VS = false> struct ConvTile {
+//   VS + KP        : (round 6) the y-split roles with EIGHT waves, for grids of at most one workgroup per CU (the 16^3 level):
+//                    two teams of four waves with the VS roles; team 0 takes the even K macro-steps of every chunk, team 1 the
+//                    odd ones, on the same LDS tile and the same output tile; team 1's partial sums reach team 0 through LDS
+//                    (aliasing the dead tile) before the epilogue.  Two waves per SIMD instead of a lone one, halo staging by
+//                    eight waves, no HBM partial-sum pass.  What it buys is small (0 .. 14 % by shape) and DESIGN.md says why:
+//                    at one workgroup per CU these roles are bound by the weight-fragment stream through the CU's vector-memory
+//                    path (3 KB per 12 MFMAs and wave ~ 64 B/clk/CU asked, ~32 delivered), which eight waves do not change.
+template <int NF, bool KSPLIT, bool VS = false, bool KP = false> struct ConvTile {
   static_assert(!(KSPLIT && VS), "one split mode at a time");
+  static_assert(!KP || VS, "the 8-wave K-parity teams sit on the y-split roles");
   static constexpr int NFW = (KSPLIT || VS) ? NF : 2 * NF;  // cout16-fragments per workgroup
   static constexpr int NB = VS ? 4 : 8;                     // voxel fragments (x-rows of 16) per wave
-  static constexpr int RED_BYTES = KSPLIT ? 2 * NF * 8 * 64 * 16 : 0;
+  static constexpr int NW = KP ? 8 : 4;                     // waves per workgroup
+  static constexpr int RED_BYTES = KSPLIT ? 2 * NF * 8 * 64 * 16 : KP ? 4 * NF * NB * 64 * 16 : 0;
   static constexpr int SRED_BYTES = (VS ? 4 : 2) * NFW * 16 * 2 * 4;
 };
 
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool KP = false>
 constexpr int conv_lds_bytes() {
   using G = ConvGeom<T, KS, CK, DIL>;
-  using TL = ConvTile<NF, KSPLIT, VS>;
+  using TL = ConvTile<NF, KSPLIT, VS, KP>;
   int a = G::LDS_TILE > TL::RED_BYTES ? G::LDS_TILE : TL::RED_BYTES;
   a = (a + 15) / 16 * 16;
   return a + TL::SRED_BYTES;
@@ -292,17 +301,18 @@ DEVI void conv_pre_load(const float* ss, int n, int csrc, int cb, int part, floa
 }
 
 // BST: backward statistics in the epilogue (ConvParams::by / bss; training, the input gradient of a block's second unit)
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false, bool BST = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false, bool BST = false, bool KP = false>
+__global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(const ConvParams p) {
   static_assert(!PRE || std::is_same<T, bf16_t>::value, "normalise-on-load exists for the 16-bit kernels");
   static_assert(!BST || (std::is_same<T, bf16_t>::value && !KSPLIT), "backward statistics exist for the 16-bit kernels without K split");
   using G = ConvGeom<T, KS, CK, DIL>;
-  using TL = ConvTile<NF, KSPLIT, VS>;
-  constexpr int NB = TL::NB, YB = NB / 2;
+  using TL = ConvTile<NF, KSPLIT, VS, KP>;
+  constexpr int NB = TL::NB, YB = NB / 2, NW = TL::NW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar row math
-  const int wm = wave & 1, wn = wave >> 1;
+  const int team = KP ? wave >> 2 : 0;                        // KP: the K-parity team; the roles below are per team
+  const int wm = wave & 1, wn = (wave >> 1) & 1;
   const int q = lane >> 4, v = lane & 15;
 
   int bt = blockIdx.x;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   constexpr int NROWS = G::HZ * G::HY;
   constexpr int PPR = G::HX * G::PPV;          // pieces per row
   constexpr int IPR = (PPR + 63) / 64;         // wave-instructions per row
-  constexpr int RPW = (NROWS + 3) / 4;         // rows per wave
+  constexpr int RPW = (NROWS + NW - 1) / NW;   // rows per wave
   int lds_off[IPR];    // byte offset of the lane's piece inside an LDS row (+ the wave's first row)
   int hx_part[IPR];    // hx * 65536 + part, or -1 when the lane has no piece / x is outside the volume
 #pragma unroll
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
   for (int f = 0; f < NF; ++f) {
     const int cbase = (f0 + f) * 16 + 4 * q;
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && cbase < p.cout && !(KSPLIT && wn == 1)) b = *(const f32x4*)(p.bias + cbase);
+    if (p.bias && cbase < p.cout && !(KSPLIT && wn == 1) && !(KP && team == 1)) b = *(const f32x4*)(p.bias + cbase);
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc[f][i] = b;
   }
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     u32x4 r[RPW][IPR];
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
-      const int row = wave + 4 * k;
+      const int row = wave + NW * k;
       const int hz = row / G::HY, hy = row % G::HY;
       const int gz = z0 - G::R + hz, gy = y0 - G::R + hy;
       const bool row_ok = row < NROWS && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;  // scalar
@@ -393,21 +403,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     if (chunk > 0) __syncthreads();  // all waves finished reading the previous chunk's tile
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
-      if (wave + 4 * k < NROWS) {
+      if (wave + NW * k < NROWS) {
 #pragma unroll
         for (int j = 0; j < IPR; ++j)
           if (lds_off[j] >= 0) {
             u32x4 val = r[k][j];
             if constexpr (PRE) {
               if (pre_ss) {  // piece by piece, right in front of its LDS write: the staged registers die as they are consumed
-                const int row = wave + 4 * k;
+                const int row = wave + NW * k;
                 const int gz = z0 - G::R + row / G::HY, gy = y0 - G::R + row % G::HY;
                 const bool row_ok = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
                 val = conv_pre_apply(val, psc[j], psh[j], p.pre_act == BRATS_ACT_LEAKY, p.pre_slope, row_ok && hx_part[j] >= 0);
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
-            *(u32x4*)(lds + lds_off[j] + k * 4 * (G::HX * G::S)) = val;
+            *(u32x4*)(lds + lds_off[j] + k * NW * (G::HX * G::S)) = val;
           }
       }
     }
@@ -416,6 +426,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     if constexpr (KSPLIT) {
       if (wn == 0) conv_mma_chunk<T, KS, CK, DIL, NF, 0>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
       else conv_mma_chunk<T, KS, CK, DIL, NF, 1>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+    } else if constexpr (KP) {
+      if (team == 0) conv_mma_chunk<T, KS, CK, DIL, NF, 0, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
+      else conv_mma_chunk<T, KS, CK, DIL, NF, 1, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     } else {
       conv_mma_chunk<T, KS, CK, DIL, NF, -1, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     }
@@ -440,11 +453,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     }
   }
 
+  // --- K-parity teams: team 1's partial sums through LDS (the tile is dead) into team 0, which runs the epilogue ---
+  if constexpr (KP) {
+    __syncthreads();
+    f32x4* red = (f32x4*)lds;
+    const int wv = wave & 3;
+    if (team == 1) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) red[((wv * NF + f) * NB + i) * 64 + lane] = acc[f][i];
+    }
+    __syncthreads();
+    if (team == 0) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) acc[f][i] += red[((wv * NF + f) * NB + i) * 64 + lane];
+    }
+  }
+
   // --- epilogue: bias, per-channel tile statistics, NDHWC store.  A fragment is one x-row, so the row
   //     pointer / row bounds are scalar and each lane adds a fixed offset: no per-store address math.
   constexpr int LDS_MAIN = ((G::LDS_TILE > TL::RED_BYTES ? G::LDS_TILE : TL::RED_BYTES) + 15) / 16 * 16;
   float* sred = (float*)(lds + LDS_MAIN);  // [2 (wm)][NFW*16][2]
-  const bool active = KSPLIT ? (wn == 0) : true;
+  const bool active = KSPLIT ? (wn == 0) : KP ? (team == 0) : true;
   if (active) {
     const bool x_ok = x0 + v < p.W;
     // dual destination (dgrad of a conv whose input was the virtual concat [x1 | x2]): channels >= ysplit
@@ -619,16 +652,39 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 }
 
 // ---- host-side dispatch -----------------------------------------------------------------------
-template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false, bool BST = false>
+template <typename T, int KS, int CK, int DIL, int NF, bool KSPLIT, bool VS = false, bool PRE = false, bool BST = false, bool KP = false>
 int conv_launch_one(const ConvParams& p, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT, VS>();
-  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS, PRE, BST>;
+  constexpr int lds = conv_lds_bytes<T, KS, CK, DIL, NF, KSPLIT, VS, KP>();
+  auto kern = conv_igemm_kernel<T, KS, CK, DIL, NF, KSPLIT, VS, PRE, BST, KP>;
   static std::atomic<uint64_t> attr_done{0};
   BRATS_ENSURE_LDS_ATTR(kern, lds, attr_done);
   dim3 grid((unsigned)(p.N * p.tz * p.ty * p.tx), (unsigned)(p.rows16 / ConvTile<NF, KSPLIT, VS>::NFW));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(KP ? 512 : 256), lds, st, p);
   BRATS_CHECK_LAUNCH();
   return 0;
+}
+
+// grids of at most one workgroup per CU (the 16^3 level of the networks: 32 tiles) take the 8-wave form of the y-split roles
+// (KP: two K-parity teams per workgroup, conv_igemm_kernel) where it is built: 16-bit, 48-channel chunks; brats_conv3d_set_kp()
+extern int g_conv_kp_mode;  // conv_host.hip
+static inline bool conv_kp_enabled() {
+  if (g_conv_kp_mode >= 0) return g_conv_kp_mode != 0;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("BRATS_CONV_KP"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+static inline long conv_kp_max_grid() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("BRATS_CONV_KP_GRID"); v = e ? atol(e) : 256; }
+  return v;
+}
+template <typename T, int KS, int CK, int DIL, bool VS, bool PRE = false, bool BST = false>
+int conv_launch_nf3(const ConvParams& p, hipStream_t st) {
+  if constexpr (std::is_same<T, bf16_t>::value && CK == 48 && KS == 3 && VS && !PRE) {
+    const long wgs = (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 3);
+    if (conv_kp_enabled() && wgs <= conv_kp_max_grid()) return conv_launch_one<T, KS, CK, DIL, 3, false, true, PRE, BST, true>(p, st);
+  }
+  return conv_launch_one<T, KS, CK, DIL, 3, false, VS, PRE, BST, false>(p, st);
 }
 
 static inline bool conv_vsplit_enabled() {
@@ -658,12 +714,12 @@ int conv_launch_ck(const ConvParams& p, hipStream_t st) {
     // workgroup) double the grid at the price of staging each halo tile twice
     if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled() &&
         (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 6) < conv_small_grid_threshold())
-      return conv_launch_one<T, KS, CK, DIL, 3, false, true, PRE>(p, st);
+      return conv_launch_nf3<T, KS, CK, DIL, true, PRE>(p, st);
     return conv_launch_one<T, KS, CK, DIL, 3, false, false, PRE>(p, st);
   }
   if (t.nf == 3 && t.ksplit) {
     // Cout = 48 (mod 96): the y-split roles (no K reduction, shared epilogue) for bf16; K-split stays for f32 / opt-out
-    if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled()) return conv_launch_one<T, KS, CK, DIL, 3, false, true, PRE>(p, st);
+    if (std::is_same<T, bf16_t>::value && conv_vsplit_enabled()) return conv_launch_nf3<T, KS, CK, DIL, true, PRE>(p, st);
     return conv_launch_one<T, KS, CK, DIL, 3, true, false, PRE>(p, st);
   }
   if (t.nf == 2 && !t.ksplit) return conv_launch_one<T, KS, CK, DIL, 2, false, false, PRE>(p, st);

@@ -431,6 +431,12 @@ def _pack_weights(w, dtype, mode, cin_pad, cin_off, cin_cnt, dil, c1):
     return packed
 
 
+def set_kp(mode):
+    """brats_conv3d_set_kp: 1 / 0 = the 8-wave K-parity form of the small-grid 3x3x3 launches on / off, -1 = default.  The packed
+    weights do not depend on it.  Returns the previous setting."""
+    return _lib.lib().brats_conv3d_set_kp(mode)
+
+
 def set_vs8(mode):
     """brats_conv3d_set_vs8 + invalidation of everything packed under the old setting (the switch changes the K chunk, i.e.
     the packed-weight layout of the layers it applies to).  Returns the previous setting."""

@@ -51,7 +51,7 @@ enum { BRATS_ACT_NONE = 0, BRATS_ACT_RELU = 1, BRATS_ACT_LEAKY = 2, BRATS_ACT_EL
  * it.  History: 2 since round 3 (a changed signature, brats_maxpool2_fwd); 3 in round 4 (additions only); 4 in round 4 (the block
  * table of brats_conv3d_pack_weights_multi changed meaning); 5 in round 5 (additions only: brats_conv3d_set_x3_wgrad_fused,
  * brats_dropout, brats_evonorm_bwd_tiles + its workspace query). */
-#define BRATS_ABI_VERSION 5
+#define BRATS_ABI_VERSION 6
 int brats_abi_version(void);
 const char* brats_last_error(void);
 
@@ -117,6 +117,11 @@ int brats_conv3d_split_granule(int cout);
  * used with (the Python side offers ops.set_vs8(), which also drops its packed-weight caches).  Returns the previous setting.
  * (Round 3's mode 2, the loader-wave kernel, measured slower and left the library: scripts/probes/experiments/.) */
 int brats_conv3d_set_vs8(int mode);
+/* 16-bit 3x3x3 launches of at most one workgroup per CU (the 16^3 level: 32 tiles) with 48-channel chunks and the 48-cout
+ * y-split roles: 1 = the 8-wave form (two K-parity teams of four waves per workgroup on one LDS tile and one output tile, team 1's
+ * partial sums through LDS: conv_igemm.hpp "KP", round 6), 0 = the 4-wave workgroup, -1 = default (BRATS_CONV_KP, on).  Same
+ * packed weights, same products; the K summation order differs (two partial sums per output).  Returns the previous setting. */
+int brats_conv3d_set_kp(int mode);
 /* y2 (may be NULL): second destination; output channels >= ysplit are written to y2 (channel index
  * minus ysplit, pitch y2pitch) -- the dgrad of a conv whose input was [x1 | x2] produces dx1 and dx2
  * as two dense tensors in one launch. */

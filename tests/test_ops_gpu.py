@@ -538,6 +538,55 @@ def test_conv3d_vs8_kernel_matches_tile_kernel(cin, cin2, cout, n, size, mode):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cin2,cout,dil,size", [
+    (384, 0, 384, 1, (16, 16, 16)),   # encoder4 / its input gradient: 256 workgroups of 48 couts
+    (384, 0, 384, 2, (16, 16, 16)),   # bottom (dilation 2)
+    (384, 384, 192, 1, (16, 16, 16)), # bottom_2 over the virtual concat [down4 | bottom]: 128 workgroups
+    (192, 0, 96, 1, (10, 12, 20)),    # ragged tiles on every axis
+])
+def test_conv3d_eight_wave_k_parity_form_matches_four_wave_form(dtype, cin, cin2, cout, dil, size):
+    """conv_igemm_kernel's KP form (round 6: grids of at most one workgroup per CU run EIGHT waves -- two K-parity teams on one LDS
+    tile and one output tile, team 1's partial sums through LDS) against the 4-wave form of the same launch at the networks'
+    16^3-level shapes: same packed weights, same products in f32; the sum over K is taken as two partial sums, so the 16-bit
+    outputs agree to one rounding step of the result and the tile statistics to 1e-5; and against torch's CPU f32 convolution.
+    The backward-statistics form (the input gradient of a block's second convolution) takes the same switch."""
+    from brats21_amd import ops
+    dev = _dev()
+    n = 2
+    x = _q(_rand((n, cin) + size, 71), dtype)
+    x2 = _q(_rand((n, cin2) + size, 72), dtype) if cin2 else None
+    w = _q(_rand((cout, cin + cin2, 3, 3, 3), 73, (2.0 / ((cin + cin2) * 27)) ** 0.5), dtype)
+    b = _rand((cout,), 74, 0.1)
+    xd, x2d = _to_ndhwc(x, dtype, dev), (_to_ndhwc(x2, dtype, dev) if cin2 else None)
+    wpk = ops.pack_weights(w.to(dev), dtype, ops.PACK_FWD, dil=dil, c1=cin if cin2 else None)
+    assert ops.conv_chunk(dtype, 3, dil, cin, cin2, cout) == 48
+    res = {}
+    old = ops.set_kp(0)
+    try:
+        for mode in (0, 1):
+            ops.set_kp(mode)
+            res[mode] = ops.conv3d(xd, wpk, cout, 3, dil, bias=b.to(dev), want_stats=True, x2=x2d)
+            if not cin2 and ops.conv_bstats_ok(dtype, dil, cin, cout, "relu"):
+                # the same launch as an input gradient with the backward statistics of a GroupNorm + ReLU unit in its epilogue
+                by = _to_ndhwc(_q(_rand((n, cout) + size, 75), dtype), dtype, dev)
+                ss = torch.stack([1.0 + 0.1 * _rand((n, cout), 76), 0.1 * _rand((n, cout), 77)], -1).contiguous().to(dev)
+                res[mode] += ops.conv3d_bstats(xd, wpk, cout, dil, by, ss, "relu")
+    finally:
+        ops.set_kp(old)
+    y0, s0, y1, s1 = res[0][0], res[0][1], res[1][0], res[1][1]
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert float((y0.float() - y1.float()).abs().max()) <= float(y0.float().abs().max()) * ulp
+    assert not torch.equal(s0, s1) or torch.equal(y0, y1)  # (really two code paths: the f32 sums differ in their last bits)
+    assert torch.allclose(s0, s1, rtol=1e-5, atol=1e-5 * float(s0.abs().max()))
+    if len(res[0]) == 4:
+        assert float((res[0][2].float() - res[1][2].float()).abs().max()) <= float(res[0][2].float().abs().max()) * ulp
+        assert torch.allclose(res[0][3], res[1][3], rtol=1e-4, atol=1e-5 * float(res[0][3].abs().max()))
+    torch.set_num_threads(16)
+    ref = F.conv3d(torch.cat([x, x2], 1) if cin2 else x, w, b, 1, dil, dil)
+    torch.testing.assert_close(_from_ndhwc(y1), ref, atol=_tol(dtype, 2e-5, 3e-2), rtol=_tol(dtype, 1e-5, 2e-2))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,size,with_bias", [(2, (32, 64, 64), True), (1, (64, 64, 128), False), (1, (36, 52, 240), True)])
 def test_conv3d_first_layer_kernel(dtype, n, size, with_bias):
     """The first layer (4 modalities padded to 8 channels -> 48, networks/equiunet2020.py:424) on the persistent kernel of

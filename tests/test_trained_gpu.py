@@ -12,8 +12,13 @@ those weights and on volumes the training never saw:
   * f32 and x3 logits within 1e-3 abs of the oracle (one 128^3 patch; the stitched logits of a configs[3] volume,
     4x240x240x155 padded to 160, 18 windows, for EquiUnet);
   * bf16 and fp16 (the reference's own autocast dtype, learning/engine.py:304): hard Dice against the target within 1e-3 of
-    the oracle's, with the margin and the fraction of thresholded voxels that flipped printed;
-    (the second, half-contrast patch is a stress volume: bf16 is asserted at 2e-3 there, everything else at 1e-3);
+    the oracle's -- the bar itself, for every precision on every volume of this test, the half-contrast stress patch included
+    (round 6: the doubled bar bf16 had there is gone) -- with the margin and the fraction of thresholded voxels that flipped printed;
+  * a SWEEP over five more trained weight sets per network (other initialisations, other training volumes) and three fresh
+    volumes each -- training-like, half contrast, a third of the contrast -- so that bf16's margin is a measured distribution and
+    not one sample: the stated bar (1e-3 on volumes like the ones the network was trained and is benchmarked on) is asserted for
+    every set and both 16-bit types, fp16 is asserted at 1e-3 on the stress volumes too, and bf16's stress-volume tail is
+    reported (profiles/r06_trained_weights_parity.txt) without a bar of its own;
   * the benchmarked chain (sliding window + 8-flip TTA, Evaluator: learning/engine.py:236-259, src/definer.py:696-697) in
     bf16 / fp16 against the same chain in f32, whose network arithmetic the stitched-logit check has just pinned.
 The 320-step training runs reproduce BIT FOR BIT across runs and boxes (every reduction of the step is ordered; checked: two
@@ -43,9 +48,9 @@ STEPS = {"equiunet": 320, "equiunet_assp_evo": 320}
 POOL = 12  # training batches of 2 patches, cycled
 
 
-def _get(model):
+def _get(model, seed=0):
     from brats21_amd import get_model
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     ns = argparse.Namespace(model=model, width=48, norm="group", act="relu", num_classes=3, dropout=0)
     with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -55,19 +60,21 @@ def _get(model):
 _trained = {}
 
 
-def _train(model):
-    """x3-mode training run on the phantom; returns (module on the GPU in eval mode, CPU state dict, loss curve)."""
-    if model in _trained:
-        return _trained[model]
+def _train(model, seed=0):
+    """x3-mode training run on the phantom; returns (module on the GPU in eval mode, CPU state dict, loss curve).  seed = 0 is the
+    weight set of rounds 4 / 5; other seeds change the initialisation and the training volumes (the sweep)."""
+    key = (model, seed)
+    if key in _trained:
+        return _trained[key]
     from brats21_amd.engine import GraphedTrainStep, TrainStep
     from brats21_amd.optim import Ranger2020
-    m = _get(model).to(DEV).train()
+    m = _get(model, seed).to(DEV).train()
     m.precision = "x3"
     with contextlib.redirect_stdout(io.StringIO()):
         opt = Ranger2020(m.parameters(), lr=2e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(.95, 0.999), eps=1e-5, weight_decay=1e-5,
                          capturable=True)
     step = GraphedTrainStep(TrainStep(m, opt, criterion=None, amp=False))
-    pool = [tuple(a.to(DEV) for a in synth.tumour_phantom(2, PATCH, 5000 + i)) for i in range(POOL)]
+    pool = [tuple(a.to(DEV) for a in synth.tumour_phantom(2, PATCH, 5000 + 100 * seed + i)) for i in range(POOL)]
     curve = []
     for it in range(STEPS[model]):
         x, t = pool[it % POOL]
@@ -78,9 +85,11 @@ def _train(model):
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     m.eval()
-    print(f"\n{model}-48 trained {STEPS[model]} x3 steps on 2x4x128^3 phantoms: loss " + " ".join(f"{i}:{l:.3f}" for i, l in curve))
-    _trained[model] = (m, sd, curve)
-    return _trained[model]
+    print(f"\n{model}-48 (weight set {seed}) trained {STEPS[model]} x3 steps on 2x4x128^3 phantoms: loss " + " ".join(f"{i}:{l:.3f}" for i, l in curve))
+    if seed != 0:  # (the sweep keeps the CPU weights only)
+        m = None
+    _trained[key] = (m, sd, curve)
+    return _trained[key]
 
 
 def _oracle(model, sd, x):
@@ -132,12 +141,70 @@ def test_trained_patch_logits_and_dice_vs_oracle(model):
         m.precision = "x3"
         assert res["fp32"][2] < LOGIT_ATOL and res["x3"][2] < LOGIT_ATOL, res
         assert res["fp16+e4m3"][0] <= F8_DICE_ATOL, (contrast, res["fp16+e4m3"])
-        for prec in ("fp32", "x3", "bf16", "fp16"):
-            # the half-contrast patch is a stress case beyond what the bar was stated for: there bf16's margin moves with the
-            # trained weights, i.e. with every kernel of the training step (4.3e-4 and 8.0e-4 seen on two trees of round 5) -- it is
-            # printed, recorded in DESIGN.md and asserted at twice the bar; every other case at the bar itself
-            bar = 2 * DICE_ATOL if (prec == "bf16" and contrast < 1.0) else DICE_ATOL
-            assert res[prec][0] <= bar, (contrast, prec, res[prec])
+        for prec in ("fp32", "x3", "bf16", "fp16"):  # the bar itself, everywhere (the half-contrast stress patch included)
+            assert res[prec][0] <= DICE_ATOL, (contrast, prec, res[prec])
+
+
+SWEEP_SEEDS = (1, 2, 3, 4, 5)
+SWEEP_VOLUMES = ((1.0, "training-like"), (0.5, "half contrast (stress)"), (0.35, "a third of the contrast (stress)"))
+
+
+@pytest.mark.parametrize("model", ["equiunet", "equiunet_assp_evo"])
+def test_trained_seed_sweep_dice_margin_distribution(model):
+    """five more trained weight sets (other initialisations, other training volumes), three fresh volumes each.
+    Asserted at the bar (1e-3, no other number in this file): bf16 and fp16 on the training-like volume of every weight set -- the
+    volumes north_star's sentence is about -- and fp16 on every stress volume.  bf16 on the stress volumes, where the trained
+    network itself is unsure (oracle Dice 0.5 .. 0.9), is REPORTED as a distribution: its tail is the number a user of the bf16
+    configuration should know, and fp16 (15.1 vs 14.5 ms / step, bench.py `fp16_mode`) is the configuration that holds the bar
+    there.  The table goes to gpurun_out/r06_trained_sweep_<model>.txt for profiles/."""
+    from brats21_amd import get_model  # noqa: F401
+    rows, lines = [], []
+    for seed in SWEEP_SEEDS:
+        _, sd, curve = _train(model, seed)
+        assert curve[-1][1] < 0.6 * curve[0][1], (seed, curve)
+        m = _get(model, seed)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        for vi, (contrast, what) in enumerate(SWEEP_VOLUMES):
+            x, t = synth.tumour_phantom(1, PATCH, 9000 + 10 * seed + vi, contrast=contrast)
+            ref = _oracle(model, sd, x)
+            d_ref = unet.hard_dice(ref, t)
+            xd = x.to(DEV)
+            row = {"seed": seed, "contrast": contrast, "oracle_dice_min": float(d_ref.min())}
+            with torch.no_grad():
+                for prec in ("bf16", "fp16"):
+                    m.precision = prec
+                    out = m(xd)
+                    out = (out[0] if isinstance(out, (tuple, list)) else out).float().cpu()
+                    row[prec] = float((unet.hard_dice(out, t) - d_ref).abs().max())
+                    row[prec + "_flips"] = float(((out > 0) != (ref > 0)).float().mean())
+            rows.append(row)
+            lines.append(f"{model}-48 weight set {seed}, {what:34s}: oracle Dice min {row['oracle_dice_min']:.4f}; |dDice| bf16 {row['bf16']:.2e} "
+                         f"(flipped {row['bf16_flips']:.1e}), fp16 {row['fp16']:.2e} (flipped {row['fp16_flips']:.1e})")
+            print("  " + lines[-1])
+        del m
+        torch.cuda.empty_cache()
+    def stat(vals):
+        v = sorted(vals)
+        return f"n {len(v)}, median {v[len(v) // 2]:.2e}, max {v[-1]:.2e}, above the 1e-3 bar: {sum(1 for a in v if a > DICE_ATOL)}"
+    like = [r for r in rows if r["contrast"] == 1.0]
+    stress = [r for r in rows if r["contrast"] < 1.0]
+    summary = [f"{model}-48, {len(SWEEP_SEEDS)} trained weight sets x {len(SWEEP_VOLUMES)} fresh volumes, hard-Dice margin against the CPU oracle:",
+               f"  training-like volumes  bf16: {stat([r['bf16'] for r in like])}",
+               f"  training-like volumes  fp16: {stat([r['fp16'] for r in like])}",
+               f"  stress volumes         bf16: {stat([r['bf16'] for r in stress])}",
+               f"  stress volumes         fp16: {stat([r['fp16'] for r in stress])}"]
+    print("\n" + "\n".join(summary))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"r06_trained_sweep_{model}.txt"), "w") as f:
+        f.write("\n".join(summary + [""] + lines) + "\n")
+    for r in rows:
+        assert r["oracle_dice_min"] >= 0.3, r  # (the comparison is about segmentations, not about empty masks)
+    for r in like:
+        assert r["bf16"] <= DICE_ATOL and r["fp16"] <= DICE_ATOL, r
+    for r in stress:
+        assert r["fp16"] <= DICE_ATOL, r
 
 
 def test_trained_config3_sliding_window_flip8_vs_oracle():
