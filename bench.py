@@ -195,6 +195,8 @@ def gpu_count_without_hip():
     for p in nodes:
         try:
             props = dict(line.split()[:2] for line in open(p) if len(line.split()) >= 2)
+        except PermissionError:
+            continue  # a GPU of the node that this container was not given (its KFD node is not readable): not ours to count
         except OSError:
             return None
         if int(props.get("simd_count", "0")) > 0:
@@ -244,6 +246,65 @@ def profiled_traffic(kernel_label):
         if rec.get("kernel_label") == kernel_label and rec.get("source_sha16") == sha:
             return rec, os.path.relpath(path, ROOT)
     return None, None
+
+
+PMC_LABEL = "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128"  # the launch `--pmc-leg` repeats (= roofline.kernel of the headline)
+
+
+def pmc_leg():
+    """`bench.py --pmc-leg`: nothing but the dominant kernel's launch -- the 48 -> 48 3x3x3 forward of 2 x 128^3 with tile statistics,
+    as the network issues it -- 2 warm-ups + 6 launches.  Run under `rocprofv3 --pmc ... -- python3 bench.py --pmc-leg` by
+    live_traffic() below (or by hand); prints one line with what it launched."""
+    from brats21_amd import ops
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    x = torch.relu(torch.randn(2, 128, 128, 128, 48, device=dev)).to(torch.bfloat16)
+    w = torch.randn(48, 48, 3, 3, 3, device=dev) * (2.0 / (48 * 27)) ** 0.5
+    wpk = ops.pack_weights(w, torch.bfloat16, ops.PACK_FWD)
+    for _ in range(8):
+        ops.conv3d(x, wpk, 48, 3, 1, want_stats=True)
+    torch.cuda.synchronize()
+    print(json.dumps({"pmc_leg": PMC_LABEL, "launches": 8}))
+    return 0
+
+
+def live_traffic(kernel_label):
+    """HBM traffic of the dominant kernel measured IN THIS RUN of bench.py: after the timed region, two child
+    processes `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --pmc-leg` -- FETCH_SIZE and WRITE_SIZE in separate
+    passes, never combined with a system trace (MI355X_MICROARCH.md, HBM / rocprofv3 PMC slots) -- and the per-launch mean of the
+    kernel's dispatches from the counter CSV; FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes), WRITE_SIZE as
+    read (16-byte-per-lane stores), both in KiB.  None when the label is not this launch, rocprofv3 is missing or a pass failed --
+    the committed record (profiled_traffic) is then the labelled fallback."""
+    import csv, glob, shutil, subprocess, tempfile
+    if kernel_label != PMC_LABEL or shutil.which("rocprofv3") is None:
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="brats_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-leg"]
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               text=True, timeout=240)
+            vals, durs = [], []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "conv_igemm_vs8_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        vals.append(float(r["Counter_Value"]))
+                        durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            if p.returncode != 0 or len(vals) < 4:
+                print(f"bench.py: rocprofv3 --pmc {ctr} pass gave {len(vals)} dispatches (rc {p.returncode}): {p.stdout[-400:]}", file=sys.stderr)
+                return None
+            vals, durs = vals[2:], durs[2:]  # (the two warm-up launches)
+            out[ctr] = (sum(vals) / len(vals), sum(durs) / len(durs), len(vals))
+    except Exception as e:
+        print(f"bench.py: live PMC traffic failed: {e!r}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"fetch_MB": round(2 * out["FETCH_SIZE"][0] / 1024, 1), "write_MB": round(out["WRITE_SIZE"][0] / 1024, 1),
+            "launches": out["FETCH_SIZE"][2], "dur_us_under_pmc": round(out["FETCH_SIZE"][1] / 1e3, 1)}
 
 
 def inference_bench(model, dev, args):
@@ -349,6 +410,11 @@ def gpu_local_cpus():
             props = dict(line.split()[:2] for line in open(p) if len(line.split()) >= 2)
             if int(props.get("simd_count", "0")) <= 0:
                 continue
+        except PermissionError:
+            continue  # (another container's GPU)
+        except (OSError, ValueError):
+            return None
+        try:
             loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
             bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
             out.append(_cpulist(open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read()))
@@ -550,6 +616,9 @@ def main():
                          "gradients (all) on the e4m3 MFMA kernel (BASELINE.json configs[4]); weight gradients stay bf16")
     ap.add_argument("--dropout", type=float, default=0.0, help="NOT the headline configuration: --dropout p of the reference's CLI")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel time table (rank 0)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child processes after the timed region)")
+    ap.add_argument("--pmc-leg", action="store_true", help="(internal) only the dominant kernel's launch, for a rocprofv3 --pmc pass")
     ap.add_argument("--no-graph-leg", action="store_true",
                     help="bare --gpus N > 1: do not run the second leg (the step incl. its RCCL all-reduces as one hipGraph, fresh ranks)")
     ap.add_argument("--dry-run", action="store_true",
@@ -563,6 +632,8 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run))
     if args.dry_run:
         return dry_run(args)
+    if args.pmc_leg:
+        return pmc_leg()
     # stdout carries ONE JSON line: everything else this process and its libraries print from here on (RCCL's version banner goes
     # to fd 1 at communicator creation) is sent to stderr; emit() below writes the line to the real stdout
     sys.stdout.flush()
@@ -767,13 +838,23 @@ def main():
     # HBM traffic of the dominant kernel comes from separate --pmc passes (never collected inside this timed run):
     # `traffic` is the committed per-launch figure of those passes, null unless it was taken on this kernel, this shape
     # and these kernel sources (profiled_traffic)
-    if roofline is not None:
+    live = None
+    if roofline is not None and world == 1 and not args.no_pmc_traffic and not args.graph:
+        live = live_traffic(roofline["kernel"])
+    if live is not None:
+        n_, d_, h_, w_ = 2, 128, 128, 128
+        roofline["traffic"] = int((live["fetch_MB"] + live["write_MB"]) * 1024 * 1024)  # bytes per launch
+        roofline["traffic_profiled"] = dict(live, algorithmic_MB=round(2 * (n_ * d_ * h_ * w_ * 48 * 2) / 1e6, 1),
+                                            source="live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two child processes "
+                                                   "of THIS run (bench.py --pmc-leg: the same launch, 6 dispatches averaged), MiB per "
+                                                   "launch, FETCH_SIZE doubled per MI355X_MICROARCH.md")
+    elif roofline is not None:
         rec, src = profiled_traffic(roofline["kernel"])
         if rec is not None:
             roofline["traffic"] = int((rec["fetch_MB"] + rec["write_MB"]) * 1024 * 1024)  # bytes per launch (the report prints MiB)
             roofline["traffic_profiled"] = {"fetch_MB": rec["fetch_MB"], "write_MB": rec["write_MB"],
                                             "algorithmic_MB": round(2 * (n * d * h * w * cout * 2) / 1e6, 1),
-                                            "source": src + " (rocprofv3 --pmc, separate passes over this kernel and shape, per launch; "
+                                            "source": "committed record (no live measurement in this run): " + src + " (rocprofv3 --pmc, separate passes over this kernel and shape, per launch; "
                                                             "FETCH_SIZE doubled per MI355X_MICROARCH.md)"}
     if args.kernel_table:
         for key in sorted(table, key=lambda k: -table[k][2]):

@@ -236,7 +236,8 @@ def _inherit_amax(dst, src):
 
 
 def _f8_ok(fp8, dtype, x, x2=None):
-    return bool(fp8) and ops.is16(dtype) and ops.conv_f8_chunk(x.shape[-1], x2.shape[-1] if x2 is not None else 0) > 0
+    return (bool(fp8) and ops.is16(dtype) and x.shape[1] >= ops.F8_MIN_SIZE and
+            ops.conv_f8_chunk(x.shape[-1], x2.shape[-1] if x2 is not None else 0) > 0)
 
 
 def _unit_act(unit, act):

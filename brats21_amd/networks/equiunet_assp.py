@@ -131,7 +131,7 @@ def _conv_any_fwd(cx, conv, x, dil, want_stats, out=None):
     """conv (3x3x3 with dilation 1 | 2, or 1x1x1) + bias.  Returns (y, stats, saved) with what backward needs."""
     w = conv.weight
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-    if cx.fp8 and k == 3 and ops.conv_f8_chunk(x.shape[-1]) > 0:
+    if cx.fp8 and k == 3 and x.shape[1] >= ops.F8_MIN_SIZE and ops.conv_f8_chunk(x.shape[-1]) > 0:
         wpk = ops.pack_weights_f8(w, PACK_FWD, cin_pad=x.shape[-1])
         y, stats = ops.conv3d_f8(x, wpk, cout, dil, bias=_flat(conv.bias), out=out, want_stats=want_stats,
                                  amax=getattr(x, "_amax", None))

@@ -567,6 +567,18 @@ def absmax(x):
     return out
 
 
+F8_MIN_SIZE = 0  # e4m3 forward convolutions only at levels whose depth is >= this many voxels (0 = every level); set_f8_min_size()
+
+
+def set_f8_min_size(n):
+    """Restrict model.conv_fp8's FORWARD convolutions to the levels with a depth of at least n voxels (64: the 128^3 and 64^3
+    levels of a 128^3 patch; 0 = all levels, the default).  An experiment knob for VERDICT r5 item 7 (does e4m3 hold the Dice bar
+    when only the large, statistics-rich levels use it?); the backward kernels do not look at it.  Returns the previous value."""
+    global F8_MIN_SIZE
+    old, F8_MIN_SIZE = F8_MIN_SIZE, int(n)
+    return old
+
+
 def conv_f8_chunk(c1, c2=0):
     """Channel chunk of the fp8 kernel for an input of c1 (+c2) channels; 0 = not supported (use conv3d)."""
     return _lib.lib().brats_conv3d_f8_chunk(c1, c2)

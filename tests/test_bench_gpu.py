@@ -109,3 +109,18 @@ def test_bench_rccl_rehearsal_eager_headline_then_graph_leg_in_fresh_ranks():
     assert g["ms_per_step"] > 0 and g["n_gpus"] == 1 and g["ddp"]["graph_captured_collectives"] is True and g["ddp"]["backend"] == "nccl"
     assert g["host_enqueue_ms"] < r["host_enqueue_ms"]  # one graph launch per step instead of a few hundred enqueues
     assert abs(g["loss"] - r["config"]["loss"]) < 2e-2  # same workload and seed (the capture adds two eager warm-up steps)
+
+
+def test_bench_measures_the_dominant_kernels_hbm_traffic_in_its_own_run():
+    """roofline.traffic is measured by the run that prints the line -- two rocprofv3 --pmc child processes
+    (FETCH_SIZE, WRITE_SIZE: separate passes) over `bench.py --pmc-leg`, the dominant kernel's launch -- and says so; the committed
+    record is only the labelled fallback.  The headline's own shape (width 48, 2 x 128^3), a short run."""
+    r = _bench("--steps", "4", "--warmup", "2", "--no-infer", "--no-cpu-baseline", "--no-parity-leg", "--no-other-configs")
+    rf = r["roofline"]
+    assert rf["kernel"] == "conv_igemm cin=48 cout=48 k=3 dil=1 @2x128x128x128"
+    tp = rf["traffic_profiled"]
+    assert tp["source"].startswith("live"), tp
+    algo = tp["algorithmic_MB"] * 1e6
+    assert rf["traffic"] == int((tp["fetch_MB"] + tp["write_MB"]) * 1024 * 1024)
+    assert 0.9 * algo < rf["traffic"] < 2.5 * algo, (rf["traffic"], algo)  # every byte at least once, no runaway re-reads
+    assert 0.9 * algo / 2 < tp["write_MB"] * 1024 * 1024 < 1.2 * algo / 2   # the output is written once
