@@ -17,10 +17,10 @@ static int conv_pre_launch_ck48(const ConvParams& p, hipStream_t st) {
   // conv_launch_ck's choice among the NF = 3 roles
   if (p.rows16 % 6 == 0) {
     if (conv_vsplit_enabled() && (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 6) < conv_small_grid_threshold())
-      return conv_launch_one<bf16_t, 3, 48, DIL, 3, false, true, true>(p, st);
+      return conv_launch_nf3<bf16_t, 3, 48, DIL, true, true>(p, st);  // (the same 8-wave choice as the plain kernel: bit-identical)
     return conv_launch_one<bf16_t, 3, 48, DIL, 3, false, false, true>(p, st);
   }
-  return conv_launch_one<bf16_t, 3, 48, DIL, 3, false, true, true>(p, st);
+  return conv_launch_nf3<bf16_t, 3, 48, DIL, true, true>(p, st);
 }
 
 int conv_pre_launch(const ConvParams& p, int ck, int dil, hipStream_t st) {

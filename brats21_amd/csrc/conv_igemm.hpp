@@ -680,7 +680,7 @@ static inline long conv_kp_max_grid() {
 }
 template <typename T, int KS, int CK, int DIL, bool VS, bool PRE = false, bool BST = false>
 int conv_launch_nf3(const ConvParams& p, hipStream_t st) {
-  if constexpr (std::is_same<T, bf16_t>::value && CK == 48 && KS == 3 && VS && !PRE) {
+  if constexpr (std::is_same<T, bf16_t>::value && CK == 48 && KS == 3 && VS) {
     const long wgs = (long)p.N * p.tz * p.ty * p.tx * (p.rows16 / 3);
     if (conv_kp_enabled() && wgs <= conv_kp_max_grid()) return conv_launch_one<T, KS, CK, DIL, 3, false, true, PRE, BST, true>(p, st);
   }

@@ -542,7 +542,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
     const int P = tid + 512 * i;
     const int vox = P / G::XPPV, part = P % G::XPPV;
     const int hx = vox % G::HX, hy = (vox / G::HX) % G::HY, hz = vox / (G::HX * G::HY);
-    const bool ok = P < G::XPIECES;
+    // (CIF = 1, the first layer: a 16-channel LDS row of which only the tensor's real 8-channel pieces are fetched -- the others
+    //  arrive as zeros from the range check, like every piece outside the volume)
+    const bool ok = P < G::XPIECES && (CIF > 1 || part * 8 < p.c1);
     xoffs[i] = ok ? ((hz * p.H + hy) * p.W + hx) * xpb + part * 16 : (int)0x80000000;
     xcode[i] = ok ? (hz | hy << 3 | hx << 6 | 1 << 14) : 0;
   }
@@ -705,10 +707,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_alltaps2_kernel(const Wgrad
       const int t = pid / CIF, nn = pid % CIF;
       float* base = p.ws + ((size_t)split * 27 + t) * p.cout * p.cin;
       const int ci = ci0 + nn * 16 + v;
+      if (CIF > 1 || ci < p.cin) {  // (CIF = 1: the slab has the tensor's real input channels as columns)
 #pragma unroll
-      for (int m = 0; m < COF; ++m)
+        for (int m = 0; m < COF; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
+          for (int r = 0; r < 4; ++r) base[(size_t)(co0 + m * 16 + 4 * q + r) * p.cin + ci] = acc[jj][m][r];
+      }
     }
   }
 }
@@ -1204,6 +1208,12 @@ static int wgrad_mfma(const void* x1, int c1, int pitch1, const void* x2, int c2
       hipLaunchKernelGGL((conv_wgrad_alltaps_kernel<1, 4>), dim3(p.nsplit, cout / 64, 1), dim3(512), (Wg3<1, 4>::LDS), st, p);
     } else if (wide) {
       hipLaunchKernelGGL((conv_wgrad_alltaps2_kernel<4, 2>), dim3(p.nsplit, cout / 64, p.cin / 32), dim3(512), lds_wide, st, p);
+    } else if (c2 <= 0 && c1 <= 16 && form != 1 && c1 % 8 == 0) {
+      // the first layer on the LDS-DMA form (round 6): two X buffers of 16-channel rows, the next tile's loads in flight behind
+      // the MFMA phase -- this layer is all loads (dY: 24 KB per tile against 1.5 k cycles of MFMA per wave)
+      static std::atomic<uint64_t> attr_f{0};
+      BRATS_ENSURE_LDS_ATTR((conv_wgrad_alltaps2_kernel<3, 1>), (Wg3b<3, 1>::LDS), attr_f);
+      hipLaunchKernelGGL((conv_wgrad_alltaps2_kernel<3, 1>), dim3(p.nsplit, cout / 48, 1), dim3(512), (Wg3b<3, 1>::LDS), st, p);
     } else if (c2 <= 0 && c1 <= 16) {
       // the slab columns of the padded ci lanes (c1 < 16) are never written and never read (cin = c1)
       hipLaunchKernelGGL(conv_wgrad_alltaps_kernel<1>, dim3(p.nsplit, cout / 48, 1), dim3(512), Wg3<1>::LDS, st, p);

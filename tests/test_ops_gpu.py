@@ -587,6 +587,29 @@ def test_conv3d_eight_wave_k_parity_form_matches_four_wave_form(dtype, cin, cin2
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,size", [(1, (64, 64, 64)), (2, (32, 48, 80))])
+def test_conv3d_first_layer_weight_gradient_vs_torch(dtype, n, size):
+    """The first layer's weight gradient (8 padded input channels -> 48) on the LDS-DMA all-taps form (round 6: two X buffers of
+    16-channel rows of which only the real 8-channel piece is fetched, the next tile's loads behind the MFMA phase) against torch
+    autograd on the CPU; the gradient columns of the four padding channels are exactly zero (the padding channels are zero)."""
+    from brats21_amd import ops
+    dev = _dev()
+    x = _q(_rand((n, 4) + size, 81), dtype)
+    dy = _q(_rand((n, 48) + size, 82, 0.1), dtype)
+    wr = torch.zeros(48, 4, 3, 3, 3, requires_grad=True)
+    torch.set_num_threads(16)
+    F.conv3d(x, wr, None, 1, 1).backward(dy)
+    xin = torch.zeros(n, *size, 8, dtype=dtype, device=dev)
+    xin[..., :4] = _to_ndhwc(x, dtype, dev)
+    dw, _ = ops.conv3d_wgrad(xin, _to_ndhwc(dy, dtype, dev), 3, 1)
+    assert tuple(dw.shape) == (48, 8, 3, 3, 3)
+    assert float(dw[:, 4:].abs().max()) == 0.0
+    ref = wr.grad
+    err = float((dw[:, :4].cpu() - ref).abs().max())
+    assert err <= 2e-3 * float(ref.abs().max()), (err, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,size,with_bias", [(2, (32, 64, 64), True), (1, (64, 64, 128), False), (1, (36, 52, 240), True)])
 def test_conv3d_first_layer_kernel(dtype, n, size, with_bias):
     """The first layer (4 modalities padded to 8 channels -> 48, networks/equiunet2020.py:424) on the persistent kernel of
