@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/final; mkdir -p $out; rm -f $out/summary.txt
 timeout 2400 python -m pytest tests -m gpu -q --deselect tests/test_trained_gpu.py > $out/pytest_gpu.log 2>&1; echo "pytest gpu (all but the trained-weights file) rc=$?" >> $out/summary.txt
-timeout 2400 python -m pytest tests/test_trained_gpu.py -m gpu -q -s > $out/trained_weights_parity.txt 2>&1; echo "trained rc=$?" >> $out/summary.txt
+BRATS_SWEEP_FULL=1 timeout 2400 python -m pytest tests/test_trained_gpu.py -m gpu -q -s > $out/trained_weights_parity.txt 2>&1; echo "trained rc=$?" >> $out/summary.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?" >> $out/summary.txt
 python3 bench.py --kernel-table > $out/bench.json 2> $out/conv_table.txt; echo "bench rc=$?" >> $out/summary.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-parity-leg --no-other-configs --no-pmc-traffic > $out/bench_profiled.log 2>&1

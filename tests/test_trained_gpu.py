@@ -156,7 +156,9 @@ def test_trained_patch_logits_and_dice_vs_oracle(model):
             assert res[prec][0] <= DICE_ATOL, (contrast, prec, res[prec])
 
 
-SWEEP_SEEDS = (1, 2, 3, 4, 5)
+# the whole sweep (five weight sets per network, ~7 minutes) runs with BRATS_SWEEP_FULL=1 -- scripts/r6_final.sh, whose output is
+# profiles/r06_final_trained_weights_parity.txt; the default GPU suite takes the first two weight sets (the same asserts)
+SWEEP_SEEDS = (1, 2, 3, 4, 5) if os.environ.get("BRATS_SWEEP_FULL", "0") == "1" else (1, 2)
 SWEEP_STEPS = {"equiunet": 560, "equiunet_assp_evo": 320}
 SWEEP_VOLUMES = ((1.0, "training-like"), (0.5, "half contrast (stress)"), (0.35, "a third of the contrast (stress)"))
 
@@ -204,7 +206,7 @@ def test_trained_seed_sweep_dice_margin_distribution(model):
     # parity: it is listed, not counted -- and at least four of the five must count
     bad = {r["seed"] for r in rows if r["contrast"] == 1.0 and r["oracle_dice_min"] < 0.5}
     lines.append(f"weight sets not counted (oracle Dice < 0.5 on their training-like volume): {sorted(bad) if bad else 'none'}")
-    assert len(bad) <= 1, bad
+    assert len(bad) <= (1 if len(SWEEP_SEEDS) >= 4 else 0), bad
     rows = [r for r in rows if r["seed"] not in bad]
     like = [r for r in rows if r["contrast"] == 1.0]
     stress = [r for r in rows if r["contrast"] < 1.0]
