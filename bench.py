@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+KFD_NODES = "/sys/class/kfd/kfd/topology/nodes"   # (module-level so that tests can point them at a fake tree)
+PCI_DEVICES = "/sys/bus/pci/devices"
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_FP8_TFLOPS = 5000.0    # dense MX-scaled e4m3 MFMA (--fp8 only)
@@ -191,7 +193,7 @@ def gpu_count_without_hip():
     the launcher process stays a process that never initialised the GPU (torch.cuda.device_count() may fall through
     to hipGetDeviceCount; ADVICE r5: a device mask narrower than the node must narrow the count).  None = unknown."""
     import glob
-    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    nodes = glob.glob(os.path.join(KFD_NODES, "*", "properties"))
     if not nodes:
         return None
     n = 0
@@ -407,7 +409,7 @@ def gpu_local_cpus():
     None when the topology cannot be read."""
     import glob
     out = []
-    nodes = sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"), key=lambda p: int(p.split("/")[-2]))
+    nodes = sorted(glob.glob(os.path.join(KFD_NODES, "*", "properties")), key=lambda p: int(p.split("/")[-2]))
     for p in nodes:
         try:
             props = dict(line.split()[:2] for line in open(p) if len(line.split()) >= 2)
@@ -420,7 +422,7 @@ def gpu_local_cpus():
         try:
             loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
             bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
-            out.append(_cpulist(open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read()))
+            out.append(_cpulist(open(os.path.join(PCI_DEVICES, bdf, "local_cpulist")).read()))
         except (OSError, KeyError, ValueError):
             return None
     return out or None

@@ -119,3 +119,60 @@ def test_graph_leg_runs_in_fresh_ranks_and_reports_a_failure_as_its_exit_code():
     assert bad["rc"] not in (0, None) and "ms_per_step" not in bad
     hung = bench.graph_ddp_leg(2, ["--gpus", "2", "--dry-run"], dict(env, BRATS_GRAPH_LEG_TIMEOUT="0.05"))
     assert hung["rc"] == 124
+
+
+def test_ranks_take_the_cpus_next_to_their_gpu(tmp_path, monkeypatch):
+    """pin_rank_to_cpus on a fake 4-GPU, 2-socket topology: KFD nodes -> PCI address -> local_cpulist; the two ranks of a socket split
+    its CPUs in rank order; a KFD node this container may not read (another tenant's GPU) is skipped; a device mask falls back to
+    contiguous slices."""
+    sys.path.insert(0, ROOT)
+    import bench
+    kfd, pci = tmp_path / "kfd", tmp_path / "pci"
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 8:
+        import pytest
+        pytest.skip("needs >= 8 CPUs")
+    half = len(cpus) // 2
+    socket = [cpus[:half], cpus[half:]]
+    (kfd / "0").mkdir(parents=True)
+    (kfd / "0" / "properties").write_text("cpu_cores_count 16\nsimd_count 0\n")
+    for g in range(4):
+        d = kfd / str(g + 1)
+        d.mkdir()
+        loc = ((0x10 + g) << 8)  # bus 0x10 + g, device 0, function 0
+        (d / "properties").write_text(f"simd_count 1024\nlocation_id {loc}\ndomain 0\n")
+        dev = pci / f"0000:{0x10 + g:02x}:00.0"
+        dev.mkdir(parents=True)
+        s = socket[g // 2]
+        (dev / "local_cpulist").write_text(f"{s[0]}-{s[-1]}\n" if s == list(range(s[0], s[-1] + 1)) else ",".join(map(str, s)) + "\n")
+    monkeypatch.setattr(bench, "KFD_NODES", str(kfd))
+    monkeypatch.setattr(bench, "PCI_DEVICES", str(pci))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "BRATS_RANK_CPUS", "BRATS_NO_PIN"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.gpu_count_without_hip() == 4
+    near = bench.gpu_local_cpus()
+    assert near == [socket[0], socket[0], socket[1], socket[1]]
+    before = os.sched_getaffinity(0)
+    try:
+        got = []
+        for local in range(4):
+            os.sched_setaffinity(0, before)
+            monkeypatch.setenv("LOCAL_RANK", str(local))
+            monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+            r = bench.pin_rank_to_cpus()
+            if half // 2 >= 4:
+                assert r is not None and "NUMA" in r["source"], r
+                got.append(sorted(os.sched_getaffinity(0)))
+            else:
+                assert r is None  # fewer than 4 CPUs per rank: nothing is pinned
+        if got:
+            assert got[0] + got[1] == socket[0] and got[2] + got[3] == socket[1]
+        # a device mask reorders / hides devices: contiguous slices of the affinity set instead
+        os.sched_setaffinity(0, before)
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1")
+        monkeypatch.setenv("LOCAL_RANK", "1")
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+        r = bench.pin_rank_to_cpus()
+        assert r is not None and r["source"].startswith("contiguous") and sorted(os.sched_getaffinity(0)) == cpus[half:]
+    finally:
+        os.sched_setaffinity(0, before)
