@@ -28,6 +28,7 @@ class TrainStep:
         self.criterion = criterion if criterion is not None else DiceLoss(jaccard=jaccard)
         self.amp_dtype = amp_dtype
         self.scaler = scaler
+        self._params = None
         if amp and amp_dtype == torch.float16 and scaler is None:
             self.scaler = torch.amp.GradScaler("cuda")  # src/main_train.py:110
 
@@ -37,8 +38,16 @@ class TrainStep:
             return fused_deep_supervision_dice(outputs, target, jaccard=self.jaccard)
         return deep_supervision_loss(self.criterion, outputs, target)[0]
 
+    def _zero_grad(self):
+        # model.zero_grad(set_to_none=True) without walking the module tree every step (0.3 ms of host time for EquiUnetASSPEvo)
+        params = self._params
+        if params is None:
+            params = self._params = list(self.model.parameters())
+        for p in params:
+            p.grad = None
+
     def __call__(self, image, target):
-        self.model.zero_grad(set_to_none=True)
+        self._zero_grad()
         with torch.autocast("cuda", dtype=self.amp_dtype, enabled=self.amp):
             outputs = self.model(image)
             loss = self.loss(outputs, target)

@@ -67,7 +67,16 @@ def _span(*key):
     return TIMER.span(key) if TIMER is not None else _NOSPAN
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as an integer handle.  torch.cuda.current_stream().cuda_stream builds a Python
+    Stream object per call (~3 us, ~250 calls per training step: 0.7 ms of host time); the raw accessor is what torch's own
+    generated code uses."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
