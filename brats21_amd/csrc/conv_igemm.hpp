@@ -361,6 +361,12 @@ __global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(
   const int lane_b = ((wm * 2) * G::HY * G::HX + (VS ? wn * 2 * G::HX : 0) + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;  // bytes of packed weights per chunk
 
+#ifdef BRATS_VS8_STAMPS  // diagnostic build only (scripts/probes/vs8_stamps.sh + igemm_stamps.py): where does a workgroup's time go?
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define IG_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define IG_STAMP(i) do { } while (0)
+#endif
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     const int c0 = chunk * CK;
     const T* src;
@@ -400,7 +406,13 @@ __global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(
         for (int j = 0; j < IPR; ++j) conv_pre_load(pre_ss, n, csrc, cb, hx_part[j] >= 0 ? hx_part[j] & 0xffff : 0, psc[j], psh[j]);
       }
     }
+    IG_STAMP(0);  // address arithmetic + issue of the halo loads
     if (chunk > 0) __syncthreads();  // all waves finished reading the previous chunk's tile
+    IG_STAMP(1);  // barrier: everybody done with the previous chunk
+#ifdef BRATS_VS8_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IG_STAMP(2);  // the halo loads landing
+#endif
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
       if (wave + NW * k < NROWS) {
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(
       }
     }
     __syncthreads();
+    IG_STAMP(3);  // LDS writes + barrier
     const char* wchunk = (const char*)p.wpk + chunk * chunk_stride;
     if constexpr (KSPLIT) {
       if (wn == 0) conv_mma_chunk<T, KS, CK, DIL, NF, 0>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
@@ -432,6 +445,7 @@ __global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(
     } else {
       conv_mma_chunk<T, KS, CK, DIL, NF, -1, NB>(lds, lane_b, q, wchunk, p.rows16, f0, lane, acc);
     }
+    IG_STAMP(4);  // MFMA loop
   }
 
   // --- K-split reduction through LDS ---
@@ -631,6 +645,13 @@ __global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(
       }
     }
   }
+#ifdef BRATS_VS8_STAMPS
+  IG_STAMP(5);  // reduction between teams + epilogue
+  if (lane == 0 && p.stamps) {
+    long long* st = p.stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TL::NW + wave) * 6;
+    for (int i = 0; i < 6; ++i) st[i] = tacc[i];
+  }
+#endif
   if (p.stats) {
     __syncthreads();
     if (tid < TL::NFW * 16) {
