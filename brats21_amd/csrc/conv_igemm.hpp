@@ -361,7 +361,7 @@ __global__ __launch_bounds__(KP ? 512 : 256, KP ? 1 : 2) void conv_igemm_kernel(
   const int lane_b = ((wm * 2) * G::HY * G::HX + (VS ? wn * 2 * G::HX : 0) + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;  // bytes of packed weights per chunk
 
-#ifdef BRATS_VS8_STAMPS  // diagnostic build only (scripts/probes/vs8_stamps.sh + igemm_stamps.py): where does a workgroup's time go?
+#ifdef BRATS_VS8_STAMPS  // diagnostic build only (scripts/probes/stamps_build.sh + igemm_stamps.py): where does a workgroup's time go?
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define IG_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else

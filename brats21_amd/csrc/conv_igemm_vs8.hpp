@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_vs8_kernel(const ConvParams
 
   const int lane_b = ((wm * 2) * G::HY * G::HX + wn * YB * G::HX + v) * G::S + q * G::UB;
   const size_t chunk_stride = (size_t)G::MS * p.rows16 * 64 * 16;
-#ifdef BRATS_VS8_STAMPS  // diagnostic build only (scripts/probes/vs8_stamps.*)
+#ifdef BRATS_VS8_STAMPS  // diagnostic build only (scripts/probes/stamps_build.sh, vs8_stamps.py)
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #define VS8_STAMP(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } while (0)
 #else

@@ -1,8 +1,8 @@
-"""Per-phase cycle shares of conv_igemm_kernel at a small-grid shape (diagnostic library built by vs8_stamps.sh):
+"""Per-phase cycle shares of conv_igemm_kernel at a small-grid shape (diagnostic library built by scripts/probes/stamps_build.sh):
    python scripts/probes/igemm_stamps.py cin cout size [dil] [kp]"""
 import os, sys
 sys.path.insert(0, '.')
-os.environ.setdefault("BRATS_HIP_LIB", os.path.abspath("brats21_amd/libbrats_hip_stamps8%s.so" % os.environ.get("SUFFIX", "")))
+os.environ.setdefault("BRATS_HIP_LIB", os.path.abspath("brats21_amd/libbrats_diag.so"))
 import torch
 cin, cout, s = (int(a) for a in sys.argv[1:4])
 dil = int(sys.argv[4]) if len(sys.argv) > 4 else 1

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Diagnostic build of the WHOLE library with -DBRATS_VS8_STAMPS (ConvParams grows a member, so every unit and both 16-bit twins are
-# rebuilt; never part of libbrats_hip.so): bash scripts/probes/igemm_stamps.sh -> brats21_amd/libbrats_diag.so
-# then on the GPU box: BRATS_HIP_LIB=$PWD/brats21_amd/libbrats_diag.so python scripts/probes/igemm_stamps.py 384 384 16 1 1
+# rebuilt; never part of libbrats_hip.so): bash scripts/probes/stamps_build.sh -> brats21_amd/libbrats_diag.so
+# then on the GPU box: python scripts/probes/igemm_stamps.py 384 384 16 1 1   (conv_igemm_kernel)   or   python scripts/probes/vs8_stamps.py   (the 4x8x16-tile kernel)
+# (delete the library afterwards: it is 13 MB that would travel with every gpurun call)
 set -e
 cd "$(dirname "$0")/../../brats21_amd/csrc"
 make -j8 twin_dispatch.o > /dev/null

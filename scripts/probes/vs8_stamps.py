@@ -1,7 +1,7 @@
-"""Per-phase cycle shares of conv_igemm_vs8_kernel (diagnostic library built by vs8_stamps.sh)."""
+"""Per-phase cycle shares of conv_igemm_vs8_kernel (diagnostic library built by scripts/probes/stamps_build.sh)."""
 import os, sys
 sys.path.insert(0, '.')
-os.environ["BRATS_HIP_LIB"] = os.path.abspath("brats21_amd/libbrats_hip_stamps8%s.so" % os.environ.get("SUFFIX", ""))
+os.environ.setdefault("BRATS_HIP_LIB", os.path.abspath("brats21_amd/libbrats_diag.so"))
 import torch
 cin, cout, s = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (48, 48, 128)))
 dev = torch.device("cuda:0")
