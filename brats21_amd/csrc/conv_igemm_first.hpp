@@ -95,14 +95,19 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(const ConvParams p, 
     }
   };
 
-  int t = blockIdx.x, cur = 0;
-  if (t < ntiles) dma_halo(t, 0);
+  // XCD-aware walk: workgroup b sits on XCD b % 8 (round-robin dispatch) and every XCD has its own L2, so each XCD takes ONE contiguous
+  // eighth of the tile list (x fastest, then y, z, n) and its workgroups walk it interleaved -- tiles that share halo lines are then
+  // fetched through one L2 instead of up to eight (PMC before: L2 hit 0.47, 168 MiB fetched for a 67 MB input)
+  const int per_xcd = (ntiles + 7) >> 3, wg_per_xcd = (int)gridDim.x >> 3;
+  const int t_lo = (blockIdx.x & 7) * per_xcd, t_hi = min(ntiles, t_lo + per_xcd);
+  int t = t_lo + ((int)blockIdx.x >> 3), cur = 0;
+  if (t < t_hi) dma_halo(t, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (also the weight fragments)
-  for (; t < ntiles; t += gridDim.x, cur ^= 1) {
+  for (; t < t_hi; t += wg_per_xcd, cur ^= 1) {
     // every wave has waited for its own pieces of this tile's halo (below / above); behind the barrier all of them are in LDS,
     // and every wave is past the previous tile's reads of the other halo buffer and of the output image
     __syncthreads();
-    if (t + (int)gridDim.x < ntiles) dma_halo(t + gridDim.x, cur ^ 1);  // lands behind the MFMAs and the epilogue
+    if (t + wg_per_xcd < t_hi) dma_halo(t + wg_per_xcd, cur ^ 1);  // lands behind the MFMAs and the epilogue
     const char* const halo = lds + cur * G::HALO_BYTES;
 
     f32x4 acc[NF][NB];
@@ -213,7 +218,7 @@ static int conv_launch_first(const ConvParams& p, hipStream_t st) {
     hipDeviceProp_t prop;
     cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  const int grid = ntiles < 2 * cus ? ntiles : 2 * cus;
+  const int grid = (ntiles < 2 * cus ? ntiles : 2 * cus) & ~7;  // (a multiple of 8: the same number of workgroups on every XCD; conv_first_ok wants >= 2048 tiles)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), FirstGeom::LDS_BYTES, st, p, ntiles);
   BRATS_CHECK_LAUNCH();
   return 0;
