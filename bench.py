@@ -746,6 +746,11 @@ def main():
         barrier()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    mine_elapsed = elapsed
+    if live:  # the headline quantity first: MAX over ranks of the timed region (everything below is accounting around it)
+        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
     # host side of a step, measured AFTER the timed region on an empty queue: how long this rank's Python / launch path needs to
     # enqueue three steps while the GPU is still busy with the first (inside the 50-step region the enqueue thread runs into the
     # full HIP queue and its time converges to the GPU's).  host_enqueue_ms close to ms_per_step = the eager step is bound by the
@@ -759,40 +764,39 @@ def main():
     torch.cuda.synchronize()
     ddp_info = None
     if buckets is not None:
-        # data-parallel accounting: per-rank step time, the collectives' stand-alone cost, and how much of it the overlap
-        # with the backward kernels hid (exposed = GPU time finish() waited for them in the sampled steps)
-        # (nothing is sampled under --graph: timing events cannot be recorded into a replayed graph -> exposed / overlap
-        #  are reported as null, never as a made-up 0.0 / 1.0)
-        exp_mine = buckets.exposed_ms()
-        mine = torch.tensor([elapsed / args.steps * 1e3, float("nan") if exp_mine is None else exp_mine, host_enqueue_ms,
-                             float(pin["n"]) if pin else 0.0], device=dev, dtype=torch.float64)
-        # ranks_seen: a 1 from every rank summed by the collective library itself (what the job's RCCL communicator spans)
-        ones = torch.ones(1, device=dev, dtype=torch.float32)
-        if live:
-            dist.all_reduce(ones)
-            both = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(both, mine)
-        else:
-            both = [mine]
-        ar = buckets.allreduce_ms()
-        exps = [float(b[1]) for b in both]
-        exposed = None if any(e != e for e in exps) else max(exps)  # NaN = not measured on that rank
-        ddp_info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "ranks_seen": int(round(float(ones.item()))),
-                    "backend": dist.get_backend() if dist.is_initialized() else None,
-                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-                    "ms_per_step_by_rank": [round(float(b[0]), 3) for b in both],
-                    "host_enqueue_ms_by_rank": [round(float(b[2]), 3) for b in both],
-                    "host_enqueue_ms": round(max(float(b[2]) for b in both), 3),
-                    "cpus_per_rank": [int(b[3]) for b in both], "cpu_pinning_rank0": pin,
-                    "buckets": len(buckets._plan),
-                    "payload_MB": round(buckets.payload_bytes() / 1e6, 1), "comm_dtype": str(buckets.comm_dtype).replace("torch.", ""),
-                    "allreduce_ms": round(ar, 3), "exposed_ms": None if exposed is None else round(exposed, 3),
-                    "overlap_frac": round(max(0.0, 1.0 - exposed / ar), 3) if (ar > 0 and exposed is not None) else None,
-                    "graph_captured_collectives": bool(args.graph)}
-    if live:
-        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+      try:  # (accounting only: whatever goes wrong here must not cost the line its headline)
+          # data-parallel accounting: per-rank step time, the collectives' stand-alone cost, and how much of it the overlap
+          # with the backward kernels hid (exposed = GPU time finish() waited for them in the sampled steps)
+          # (nothing is sampled under --graph: timing events cannot be recorded into a replayed graph -> exposed / overlap
+          #  are reported as null, never as a made-up 0.0 / 1.0)
+          exp_mine = buckets.exposed_ms()
+          mine = torch.tensor([mine_elapsed / args.steps * 1e3, float("nan") if exp_mine is None else exp_mine, host_enqueue_ms,
+                               float(pin["n"]) if pin else 0.0], device=dev, dtype=torch.float64)
+          # ranks_seen: a 1 from every rank summed by the collective library itself (what the job's RCCL communicator spans)
+          ones = torch.ones(1, device=dev, dtype=torch.float32)
+          if live:
+              dist.all_reduce(ones)
+              both = [torch.empty_like(mine) for _ in range(world)]
+              dist.all_gather(both, mine)
+          else:
+              both = [mine]
+          ar = buckets.allreduce_ms()
+          exps = [float(b[1]) for b in both]
+          exposed = None if any(e != e for e in exps) else max(exps)  # NaN = not measured on that rank
+          ddp_info = {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "ranks_seen": int(round(float(ones.item()))),
+                      "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                      "ms_per_step_by_rank": [round(float(b[0]), 3) for b in both],
+                      "host_enqueue_ms_by_rank": [round(float(b[2]), 3) for b in both],
+                      "host_enqueue_ms": round(max(float(b[2]) for b in both), 3),
+                      "cpus_per_rank": [int(b[3]) for b in both], "cpu_pinning_rank0": pin,
+                      "buckets": len(buckets._plan),
+                      "payload_MB": round(buckets.payload_bytes() / 1e6, 1), "comm_dtype": str(buckets.comm_dtype).replace("torch.", ""),
+                      "allreduce_ms": round(ar, 3), "exposed_ms": None if exposed is None else round(exposed, 3),
+                      "overlap_frac": round(max(0.0, 1.0 - exposed / ar), 3) if (ar > 0 and exposed is not None) else None,
+                      "graph_captured_collectives": bool(args.graph)}
+      except Exception as e:
+        ddp_info = {"error": repr(e)[:300]}
     if rank != 0:
         if live:
             dist.destroy_process_group()
